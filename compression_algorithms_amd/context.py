@@ -1,0 +1,66 @@
+"""One codec context per process-and-GPU (mi_ctx of include/mi_codec.h), plus the small
+torch plumbing the Python layer needs: device buffers are torch tensors, only their
+data_ptr() crosses the C ABI."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+class Context:
+    def __init__(self, device=0):
+        if not torch.cuda.is_available():
+            raise _lib.MiError(9, "no HIP device visible (the codec has no CPU fallback)")
+        self.device = torch.device("cuda", device)
+        self.L = _lib.lib()
+        h = C.c_void_p()
+        _lib.check(self.L.mi_ctx_create(C.byref(h), device), "mi_ctx_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mi_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def stream_ptr(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_profiling(self, on=True):
+        _lib.check(self.L.mi_set_profiling(self.h, 1 if on else 0), "mi_set_profiling")
+
+    def kernel_times(self):
+        arr = (_lib.KernelTime * 64)()
+        k = self.L.mi_get_kernel_times(self.h, arr, 64)
+        return [dict(name=arr[i].name.decode(), ms=arr[i].ms, launches=int(arr[i].launches), bytes=int(arr[i].bytes))
+                for i in range(k)]
+
+
+_default = {}
+
+
+def default_context(device=None):
+    if device is None:
+        device = torch.cuda.current_device()
+    if device not in _default:
+        _default[device] = Context(device)
+    return _default[device]
+
+
+def as_device_bytes(data, device):
+    """bytes / numpy / tensor -> contiguous uint8 tensor on `device`, 16-byte aligned"""
+    if isinstance(data, torch.Tensor):
+        t = data.to(device=device, dtype=torch.uint8).contiguous()
+    else:
+        import numpy as np
+        a = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        t = torch.from_numpy(np.ascontiguousarray(a).copy()).to(device)
+    if t.data_ptr() % 16:
+        t = t.clone()
+    return t

@@ -1,0 +1,72 @@
+// common.h — internal declarations shared by the HIP translation units of libmi_codec.so.
+// gfx950 (CDNA4) only: 64-wide wavefronts are assumed everywhere.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include <string>
+
+#include "../../include/mi_codec.h"
+
+#define MI_WAVE 64
+
+struct mi_prof_entry {
+    std::string name;
+    double      ms = 0.0;
+    uint64_t    launches = 0;
+    uint64_t    bytes = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::vector<uint64_t> pending_bytes;
+};
+
+struct mi_ctx {
+    int         device = 0;
+    hipStream_t stream = nullptr;       // the context's own stream
+    int         last_hip = 0;
+    int         profiling = 0;
+    int         num_cu = 256;
+    // workspace (device), grown on demand, never inside a captured region
+    void       *ws = nullptr;
+    size_t      ws_bytes = 0;
+    // small pinned host staging area for info structs
+    void       *h_pinned = nullptr;
+    size_t      h_pinned_bytes = 0;
+    std::vector<mi_prof_entry> prof;
+    std::vector<hipEvent_t>    event_pool;
+};
+
+#define MI_HIP(ctx, call)                                                     \
+    do {                                                                      \
+        hipError_t e__ = (call);                                              \
+        if (e__ != hipSuccess) {                                              \
+            (ctx)->last_hip = (int)e__;                                       \
+            return MI_ERR_HIP;                                                \
+        }                                                                     \
+    } while (0)
+
+// grow the context workspace to at least `bytes` (256-byte aligned carve-outs are the caller's job)
+mi_status mi_ws_reserve(mi_ctx *ctx, size_t bytes);
+
+// profiling: bracket a launch with events on the launch stream
+struct mi_prof_scope {
+    mi_ctx *ctx; int idx; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
+    mi_prof_scope(mi_ctx *c, const char *name, hipStream_t st, uint64_t bytes);
+    ~mi_prof_scope();
+};
+
+static inline size_t mi_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// simple carve-out allocator over the workspace
+struct mi_carver {
+    uint8_t *base; size_t off = 0;
+    explicit mi_carver(void *b) : base((uint8_t *)b) {}
+    template <typename T> T *take(size_t count) {
+        off = mi_align_up(off, 256);
+        T *p = (T *)(base + off);
+        off += count * sizeof(T);
+        return p;
+    }
+};

@@ -1,0 +1,142 @@
+// ctx.hip — context, workspace, error strings and kernel timing for libmi_codec.so.
+#include "common.h"
+
+extern "C" {
+
+const char *mi_version(void) { return "mi_codec 0.1 (gfx950)"; }
+
+const char *mi_status_str(mi_status s)
+{
+    switch (s) {
+    case MI_OK: return "ok";
+    case MI_ERR_ARG: return "bad argument";
+    case MI_ERR_HIP: return "HIP call failed";
+    case MI_ERR_NOMEM: return "out of memory";
+    case MI_ERR_CAPACITY: return "output buffer too small";
+    case MI_ERR_EMPTY_INPUT: return "empty input (reference: ERROR: Queue is empty)";
+    case MI_ERR_SINGLE_SYMBOL: return "single distinct symbol (reference: ERROR: No code for character)";
+    case MI_ERR_CODE_TOO_LONG: return "Huffman code longer than 32 bits";
+    case MI_ERR_CORRUPT: return "corrupt stream";
+    case MI_ERR_NO_DEVICE: return "no HIP device: this library has no CPU fallback";
+    }
+    return "unknown";
+}
+
+mi_status mi_ctx_create(mi_ctx **out, int device)
+{
+    if (!out) return MI_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
+        return MI_ERR_NO_DEVICE;
+    mi_ctx *c = new (std::nothrow) mi_ctx();
+    if (!c) return MI_ERR_NOMEM;
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete c; return MI_ERR_NO_DEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MI_ERR_HIP; }
+    c->h_pinned_bytes = 1 << 16;
+    if (hipHostMalloc(&c->h_pinned, c->h_pinned_bytes, hipHostMallocDefault) != hipSuccess) {
+        hipStreamDestroy(c->stream); delete c; return MI_ERR_NOMEM;
+    }
+    *out = c;
+    return MI_OK;
+}
+
+void mi_ctx_destroy(mi_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    for (auto &p : c->prof)
+        for (auto &ev : p.pending) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    for (auto e : c->event_pool) hipEventDestroy(e);
+    if (c->ws) hipFree(c->ws);
+    if (c->h_pinned) hipHostFree(c->h_pinned);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int mi_last_hip_error(const mi_ctx *c) { return c ? c->last_hip : 0; }
+
+mi_status mi_sync(mi_ctx *c, void *stream)
+{
+    if (!c) return MI_ERR_ARG;
+    MI_HIP(c, hipStreamSynchronize((hipStream_t)stream));
+    return MI_OK;
+}
+
+mi_status mi_set_profiling(mi_ctx *c, int on)
+{
+    if (!c) return MI_ERR_ARG;
+    c->profiling = on;
+    return MI_OK;
+}
+
+int mi_get_kernel_times(mi_ctx *c, mi_kernel_time *out, int cap)
+{
+    if (!c || !out) return 0;
+    int n = 0;
+    for (auto &p : c->prof) {
+        for (size_t i = 0; i < p.pending.size(); ++i) {
+            float ms = 0.f;
+            hipEventSynchronize(p.pending[i].second);
+            if (hipEventElapsedTime(&ms, p.pending[i].first, p.pending[i].second) == hipSuccess) {
+                p.ms += ms; p.launches += 1; p.bytes += p.pending_bytes[i];
+            }
+            c->event_pool.push_back(p.pending[i].first);
+            c->event_pool.push_back(p.pending[i].second);
+        }
+        p.pending.clear(); p.pending_bytes.clear();
+    }
+    for (auto &p : c->prof) {
+        if (!p.launches || n >= cap) continue;
+        out[n].name = p.name.c_str();
+        out[n].ms = p.ms / (double)p.launches;
+        out[n].launches = p.launches;
+        out[n].bytes = p.bytes;
+        ++n;
+        p.ms = 0; p.launches = 0; p.bytes = 0;
+    }
+    return n;
+}
+
+}  // extern "C"
+
+mi_status mi_ws_reserve(mi_ctx *c, size_t bytes)
+{
+    if (bytes <= c->ws_bytes) return MI_OK;
+    // growing frees the old block: only legal while nothing that uses it is in flight
+    MI_HIP(c, hipDeviceSynchronize());
+    if (c->ws) { MI_HIP(c, hipFree(c->ws)); c->ws = nullptr; c->ws_bytes = 0; }
+    size_t want = mi_align_up(bytes + bytes / 8, 1 << 20);
+    MI_HIP(c, hipMalloc(&c->ws, want));
+    c->ws_bytes = want;
+    return MI_OK;
+}
+
+static hipEvent_t take_event(mi_ctx *c)
+{
+    if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+
+mi_prof_scope::mi_prof_scope(mi_ctx *c, const char *name, hipStream_t st, uint64_t bytes) : ctx(c), idx(-1), s(st)
+{
+    if (!c->profiling) return;
+    for (size_t i = 0; i < c->prof.size(); ++i) if (c->prof[i].name == name) { idx = (int)i; break; }
+    if (idx < 0) { c->prof.emplace_back(); c->prof.back().name = name; idx = (int)c->prof.size() - 1; }
+    a = take_event(c); b = take_event(c);
+    c->prof[idx].pending_bytes.push_back(bytes);
+    hipEventRecord(a, s);
+}
+
+mi_prof_scope::~mi_prof_scope()
+{
+    if (idx < 0) return;
+    hipEventRecord(b, s);
+    ctx->prof[idx].pending.emplace_back(a, b);
+}

@@ -1,0 +1,60 @@
+"""Host-side mirror of the reference's Huffman interface (algorithms/huffman/huffman.h:90-113)
+over the HIP path.  `huffman_compress` keeps the reference's meaning — one tree over the
+whole buffer, tree-path codes, MSB-first u32 words — and returns what the reference returns
+through its BitWriter and root Node: the words, (word_idx, bit_idx, buffer_size) and the tree.
+Errors the reference reports with printf+exit(1) are raised as MiError with the same cause."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .context import as_device_bytes, default_context
+
+
+class HuffmanResult:
+    def __init__(self, words, info, tree):
+        self.words = words                      # uint32 tensor on the device, ceil(bits/32) long
+        self.total_bits = int(info.total_bits)
+        self.word_idx = int(info.word_idx)      # BitWriter.word_idx
+        self.bit_idx = int(info.bit_idx)        # BitWriter.bit_idx
+        self.buffer_size = int(info.buffer_size)  # BitWriter.buffer_size (huffman.c:318-320)
+        self.n_symbols = int(info.n_symbols)
+        self.max_code_len = int(info.max_code_len)
+        self.n_nodes = int(info.n_nodes)
+        self.codes = np.ctypeslib.as_array(tree.code).copy()
+        self.lengths = np.ctypeslib.as_array(tree.length).copy()
+        self.tree = tree
+
+    def preorder(self):
+        """(is_leaf, value, frequency) in pre-order, like walking the reference's Node tree"""
+        t = self.tree
+        out, stack = [], [self.n_nodes - 1]
+        while stack:
+            i = stack.pop()
+            leaf = t.left[i] < 0
+            out.append((1 if leaf else 0, int(t.value[i]), int(t.frequency[i])))
+            if not leaf:
+                stack.append(t.right[i])
+                stack.append(t.left[i])
+        return out
+
+
+def huffman_compress(data, ctx=None):
+    """data: bytes / numpy uint8 / uint8 tensor (device tensors are used in place)."""
+    ctx = ctx or default_context()
+    d_in = as_device_bytes(data, ctx.device)
+    n = d_in.numel()
+    cap = n + 2
+    words = torch.empty(cap, dtype=torch.int32, device=ctx.device)
+    d_info = torch.zeros(C.sizeof(_lib.HuffmanInfo), dtype=torch.uint8, device=ctx.device)
+    d_tree = torch.zeros(C.sizeof(_lib.HuffmanTree), dtype=torch.uint8, device=ctx.device)
+    st = ctx.L.mi_huffman_encode_dev(ctx.h, C.c_void_p(d_in.data_ptr() if n else 0), n, C.c_void_p(words.data_ptr()), cap,
+                                     C.c_void_p(d_info.data_ptr()), C.c_void_p(d_tree.data_ptr()), ctx.stream_ptr())
+    _lib.check(st, "mi_huffman_encode_dev")
+    info = _lib.HuffmanInfo.from_buffer_copy(d_info.cpu().numpy().tobytes())
+    if info.status != _lib.MI_OK:
+        raise _lib.MiError(info.status, "huffman_compress")
+    tree = _lib.HuffmanTree.from_buffer_copy(d_tree.cpu().numpy().tobytes())
+    nw = (info.total_bits + 31) // 32
+    return HuffmanResult(words[:nw], info, tree)

@@ -1,0 +1,188 @@
+/*
+ * mi_codec.h — C ABI of the MI355X-native block-parallel compressor core
+ * (libmi_codec.so: hand-written HIP kernels for gfx950 + this thin C layer).
+ *
+ * This is the drop-in boundary for the hot path of jdm365/Compression_Algorithms
+ * (SURVEY.md section 8b).  Plain pointers and sizes only; no torch / C++ types.
+ * Every entry point returns an mi_status instead of the reference's printf+exit(1).
+ * The reference-NAMED wrappers (lz77_compress, huffman_compress, compress, ...) that a
+ * maintainer links instead of the sources under algorithms/<dir>/ are declared in mi_lz77.h,
+ * mi_huffman.h, mi_deflate.h and mi_fse.h; each is a few lines over the functions here.
+ *
+ * Pointer conventions
+ *   d_*   device (HBM) pointers, caller-owned (hipMalloc / torch tensor.data_ptr()).
+ *   h_*   host pointers.
+ *   stream: a hipStream_t passed as void* (NULL = HIP's default stream, as everywhere in HIP).
+ *           The host-buffer convenience calls use a private stream of the context.
+ * All *_dev functions are asynchronous on `stream` unless stated; they never allocate
+ * (workspace lives in the context and grows only in mi_ctx_reserve / on first use of a
+ * larger size, before any launch), so a caller may capture them in a hipGraph.
+ */
+#ifndef MI_CODEC_H
+#define MI_CODEC_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    MI_OK = 0,
+    MI_ERR_ARG = 1,            /* bad argument (NULL, size, params out of range)           */
+    MI_ERR_HIP = 2,            /* a HIP call failed; mi_last_hip_error() has the code        */
+    MI_ERR_NOMEM = 3,
+    MI_ERR_CAPACITY = 4,       /* output buffer too small                                   */
+    MI_ERR_EMPTY_INPUT = 5,    /* reference: "ERROR: Queue is empty" exit(1)  huffman.c:149-152 */
+    MI_ERR_SINGLE_SYMBOL = 6,  /* reference: "ERROR: No code for character" exit(1) huffman.c:278-281 */
+    MI_ERR_CODE_TOO_LONG = 7,  /* a Huffman code > 32 bits: the reference silently emits garbage (u32 code) */
+    MI_ERR_CORRUPT = 8,        /* decoder: malformed stream                                  */
+    MI_ERR_NO_DEVICE = 9       /* no gfx950 device / HIP runtime: there is NO CPU fallback   */
+} mi_status;
+
+typedef struct mi_ctx mi_ctx;
+
+/* One context per process-and-GPU (one process per GPU is the deployment model). */
+mi_status   mi_ctx_create(mi_ctx **out, int device_ordinal);
+void        mi_ctx_destroy(mi_ctx *ctx);
+const char *mi_status_str(mi_status s);
+int         mi_last_hip_error(const mi_ctx *ctx);
+const char *mi_version(void);
+/* blocks until everything queued on `stream` has finished */
+mi_status   mi_sync(mi_ctx *ctx, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Huffman, whole buffer, one tree        replaces algorithms/huffman/huffman.c:288-328
+ *   histogram (huffman.c:184-187) -> heap-exact tree (:189-211) -> tree-path codes
+ *   (:217-250) -> MSB-first u32 words (:18-48)
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+    uint64_t total_bits;
+    uint64_t word_idx;          /* BitWriter.word_idx  = total_bits / 32                    */
+    uint64_t bit_idx;           /* BitWriter.bit_idx   = total_bits % 32                    */
+    uint64_t buffer_size;       /* BitWriter.buffer_size per huffman.c:318-320              */
+    uint32_t n_symbols;
+    uint32_t max_code_len;
+    uint32_t status;            /* mi_status decided on the device (empty / single / too long) */
+    uint32_t n_nodes;           /* tree nodes written to the tree arrays (<= 511)           */
+} mi_huffman_info;
+
+/* the tree in array form, node ids in creation order (leaves in symbol order, then merges);
+ * root = n_nodes-1.  Mirrors the reference's Node{value,frequency,left,right}. */
+typedef struct {
+    uint32_t frequency[511];
+    int16_t  left[511];         /* -1 for a leaf */
+    int16_t  right[511];
+    uint8_t  value[511];
+    uint8_t  pad;
+    uint32_t code[256];
+    uint8_t  length[256];
+} mi_huffman_tree;
+
+/* words needed for n input bytes in the worst case the ABI accepts (codes <= 32 bits) */
+static inline uint64_t mi_huffman_bound_words(uint64_t n) { return n + 2; }
+
+/* d_words must hold cap_words u32 (>= ceil(bits/32)+1).  Words [0, ceil(bits/32)) are fully defined
+ * (unused low bits of the last one are 0, as after init_bitwriter's memset); words past that are not touched.
+ * d_info / d_tree are device buffers of sizeof(mi_huffman_info) / sizeof(mi_huffman_tree). */
+mi_status mi_huffman_encode_dev(mi_ctx *ctx, const uint8_t *d_in, uint64_t n,
+                                uint32_t *d_words, uint64_t cap_words,
+                                mi_huffman_info *d_info, mi_huffman_tree *d_tree, void *stream);
+/* host-buffer convenience: copies in, encodes, copies out, synchronises. h_words: cap_words u32. */
+mi_status mi_huffman_encode(mi_ctx *ctx, const uint8_t *h_in, uint64_t n,
+                            uint32_t *h_words, uint64_t cap_words,
+                            mi_huffman_info *h_info, mi_huffman_tree *h_tree);
+/* decode exactly n symbols with the tree arrays; replaces huffman.c:330-364 */
+mi_status mi_huffman_decode_dev(mi_ctx *ctx, const uint32_t *d_words, uint64_t total_bits,
+                                const mi_huffman_tree *d_tree, uint32_t n_nodes,
+                                uint8_t *d_out, uint64_t n, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * LZ77 greedy tokenisers, block-parallel.
+ *   deflate flavour: algorithms/deflate/lz77.c:199-280 per block of `block` bytes with a
+ *     FRESH table per block (the sharded parity definition); byte tokens
+ *     {0,c} / {1,dlo,dhi,len} (lz77.c:176-197).
+ *   lz77 flavour: algorithms/lz77/lz77.c:264-345 per block; LSB-first bit tokens
+ *     1+8 / 1+wbits+lbits (lz77.c:290-330).
+ * A block is encoded as if followed by zero bytes (the reference reads past `size`).
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+    uint32_t wbits;       /* window bits: lz77 14 (shipped) or 16; deflate 15             */
+    uint32_t lbits;       /* length bits: lz77 4; deflate 5                               */
+    uint32_t tbits;       /* log2 table size: lz77 wbits+6; deflate 20                    */
+    uint32_t deflate;     /* 1: deflate rules (insert probe wraps, literal iff p-m >= W-1, byte tokens) */
+    uint32_t block;       /* block size in bytes, 1..65536                                */
+} mi_lz_params;
+
+static inline mi_lz_params mi_lz_params_deflate(void) { mi_lz_params p = {15, 5, 20, 1, 65536}; return p; }
+static inline mi_lz_params mi_lz_params_lz77(uint32_t wbits) { mi_lz_params p = {wbits, 4, wbits + 6, 0, 65536}; return p; }
+
+static inline uint64_t mi_lz_num_blocks(uint64_t n, const mi_lz_params *p) { return (n + p->block - 1) / p->block; }
+/* bound on the concatenated stream, in bytes */
+static inline uint64_t mi_lz_bound_bytes(uint64_t n, const mi_lz_params *p)
+{
+    return p->deflate ? 2 * n + 8 : (9 * n + 7) / 8 + 16;
+}
+
+/*
+ * Encode n bytes at d_in as ceil(n/block) independent blocks.
+ *   d_out        concatenated stream: deflate flavour = byte tokens of block 0,1,2,...;
+ *                lz77 flavour = the blocks' bit streams concatenated bit-contiguously
+ *                (block b starts at bit d_block_bits_excl[b]); zero-filled by the call.
+ *   d_block_bits u64[nblocks+1]: EXCLUSIVE prefix sum of per-block stream lengths in BITS
+ *                (deflate: 8 * bytes); entry nblocks = total.
+ */
+mi_status mi_lz_encode_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_in, uint64_t n,
+                           uint8_t *d_out, uint64_t cap_bytes, uint64_t *d_block_bits, void *stream);
+mi_status mi_lz_encode(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *h_in, uint64_t n,
+                       uint8_t *h_out, uint64_t cap_bytes, uint64_t *h_block_bits);
+/* decode; every block is truncated at its original length (an overshooting last match, A.3.4) */
+mi_status mi_lz_decode_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_stream,
+                           const uint64_t *d_block_bits, uint8_t *d_out, uint64_t n, void *stream);
+
+/* debugging / parity hooks used by the tests: find() at every position of every block
+ * (0xFFFF = none), i.e. the output of the match-finder stage alone. */
+mi_status mi_lz_find_all_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_in, uint64_t n,
+                             uint16_t *d_cand, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * FSE / tANS, block-parallel (fse/src/main.zig — an unfinished sketch; the stream format is
+ * defined by this build).  Record layout in include/mi_fse.h.
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+    uint32_t table_log;   /* 8 (reference TABLE_LOG) .. 12                                 */
+    uint32_t streams;     /* sub-streams per block, 1..64 (one GPU lane each)               */
+    uint32_t spread;      /* 0: contiguous symbol ranges (main.zig:159-177), 1: stride spread */
+    uint32_t block;       /* block size in bytes, 4..65536                                  */
+} mi_fse_params;
+
+static inline mi_fse_params mi_fse_params_default(void) { mi_fse_params p = {8, 64, 1, 65536}; return p; }
+uint64_t  mi_fse_block_bound(const mi_fse_params *p);        /* bytes per block record, worst case */
+/* d_out: nblocks records at stride mi_fse_block_bound(); d_sizes u32[nblocks] = used bytes.
+ * d_packed (optional, may be NULL): the records concatenated; d_offsets u64[nblocks+1]. */
+mi_status mi_fse_encode_dev(mi_ctx *ctx, const mi_fse_params *p, const uint8_t *d_in, uint64_t n,
+                            uint8_t *d_packed, uint64_t cap_bytes, uint64_t *d_offsets, void *stream);
+mi_status mi_fse_decode_dev(mi_ctx *ctx, const mi_fse_params *p, const uint8_t *d_packed,
+                            const uint64_t *d_offsets, uint8_t *d_out, uint64_t n, void *stream);
+/* the normalisation step alone (main.zig:106-149), for parity tests: d_freq u64[256] -> d_cnt u32[256] */
+mi_status mi_fse_normalise_dev(mi_ctx *ctx, const uint64_t *d_freq, uint32_t table_log, uint32_t *d_cnt, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * timing of the last *_dev call's dominant kernel, measured with hipEvents on the stream
+ * the kernels ran on (bench.py's roofline leg).  Enabled by mi_set_profiling(ctx, 1).
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+    const char *name;
+    double      ms;       /* average duration per launch                                   */
+    uint64_t    launches;
+    uint64_t    bytes;    /* algorithmic bytes the launches moved               */
+} mi_kernel_time;
+mi_status mi_set_profiling(mi_ctx *ctx, int on);
+/* returns the number of entries written (<= cap); resets the accumulators */
+int       mi_get_kernel_times(mi_ctx *ctx, mi_kernel_time *out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
