@@ -1,0 +1,174 @@
+// lz_common.h — shared pieces of the block-parallel LZ77 pipeline (lz_find.hip, lz_emit.hip).
+//
+// The reference's match finder (algorithms/lz77/lz77.c:55-108, algorithms/deflate/lz77.c:77-174)
+// is one candidate lookup in a 2^20..2^22 bucket linear-probing table with FIFO eviction and
+// no tombstones.  Because every position is inserted exactly once, in order, whatever the
+// parse does, find() at position p is a pure function of the block prefix, and the table
+// never has to exist: positions are sorted by home bucket, split into probe clusters that
+// cannot interact ("parking" bound), and each cluster is replayed in time order against a
+// dense occupancy bitmap held in LDS.  DESIGN.md has the argument and the measurements.
+#pragma once
+#include "common.h"
+
+#define LZ_MAX_BLOCK   65536u
+#define LZ_TAIL        64u            // zero bytes the reference would read past the block end
+#define LZ_NONE16      0xFFFFu
+
+// emulation tiles
+#define LZ_TILE_NOM    4096u          // nominal entries per tile (tile t = clusters that start in [t*NOM,(t+1)*NOM))
+#define LZ_TILE_CAP    8192u          // LDS capacity of a normal tile
+#define LZ_GIANT_MIN   (LZ_TILE_CAP - LZ_TILE_NOM)   // a cluster larger than this is replayed by k_lz_emulate_giant
+#define LZ_GIANT_CAP   18432u         // LDS capacity of the giant kernel; above: global-memory path
+#define LZ_MAX_TILES   (LZ_MAX_BLOCK / LZ_TILE_NOM)
+#define LZ_MAX_GIANTS_PER_BLOCK 16u
+
+struct LzP {
+    uint32_t wbits, lbits, tbits, deflate, block;
+};
+
+// per-block record written by k_lz_sort_home
+struct LzBlockMeta {
+    uint32_t n;            // bytes in this block
+    uint32_t ngroups;
+    uint32_t anom_idx;     // dense index of bucket 0 inside cluster 0 (spurious one-time clear), or ~0u
+    uint32_t limit_idx;    // dense index of bucket T inside cluster 0 (deflate find() must stop there), or ~0u
+    uint32_t rot;          // rotation applied to the home order (deflate insert wraps modulo T)
+    uint32_t pad[3];
+};
+
+// entry record, 64 bits: gid | pos << 16 | rloc << 32 | pid << 48
+//   gid   cluster number in home order        pos   position in the block (= time)
+//   rloc  dense bucket index of the home      pid   position of the first occurrence of the same word
+__device__ __forceinline__ uint64_t lz_pack(uint32_t gid, uint32_t pos, uint32_t rloc, uint32_t pid)
+{
+    return (uint64_t)gid | ((uint64_t)pos << 16) | ((uint64_t)rloc << 32) | ((uint64_t)pid << 48);
+}
+
+// per-batch scratch (device pointers into the context workspace); all per-block strides are fixed
+struct LzScratch {
+    uint16_t    *posA, *posB;      // [nb][65536]  sort by home, ping-pong
+    uint64_t    *eA, *eB;          // [nb][65536]  entry records, ping-pong of the sort by cluster
+    uint16_t    *cand;             // [nb][65536]  find() result per position
+    LzBlockMeta *meta;             // [nb]
+    uint32_t    *giant_count;      // [1]
+    uint32_t    *giant_list;       // [nb * LZ_MAX_GIANTS_PER_BLOCK][2] = {block, start index}
+    uint32_t    *slot;             // [nb][SLOT_WORDS] block-local token stream
+    uint64_t    *block_bits;       // [nb] bits produced per block (this batch)
+};
+#define LZ_SLOT_WORDS  (LZ_MAX_BLOCK / 2 + 16)     // 2 bytes per input byte worst case (+ slack), in u32
+
+// reference hash(): algorithms/lz77/lz77.c:13-41 == algorithms/deflate/lz77.c:14-42
+__device__ __forceinline__ uint32_t lz_mix32(uint32_t w)
+{
+    uint32_t k = w * 0xcc9e2d51u;
+    k = (k << 15) | (k >> 17);
+    k *= 0x1b873593u;
+    uint32_t h = (k << 13) | (k >> 19);
+    h = h * 5u + 0xe6546b64u;
+    h ^= h >> 16; h *= 0x85ebca6bu;
+    h ^= h >> 13; h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
+}
+
+// little-endian 32-bit word at an arbitrary byte offset of an LDS byte array (4-byte aligned base,
+// >= 8 readable bytes after the last valid offset)
+__device__ __forceinline__ uint32_t lds_word(const uint8_t *s, uint32_t p)
+{
+    const uint32_t *a = reinterpret_cast<const uint32_t *>(s + (p & ~3u));
+    const uint64_t v = (uint64_t)a[0] | ((uint64_t)a[1] << 32);
+    return (uint32_t)(v >> ((p & 3u) * 8u));
+}
+
+// ---- block-wide scans over 1024 threads (16 waves) -------------------------------------------
+template <typename T, typename Op>
+__device__ __forceinline__ T wave_inclusive_scan(T v, Op op)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        T t = __shfl_up(v, o);
+        if (lane >= o) v = op(v, t);
+    }
+    return v;
+}
+
+// exclusive scan across the block; `ident` is the identity; s_tmp needs nwaves+1 entries.
+// returns the exclusive prefix for this thread and the block total through *total.
+template <typename T, typename Op>
+__device__ __forceinline__ T block_exclusive_scan(T v, Op op, T ident, T *s_tmp, T *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    T inc = wave_inclusive_scan(v, op);
+    T exc = __shfl_up(inc, 1);
+    if (lane == 0) exc = ident;
+    if (lane == 63) s_tmp[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T run = ident;
+        for (int w = 0; w < nw; ++w) { T t = s_tmp[w]; s_tmp[w] = run; run = op(run, t); }
+        s_tmp[nw] = run;
+    }
+    __syncthreads();
+    T res = op(s_tmp[wave], exc);
+    *total = s_tmp[nw];
+    __syncthreads();
+    return res;
+}
+
+struct OpAddU32 { __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a + b; } };
+struct OpMaxI32 { __device__ int32_t operator()(int32_t a, int32_t b) const { return a > b ? a : b; } };
+
+// ---- one stable LSD radix pass over n elements held by a 1024-thread workgroup ----------------
+// Wave w owns the contiguous segment [w*seg, (w+1)*seg): per-wave digit counts -> offsets by a
+// (digit-major, wave-minor) scan -> each wave scatters its segment in order, ranking the 64
+// elements of a step with ballots; no workgroup barrier inside the scatter.
+//   load(i)  -> element (any trivially copyable type E) at input index i
+//   digit(e) -> 0 .. (1<<NBITS)-1
+//   store(j, e) writes element e to output index j
+template <int NBITS, typename E, typename Load, typename Digit, typename Store>
+__device__ __forceinline__ void radix_pass_1024(uint32_t n, uint32_t (*s_cnt)[256], Load load, Digit digit, Store store)
+{
+    constexpr int ND = 1 << NBITS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t seg = ((n + 1023u) / 1024u) * 64u;
+    const uint32_t a = wave * seg, b = (a + seg < n) ? a + seg : n;
+    for (int i = tid; i < 16 * 256; i += 1024) (&s_cnt[0][0])[i] = 0;
+    __syncthreads();
+    for (uint32_t i = a + lane; i < b; i += 64) atomicAdd(&s_cnt[wave][digit(load(i))], 1u);
+    __syncthreads();
+    // offsets: thread d < ND walks the 16 waves of digit d; then an exclusive scan over digits
+    uint32_t tot = 0;
+    if (tid < ND) {
+        for (int w = 0; w < 16; ++w) { uint32_t t = s_cnt[w][tid]; s_cnt[w][tid] = tot; tot += t; }
+    }
+    __shared__ uint32_t s_scan[18];
+    uint32_t total;
+    uint32_t base = block_exclusive_scan<uint32_t>(tid < ND ? tot : 0u, OpAddU32(), 0u, s_scan, &total);
+    if (tid < ND) {
+        for (int w = 0; w < 16; ++w) s_cnt[w][tid] += base;
+    }
+    __syncthreads();
+    for (uint32_t i0 = a; i0 < b; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        const bool valid = i < b;
+        E e{};
+        uint32_t d = 0;
+        if (valid) { e = load(i); d = digit(e); }
+        uint64_t mask = __ballot(valid);
+#pragma unroll
+        for (int k = 0; k < NBITS; ++k) {
+            const bool bit = (d >> k) & 1u;
+            const uint64_t bal = __ballot(valid && bit);
+            mask &= bit ? bal : ~bal;
+        }
+        const uint64_t below = mask & ((1ull << lane) - 1ull);
+        const uint32_t rank = __popcll(below), cnt = __popcll(mask);
+        const int leader = __ffsll((unsigned long long)mask) - 1;
+        uint32_t old = 0;
+        if (valid && lane == leader) old = atomicAdd(&s_cnt[wave][d], cnt);
+        old = __shfl(old, leader < 0 ? 0 : leader);
+        if (valid) store(old + rank, e);
+    }
+    __syncthreads();
+}

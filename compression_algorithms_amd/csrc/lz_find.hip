@@ -1,0 +1,495 @@
+// lz_find.hip — the reference's hash-table match finder, replayed without the table.
+//
+// Replaces, per block: hash (algorithms/lz77/lz77.c:13-41), insert_hash_table (:55-86,
+// deflate variant algorithms/deflate/lz77.c:77-145) and find (:94-108 / deflate :147-174)
+// as driven by lz77_compress (lz77.c:281-338 / deflate lz77.c:215-275).
+//
+//   k_lz_sort_home       block -> LDS; positions sorted by (home bucket, time) with three
+//                        stable 8-bit radix passes; probe clusters by a prefix-max ("parking")
+//                        sweep; per position {cluster, dense home index, word id}
+//   k_lz_sort_cluster    entries sorted by (cluster, time): two stable 8-bit radix passes
+//   k_lz_emulate         a tile of clusters in LDS; one lane replays one cluster in time
+//                        order: FIFO eviction, find, first-fit insert on an occupancy bitmap
+//   k_lz_emulate_giant   clusters too large for a tile (one workgroup each)
+//
+// Output: cand[p] = what find(word at p) returns in the table state after positions 0..p-1
+// were inserted (0xFFFF = none).  The parse consumes it in lz_emit.hip.
+#include "lz_common.h"
+
+// =============================================================================================
+// k_lz_sort_home
+// =============================================================================================
+__global__ __launch_bounds__(1024)
+void k_lz_sort_home(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, LzScratch sc, uint64_t block0)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[LZ_MAX_BLOCK + LZ_TAIL + 16];
+    __shared__ uint32_t s_cnt[16][256];
+    __shared__ int32_t  s_i32[18];
+    __shared__ uint32_t s_u32[18];
+    __shared__ uint32_t s_rot;
+
+    const int tid = threadIdx.x;
+    const uint32_t lb = blockIdx.x;
+    const uint64_t off = (block0 + lb) * (uint64_t)P.block;
+    const uint32_t n = (uint32_t)((n_total - off) < P.block ? (n_total - off) : P.block);
+    const uint8_t *src = in + off;
+    const uint32_t T = 1u << P.tbits, Tmask = T - 1u;
+
+    // ---- block -> LDS, zero tail (the reference reads past `size`; the parity definition is zeros)
+    const bool vec_ok = (((uintptr_t)src) & 15u) == 0;
+    for (uint32_t i = tid * 16u; i < LZ_MAX_BLOCK + LZ_TAIL; i += 1024u * 16u) {
+        if (vec_ok && i + 16u <= n) {
+            *reinterpret_cast<uint4 *>(s_in + i) = *reinterpret_cast<const uint4 *>(src + i);
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < 16; ++k) s_in[i + k] = (i + k < n) ? src[i + k] : (uint8_t)0;
+        }
+    }
+    if (tid < 16) s_in[LZ_MAX_BLOCK + LZ_TAIL + tid] = 0;
+    if (tid == 0) s_rot = 0;
+    __syncthreads();
+
+    uint16_t *A = sc.posA + (size_t)lb * LZ_MAX_BLOCK;
+    uint16_t *B = sc.posB + (size_t)lb * LZ_MAX_BLOCK;
+    auto home_of = [&](uint32_t p) -> uint32_t { return lz_mix32(lds_word(s_in, p)) & Tmask; };
+
+    // ---- sort positions by home, stable in time: identity -> A -> B -> A
+    radix_pass_1024<8, uint32_t>(n, s_cnt,
+        [&](uint32_t i) { return i; },
+        [&](uint32_t e) { return home_of(e) & 255u; },
+        [&](uint32_t j, uint32_t e) { A[j] = (uint16_t)e; });
+    radix_pass_1024<8, uint32_t>(n, s_cnt,
+        [&](uint32_t i) { return (uint32_t)A[i]; },
+        [&](uint32_t e) { return (home_of(e) >> 8) & 255u; },
+        [&](uint32_t j, uint32_t e) { B[j] = (uint16_t)e; });
+    radix_pass_1024<8, uint32_t>(n, s_cnt,
+        [&](uint32_t i) { return (uint32_t)B[i]; },
+        [&](uint32_t e) { return (home_of(e) >> 16) & 255u; },
+        [&](uint32_t j, uint32_t e) { A[j] = (uint16_t)e; });
+
+    // ---- cluster sweep over the sorted order (logical index k; `rot` rotates the order when a
+    //      deflate-style cluster wraps past bucket T-1 into bucket 0)
+    const uint32_t k0 = tid * 64u, k1 = (k0 + 64u < n) ? k0 + 64u : n;
+    uint32_t rot = 0;
+    uint32_t gid_base = 0, ngroups = 0;
+    int32_t  premax = INT32_MIN, gs_carry = -1, hs_carry = -1;
+    int32_t  gmax_total = INT32_MIN;
+    for (int iter = 0; iter < 2; ++iter) {
+        auto phys = [&](uint32_t k) { uint32_t p = k + rot; return p >= n ? p - n : p; };
+        auto hk_at = [&](uint32_t k, uint32_t &pos) -> int32_t {
+            const uint32_t ph = phys(k);
+            pos = A[ph];
+            int32_t h = (int32_t)home_of(pos);
+            if (rot && ph >= rot) h -= (int32_t)T;
+            return h;
+        };
+        // (a) chunk maximum of g = home - k
+        int32_t m = INT32_MIN;
+        for (uint32_t k = k0; k < k1; ++k) { uint32_t pos; int32_t g = hk_at(k, pos) - (int32_t)k; m = g > m ? g : m; }
+        premax = block_exclusive_scan<int32_t>(m, OpMaxI32(), INT32_MIN, s_i32, &gmax_total);
+        // (b) heads and home-run starts of the chunk
+        uint32_t nheads = 0; int32_t lasthead = -1, lastrun = -1;
+        {
+            int32_t run = premax, prev_h = 0;
+            if (k0 > 0 && k0 < n) { uint32_t pp; prev_h = hk_at(k0 - 1, pp); }
+            for (uint32_t k = k0; k < k1; ++k) {
+                uint32_t pos; const int32_t h = hk_at(k, pos), g = h - (int32_t)k;
+                const bool head = (k == 0) || (g >= run);
+                run = g > run ? g : run;
+                if (head) { ++nheads; lasthead = (int32_t)k; }
+                if (k == 0 || h != prev_h) lastrun = (int32_t)k;
+                prev_h = h;
+            }
+        }
+        uint32_t total_heads; int32_t last_group_start, dummy;
+        gid_base = block_exclusive_scan<uint32_t>(nheads, OpAddU32(), 0u, s_u32, &total_heads);
+        gs_carry = block_exclusive_scan<int32_t>(lasthead, OpMaxI32(), -1, s_i32, &last_group_start);
+        hs_carry = block_exclusive_scan<int32_t>(lastrun, OpMaxI32(), -1, s_i32, &dummy);
+        ngroups = total_heads;
+        const int64_t e_last = (int64_t)gmax_total + (int64_t)n;
+        if (iter == 0 && P.deflate && e_last > (int64_t)T && last_group_start > 0) {
+            rot = (uint32_t)last_group_start;           // uniform: every thread computes the same value
+            continue;
+        }
+        // (c) emit one record per position
+        {
+            uint64_t *E = sc.eA + (size_t)lb * LZ_MAX_BLOCK;
+            uint16_t *cand = sc.cand + (size_t)lb * LZ_MAX_BLOCK;
+            int32_t run = premax, prev_h = 0;
+            uint32_t cur_gs = 0, cur_gid = gid_base; int32_t cur_base = 0;
+            uint32_t cur_hs = 0, hs_word = 0, hs_pos = 0;
+            if (k0 < n) {
+                uint32_t pp;
+                if (k0 > 0) prev_h = hk_at(k0 - 1, pp);
+                if (gs_carry >= 0) { cur_gs = (uint32_t)gs_carry; cur_base = hk_at(cur_gs, pp); cur_gid = gid_base - 1u; }
+                if (hs_carry >= 0) { cur_hs = (uint32_t)hs_carry; (void)hk_at(cur_hs, hs_pos); hs_word = lds_word(s_in, hs_pos); }
+            }
+            uint32_t seen = 0;
+            for (uint32_t k = k0; k < k1; ++k) {
+                uint32_t pos; const int32_t h = hk_at(k, pos), g = h - (int32_t)k;
+                const bool head = (k == 0) || (g >= run);
+                run = g > run ? g : run;
+                const uint32_t w = lds_word(s_in, pos);
+                if (head) { cur_gs = k; cur_base = h; cur_gid = gid_base + seen; ++seen; }
+                uint32_t pid;
+                if (k == 0 || h != prev_h) { cur_hs = k; hs_word = w; hs_pos = pos; pid = pos; }
+                else if (w == hs_word) pid = hs_pos;
+                else {                                     // two different words share a home bucket: rare
+                    pid = pos;
+                    for (uint32_t kk = cur_hs + 1; kk < k; ++kk) {
+                        uint32_t p2; (void)hk_at(kk, p2);
+                        if (lds_word(s_in, p2) == w) { pid = p2; break; }
+                    }
+                }
+                prev_h = h;
+                const uint32_t rloc = cur_gs + (uint32_t)(h - cur_base);
+                E[pos] = lz_pack(cur_gid, pos, rloc, pid);
+                cand[pos] = LZ_NONE16;
+            }
+        }
+        if (tid == 0) {
+            LzBlockMeta mt;
+            mt.n = n; mt.ngroups = ngroups; mt.rot = rot;
+            mt.anom_idx = ~0u; mt.limit_idx = ~0u;
+            uint32_t p0; const int32_t h0 = hk_at(0, p0);
+            const bool cross = P.deflate && (rot > 0 || (e_last > (int64_t)T && ngroups == 1));
+            if (cross) {
+                const uint32_t raw = home_of(p0);
+                mt.anom_idx = T - raw; mt.limit_idx = T - raw;
+            } else if (h0 == 0) {
+                mt.anom_idx = 0;
+            }
+            mt.pad[0] = mt.pad[1] = mt.pad[2] = 0;
+            sc.meta[lb] = mt;
+        }
+        break;
+    }
+}
+
+// =============================================================================================
+// k_lz_sort_cluster: (cluster, time) order.  Input records sit at index = position, i.e. in
+// time order, so two stable passes over the 16-bit cluster number are enough.
+// =============================================================================================
+__global__ __launch_bounds__(1024)
+void k_lz_sort_cluster(LzScratch sc)
+{
+    __shared__ uint32_t s_cnt[16][256];
+    const uint32_t lb = blockIdx.x;
+    const uint32_t n = sc.meta[lb].n;
+    uint64_t *A = sc.eA + (size_t)lb * LZ_MAX_BLOCK;
+    uint64_t *B = sc.eB + (size_t)lb * LZ_MAX_BLOCK;
+    radix_pass_1024<8, uint64_t>(n, s_cnt,
+        [&](uint32_t i) { return A[i]; },
+        [&](uint64_t e) { return (uint32_t)e & 255u; },
+        [&](uint32_t j, uint64_t e) { B[j] = e; });
+    radix_pass_1024<8, uint64_t>(n, s_cnt,
+        [&](uint32_t i) { return B[i]; },
+        [&](uint64_t e) { return ((uint32_t)e >> 8) & 255u; },
+        [&](uint32_t j, uint64_t e) { A[j] = e; });
+}
+
+// =============================================================================================
+// cluster replay
+// =============================================================================================
+// LDS image of a set of clusters, indices are dense "slots": entry i's home bucket is slot
+// rs[i] (before its insertion; afterwards rs[i] holds the slot it occupies).  A cluster of m
+// entries owns exactly m consecutive slots and can never need more (parking bound).
+struct TileView {
+    uint16_t *pos, *rs, *pid, *occ;
+    uint32_t *bm;           // occupancy bits, one per slot
+    uint32_t  n;            // entries (= slots) in the view
+};
+#define RS_HEAD 0x8000u
+#define RS_MASK 0x7FFFu
+
+__device__ __forceinline__ bool bm_test(const uint32_t *bm, uint32_t b) { return (bm[b >> 5] >> (b & 31u)) & 1u; }
+
+// first zero bit at or after r (exists inside the cluster by the parking bound)
+__device__ __forceinline__ uint32_t bm_next_zero(const uint32_t *bm, uint32_t r)
+{
+    uint32_t wi = r >> 5;
+    uint32_t w = bm[wi] | ((1u << (r & 31u)) - 1u);
+    while (w == 0xFFFFFFFFu) w = bm[++wi];
+    return (wi << 5) + (uint32_t)__builtin_ctz(~w);
+}
+
+// replay entries [s, e) of the view (one cluster) in time order.  anom / limit: slot of bucket 0 /
+// bucket T for the cluster that contains them (else ~0u).
+__device__ void replay_cluster(const TileView &v, uint32_t s, uint32_t e, uint32_t W, uint32_t anom, uint32_t limit,
+                               uint16_t *__restrict__ cand)
+{
+    uint32_t ev = s;
+    bool anom_pending = anom != ~0u;
+    for (uint32_t i = s; i < e; ++i) {
+        const uint32_t p = v.pos[i];
+        const uint32_t rsv = v.rs[i];
+        const uint32_t r = rsv & RS_MASK;
+        const uint32_t pid = v.pid[i];
+        // FIFO eviction: insertion k retires insertion k-W *after* writing, so what find/insert at
+        // p see is everything inserted at or after p-W  (lz77.c:70-76)
+        while (ev < i && (uint32_t)v.pos[ev] + W < p) {
+            const uint32_t b = v.rs[ev] & RS_MASK;
+            atomicAnd(&v.bm[b >> 5], ~(1u << (b & 31u)));       // clears the BUCKET, whoever sits there
+            ++ev;
+        }
+        // the ring starts zero-filled, so insertion W-1 clears bucket 0 once
+        if (anom_pending && p > W - 1u) {
+            atomicAnd(&v.bm[anom >> 5], ~(1u << (anom & 31u)));
+            anom_pending = false;
+        }
+        // find: first slot from the home that is empty (-> none) or holds the same word
+        uint32_t res = LZ_NONE16;
+        for (uint32_t b = r;; ++b) {
+            if (b == limit && r < limit) break;                 // deflate find() does not wrap past T-1
+            if (!bm_test(v.bm, b)) break;
+            const uint32_t o = v.occ[b];
+            if (v.pid[o] == pid) { res = v.pos[o]; break; }
+        }
+        if (res != LZ_NONE16) cand[p] = (uint16_t)res;
+        // insert: first free slot from the home
+        const uint32_t b = bm_next_zero(v.bm, r);
+        atomicOr(&v.bm[b >> 5], 1u << (b & 31u));
+        v.occ[b] = (uint16_t)i;
+        v.rs[i] = (uint16_t)((rsv & RS_HEAD) | b);
+    }
+}
+
+__global__ __launch_bounds__(512)
+void k_lz_emulate(LzP P, LzScratch sc)
+{
+    __shared__ uint16_t s_pos[LZ_TILE_CAP], s_rs[LZ_TILE_CAP], s_pid[LZ_TILE_CAP], s_occ[LZ_TILE_CAP];
+    __shared__ uint32_t s_bm[LZ_TILE_CAP / 32 + 2];
+    __shared__ uint32_t s_a, s_b, s_lasthead, s_giant;
+
+    const int tid = threadIdx.x;
+    const uint32_t lb = blockIdx.y, t = blockIdx.x;
+    const LzBlockMeta mt = sc.meta[lb];
+    const uint32_t n = mt.n;
+    const uint32_t lo = t * LZ_TILE_NOM, hi = (lo + LZ_TILE_NOM < n) ? lo + LZ_TILE_NOM : n;
+    if (lo >= n) return;
+    const uint64_t *E = sc.eA + (size_t)lb * LZ_MAX_BLOCK;
+    auto gid_at = [&](uint32_t i) { return (uint32_t)E[i] & 0xFFFFu; };
+    auto is_head = [&](uint32_t i) { return i == 0 || gid_at(i) != gid_at(i - 1); };
+
+    if (tid == 0) { s_a = ~0u; s_b = ~0u; s_lasthead = 0; s_giant = 0; }
+    __syncthreads();
+    // a = first head in [lo, hi)
+    for (uint32_t i = lo + tid; i < hi; i += 512) if (is_head(i)) atomicMin(&s_a, i);
+    __syncthreads();
+    const uint32_t a = s_a;
+    if (a == ~0u) return;                       // a cluster that started earlier covers this whole range
+    // b = first head at or after hi (or n); give up after LZ_GIANT_MIN entries: the last cluster is a giant
+    for (uint32_t i = hi + tid; i < n && i <= hi + LZ_GIANT_MIN; i += 512) if (is_head(i)) atomicMin(&s_b, i);
+    for (uint32_t i = a + tid; i < hi; i += 512) if (is_head(i)) atomicMax(&s_lasthead, i);
+    __syncthreads();
+    uint32_t b = s_b;
+    if (b == ~0u) b = (n <= hi + LZ_GIANT_MIN) ? n : ~0u;
+    const uint32_t lasthead = s_lasthead;
+    if (b == ~0u || b - lasthead > LZ_GIANT_MIN || b - a > LZ_TILE_CAP) {
+        // the cluster that starts at `lasthead` is too large for this tile: hand it to the giant kernel
+        if (tid == 0) {
+            const uint32_t k = atomicAdd(sc.giant_count, 1u);
+            sc.giant_list[2 * k] = lb; sc.giant_list[2 * k + 1] = lasthead;
+        }
+        b = lasthead;
+    }
+    const uint32_t m = b - a;
+    if (m == 0) return;
+    // ---- load the tile
+    for (uint32_t i = tid; i < m; i += 512) {
+        const uint64_t e = E[a + i];
+        const uint32_t gid = (uint32_t)e & 0xFFFFu;
+        const bool head = (i == 0) || (((uint32_t)E[a + i - 1] & 0xFFFFu) != gid);
+        s_pos[i] = (uint16_t)(e >> 16);
+        s_rs[i] = (uint16_t)((((uint32_t)(e >> 32) & 0xFFFFu) - a) | (head ? RS_HEAD : 0u));
+        s_pid[i] = (uint16_t)(e >> 48);
+    }
+    for (uint32_t i = tid; i < LZ_TILE_CAP / 32 + 2; i += 512) s_bm[i] = 0;
+    __syncthreads();
+    // pid is a POSITION (first occurrence of the word); compare through it directly
+    TileView v{s_pos, s_rs, s_pid, s_occ, s_bm, m};
+    const uint32_t W = 1u << P.wbits;
+    uint16_t *cand = sc.cand + (size_t)lb * LZ_MAX_BLOCK;
+    for (uint32_t s = tid; s < m; s += 512) {
+        if (!(s_rs[s] & RS_HEAD)) continue;
+        uint32_t e = s + 1;
+        while (e < m && !(s_rs[e] & RS_HEAD)) ++e;
+        if (e - s < 2) continue;                 // a lone entry finds nothing and blocks nobody
+        const bool first = (a + s) == 0;
+        replay_cluster(v, s, e, W, first ? mt.anom_idx : ~0u, first ? mt.limit_idx : ~0u, cand);
+    }
+}
+
+// one workgroup per giant cluster.  <= LZ_GIANT_CAP entries: same replay from LDS, lane 0.
+// Larger: slots/occupants live in global scratch (eB, free after the sort), bitmap in LDS.
+__global__ __launch_bounds__(256)
+void k_lz_emulate_giant(LzP P, LzScratch sc)
+{
+    __shared__ uint16_t s_pos[LZ_GIANT_CAP], s_rs[LZ_GIANT_CAP], s_pid[LZ_GIANT_CAP], s_occ[LZ_GIANT_CAP];
+    __shared__ uint32_t s_bm[LZ_MAX_BLOCK / 32 + 2];
+    __shared__ uint32_t s_end;
+    const int tid = threadIdx.x;
+    const uint32_t count = *sc.giant_count;
+    for (uint32_t g = blockIdx.x; g < count; g += gridDim.x) {
+        const uint32_t lb = sc.giant_list[2 * g], a = sc.giant_list[2 * g + 1];
+        const LzBlockMeta mt = sc.meta[lb];
+        const uint32_t n = mt.n;
+        const uint64_t *E = sc.eA + (size_t)lb * LZ_MAX_BLOCK;
+        const uint32_t gid = (uint32_t)E[a] & 0xFFFFu;
+        __syncthreads();
+        if (tid == 0) s_end = n;
+        __syncthreads();
+        for (uint32_t i = a + 1 + tid; i < n; i += 256) if (((uint32_t)E[i] & 0xFFFFu) != gid) { atomicMin(&s_end, i); break; }
+        __syncthreads();
+        const uint32_t b = s_end, m = b - a;
+        const uint32_t W = 1u << P.wbits;
+        uint16_t *cand = sc.cand + (size_t)lb * LZ_MAX_BLOCK;
+        const bool first = a == 0;
+        const uint32_t anom = first ? mt.anom_idx : ~0u, limit = first ? mt.limit_idx : ~0u;
+        for (uint32_t i = tid; i < LZ_MAX_BLOCK / 32 + 2; i += 256) s_bm[i] = 0;
+        if (m <= LZ_GIANT_CAP) {
+            for (uint32_t i = tid; i < m; i += 256) {
+                const uint64_t e = E[a + i];
+                s_pos[i] = (uint16_t)(e >> 16);
+                s_rs[i] = (uint16_t)((((uint32_t)(e >> 32) & 0xFFFFu) - a) | (i == 0 ? RS_HEAD : 0u));
+                s_pid[i] = (uint16_t)(e >> 48);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                TileView v{s_pos, s_rs, s_pid, s_occ, s_bm, m};
+                replay_cluster(v, 0, m, W, anom, limit, cand);
+            }
+        } else {
+            // global-memory replay: slot[] and occ[] (u16 each) carved from this block's eB
+            __syncthreads();
+            if (tid == 0) {
+                uint16_t *slot = reinterpret_cast<uint16_t *>(sc.eB + (size_t)lb * LZ_MAX_BLOCK);
+                uint16_t *occ = slot + LZ_MAX_BLOCK;
+                uint32_t ev = 0;
+                bool anom_pending = anom != ~0u;
+                for (uint32_t i = 0; i < m; ++i) {
+                    const uint64_t e = E[a + i];
+                    const uint32_t p = (uint32_t)(e >> 16) & 0xFFFFu, r = ((uint32_t)(e >> 32) & 0xFFFFu) - a;
+                    const uint32_t pid = (uint32_t)(e >> 48);
+                    while (ev < i && (((uint32_t)(E[a + ev] >> 16)) & 0xFFFFu) + W < p) {
+                        const uint32_t bb = slot[ev];
+                        s_bm[bb >> 5] &= ~(1u << (bb & 31u));
+                        ++ev;
+                    }
+                    if (anom_pending && p > W - 1u) { s_bm[anom >> 5] &= ~(1u << (anom & 31u)); anom_pending = false; }
+                    uint32_t res = LZ_NONE16;
+                    for (uint32_t bb = r;; ++bb) {
+                        if (bb == limit && r < limit) break;
+                        if (!bm_test(s_bm, bb)) break;
+                        const uint64_t oe = E[a + occ[bb]];
+                        if ((uint32_t)(oe >> 48) == pid) { res = (uint32_t)(oe >> 16) & 0xFFFFu; break; }
+                    }
+                    if (res != LZ_NONE16) cand[p] = (uint16_t)res;
+                    const uint32_t bb = bm_next_zero(s_bm, r);
+                    s_bm[bb >> 5] |= 1u << (bb & 31u);
+                    occ[bb] = (uint16_t)i;
+                    slot[i] = (uint16_t)bb;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// =============================================================================================
+// host side of the match finder
+// =============================================================================================
+size_t lz_scratch_bytes(uint32_t nb)
+{
+    size_t per = (size_t)LZ_MAX_BLOCK * (2 + 2 + 8 + 8 + 2) + sizeof(LzBlockMeta) + LZ_MAX_GIANTS_PER_BLOCK * 8 +
+                 (size_t)LZ_SLOT_WORDS * 4 + 8;
+    return per * nb + 16 * 256 + 4096;
+}
+
+void lz_carve(mi_ctx *ctx, uint32_t nb, LzScratch *sc)
+{
+    mi_carver cv(ctx->ws);
+    sc->posA = cv.take<uint16_t>((size_t)nb * LZ_MAX_BLOCK);
+    sc->posB = cv.take<uint16_t>((size_t)nb * LZ_MAX_BLOCK);
+    sc->eA = cv.take<uint64_t>((size_t)nb * LZ_MAX_BLOCK);
+    sc->eB = cv.take<uint64_t>((size_t)nb * LZ_MAX_BLOCK);
+    sc->cand = cv.take<uint16_t>((size_t)nb * LZ_MAX_BLOCK);
+    sc->meta = cv.take<LzBlockMeta>(nb);
+    sc->giant_count = cv.take<uint32_t>(64);
+    sc->giant_list = cv.take<uint32_t>((size_t)nb * LZ_MAX_GIANTS_PER_BLOCK * 2);
+    sc->slot = cv.take<uint32_t>((size_t)nb * LZ_SLOT_WORDS);
+    sc->block_bits = cv.take<uint64_t>(nb + 1);
+}
+
+mi_status lz_check_params(const mi_lz_params *p)
+{
+    if (!p) return MI_ERR_ARG;
+    if (p->wbits < 8 || p->wbits > 16) return MI_ERR_ARG;
+    if (p->lbits < 3 || p->lbits > 8) return MI_ERR_ARG;
+    if (p->tbits < 17 || p->tbits > 24) return MI_ERR_ARG;
+    if (p->block < 1 || p->block > LZ_MAX_BLOCK) return MI_ERR_ARG;
+    if (p->deflate && (1u + p->wbits + p->lbits > 32 || p->lbits > 8)) return MI_ERR_ARG;
+    return MI_OK;
+}
+
+// runs the match finder for blocks [block0, block0+nb) of the input; cand lands in sc->cand
+mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
+                        const LzScratch &sc, hipStream_t s)
+{
+    MI_HIP(ctx, hipMemsetAsync(sc.giant_count, 0, 4, s));
+    {
+        mi_prof_scope p(ctx, "k_lz_sort_home", s, (uint64_t)nb * P.block);
+        hipLaunchKernelGGL(k_lz_sort_home, dim3(nb), dim3(1024), 0, s, d_in, n, P, sc, block0);
+    }
+    {
+        mi_prof_scope p(ctx, "k_lz_sort_cluster", s, (uint64_t)nb * P.block);
+        hipLaunchKernelGGL(k_lz_sort_cluster, dim3(nb), dim3(1024), 0, s, sc);
+    }
+    {
+        mi_prof_scope p(ctx, "k_lz_emulate", s, (uint64_t)nb * P.block);
+        const uint32_t tiles = (P.block + LZ_TILE_NOM - 1) / LZ_TILE_NOM;
+        hipLaunchKernelGGL(k_lz_emulate, dim3(tiles, nb), dim3(512), 0, s, P, sc);
+    }
+    {
+        mi_prof_scope p(ctx, "k_lz_emulate_giant", s, (uint64_t)nb * P.block);
+        const uint32_t grid = nb < 1024 ? nb : 1024;
+        hipLaunchKernelGGL(k_lz_emulate_giant, dim3(grid), dim3(256), 0, s, P, sc);
+    }
+    MI_HIP(ctx, hipGetLastError());
+    return MI_OK;
+}
+
+uint32_t lz_batch_blocks(uint64_t nblocks)
+{
+    const uint64_t cap = 512;
+    return (uint32_t)(nblocks < cap ? (nblocks ? nblocks : 1) : cap);
+}
+
+extern "C" mi_status mi_lz_find_all_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_in, uint64_t n,
+                                        uint16_t *d_cand, void *stream)
+{
+    if (!ctx || !d_in || !d_cand) return MI_ERR_ARG;
+    mi_status st = lz_check_params(p);
+    if (st) return st;
+    if (n == 0) return MI_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block};
+    const uint64_t nblocks = (n + P.block - 1) / P.block;
+    const uint32_t nbmax = lz_batch_blocks(nblocks);
+    st = mi_ws_reserve(ctx, lz_scratch_bytes(nbmax));
+    if (st) return st;
+    LzScratch sc;
+    lz_carve(ctx, nbmax, &sc);
+    for (uint64_t b0 = 0; b0 < nblocks; b0 += nbmax) {
+        const uint32_t nb = (uint32_t)((nblocks - b0) < nbmax ? (nblocks - b0) : nbmax);
+        st = lz_find_batch(ctx, P, d_in, n, b0, nb, sc, s);
+        if (st) return st;
+        // cand rows are LZ_MAX_BLOCK apart in scratch; the caller's array is block-size apart
+        for (uint32_t i = 0; i < nb; ++i) {
+            const uint64_t off = (b0 + i) * (uint64_t)P.block;
+            const uint64_t len = (n - off) < P.block ? (n - off) : P.block;
+            MI_HIP(ctx, hipMemcpyAsync(d_cand + off, sc.cand + (size_t)i * LZ_MAX_BLOCK, len * 2, hipMemcpyDeviceToDevice, s));
+        }
+    }
+    return MI_OK;
+}

@@ -1,0 +1,67 @@
+"""GPU parity of the match-finder stage alone: find() at every position (parse-independent,
+SURVEY.md section 0) from the HIP cluster replay against the oracle's literal table."""
+import numpy as np
+import pytest
+import torch
+
+from compression_algorithms_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = [("deflate", None), ("lz77", 14), ("lz77", 16)]
+
+
+def _oracle_find(data, p):
+    from oracle import orc
+    out = np.empty(len(data), dtype=np.uint32)
+    for at in range(0, len(data), p.block):
+        out[at:at + p.block] = orc.find_all(data[at:at + p.block], p.wbits, p.tbits, bool(p.deflate))
+    return np.where(out == 0xFFFFFFFF, 0xFFFF, out).astype(np.uint16)
+
+
+def _check(data, flavour, wbits, block=65536):
+    from compression_algorithms_amd import lz
+    data = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    p = lz.params(flavour, wbits, block)
+    got = lz.find_all(data, p).cpu().numpy().view(np.uint16)
+    want = _oracle_find(data, p)
+    bad = np.flatnonzero(got != want)
+    assert bad.size == 0, f"{flavour} w{wbits}: {bad.size} mismatches, first at {bad[:5]}: got {got[bad[:5]]} want {want[bad[:5]]}"
+
+
+@pytest.mark.parametrize("flavour,wbits", CONFIGS)
+def test_enwik_like(flavour, wbits):
+    _check(synth.enwik_like(400_000, seed=7).numpy(), flavour, wbits)
+
+
+@pytest.mark.parametrize("flavour,wbits", CONFIGS)
+def test_seed_with_table_end_overflow(flavour, wbits):
+    # seed 12345 has a frequent word whose home is 5 buckets before the end of a 2^20 table: the
+    # lz77 insert probes past T-1 (unbounded bucket ids), the deflate insert wraps to bucket 0
+    _check(synth.enwik_like(300_000, seed=12345).numpy(), flavour, wbits)
+
+
+@pytest.mark.parametrize("flavour,wbits", CONFIGS)
+@pytest.mark.parametrize("kind,n", [("zeros", 65536), ("zeros", 70000), ("single", 40000), ("two", 65536),
+                                    ("random", 65536), ("period3", 65536), ("period4", 65536), ("period16384", 49152),
+                                    ("period32767", 65536), ("period32768", 65536), ("zero_tail", 1000),
+                                    ("random", 5), ("random", 3), ("random", 1), ("skewed", 65536)])
+def test_adversarial(flavour, wbits, kind, n):
+    _check(synth.adversarial(kind, n), flavour, wbits)
+
+
+@pytest.mark.parametrize("flavour,wbits", CONFIGS)
+def test_source_code_like(flavour, wbits):
+    # indentation runs: clusters of many thousand entries (the giant-cluster kernel)
+    rng = np.random.default_rng(5)
+    lines = []
+    words = [b"self", b"return", b"if", b"else", b"for", b"in", b"range", b"value", b"def", b"None", b"x", b"y"]
+    for _ in range(6000):
+        ind = b"    " * int(rng.integers(0, 6))
+        lines.append(ind + b" ".join(words[int(i)] for i in rng.integers(0, len(words), int(rng.integers(1, 7)))) + b"\n")
+    _check(b"".join(lines)[:200_000], flavour, wbits)
+
+
+@pytest.mark.parametrize("block", [4096, 10000, 65536])
+def test_block_sizes(block):
+    _check(synth.enwik_like(150_000, seed=9).numpy(), "deflate", None, block)
