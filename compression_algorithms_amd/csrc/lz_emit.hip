@@ -1,0 +1,423 @@
+// lz_emit.hip — greedy parse, token emission and stream concatenation for the LZ77 paths.
+//
+// Replaces the loop body of lz77_compress (algorithms/lz77/lz77.c:281-338; deflate variant
+// algorithms/deflate/lz77.c:215-275) given the match finder's per-position candidates:
+//
+//   k_lz_parse_emit  per block: match length at every position (lz77.c:302-313), the greedy
+//                    chain p -> p+1 | p+len resolved with 64-position chunk exit tables
+//                    composed in two levels, token ranks by popcount prefix sums, tokens
+//                    bit-packed LSB first through an LDS window (lz77.c:144-174: bit i of the
+//                    stream is bit i%8 of byte i/8; deflate byte tokens lz77.c:176-197 are the
+//                    same thing with 16/32-bit tokens)
+//   k_lz_concat      block streams -> one stream, bit-contiguous (a funnel-shift gather, one
+//                    thread per output dword)
+//   k_lz_decode      one wave per block; replaces lz77_decompress (lz77.c:347-377)
+#include "lz_common.h"
+
+__device__ __forceinline__ uint32_t select_bit(uint64_t m, uint32_t r)   // index of the r-th set bit
+{
+    for (uint32_t k = 0; k < r; ++k) m &= m - 1;
+    return (uint32_t)__builtin_ctzll(m);
+}
+
+__global__ __launch_bounds__(1024)
+void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, LzScratch sc, uint64_t block0)
+{
+    // region0: input bytes -> exit tables [64][1024] -> {token base, match base, staging window}
+    __shared__ __attribute__((aligned(16))) uint8_t s_r0[LZ_MAX_BLOCK + LZ_TAIL + 16];
+    __shared__ uint8_t  s_L[LZ_MAX_BLOCK];
+    __shared__ uint64_t s_tok[1024], s_mat[1024];
+    __shared__ uint8_t  s_entry[1024];
+    __shared__ uint8_t  s_sexit[32][32];
+    __shared__ uint8_t  s_sentry[32];
+    __shared__ uint32_t s_scan[18];
+    __shared__ uint64_t s_q0, s_q1;
+
+    const int tid = threadIdx.x;
+    const uint32_t lb = blockIdx.x;
+    const uint64_t off = (block0 + lb) * (uint64_t)P.block;
+    const uint32_t n = (uint32_t)((n_total - off) < P.block ? (n_total - off) : P.block);
+    const uint8_t *src = in + off;
+    const uint16_t *cand = sc.cand + (size_t)lb * LZ_MAX_BLOCK;
+    const uint32_t W = 1u << P.wbits, max_len = (1u << P.lbits) - 1u;
+
+    // ---- block -> LDS with the zero tail
+    const bool vec_ok = (((uintptr_t)src) & 15u) == 0;
+    for (uint32_t i = tid * 16u; i < LZ_MAX_BLOCK + LZ_TAIL; i += 1024u * 16u) {
+        if (vec_ok && i + 16u <= n) {
+            *reinterpret_cast<uint4 *>(s_r0 + i) = *reinterpret_cast<const uint4 *>(src + i);
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < 16; ++k) s_r0[i + k] = (i + k < n) ? src[i + k] : (uint8_t)0;
+        }
+    }
+    __syncthreads();
+
+    // ---- A: token length at every position, were a token to start there
+    for (uint32_t p = tid; p < n; p += 1024u) {
+        const uint32_t c = cand[p];
+        uint32_t len = 0;
+        if (c != LZ_NONE16) {
+            const uint32_t dist = p - c;
+            const bool literal = P.deflate ? (dist >= W - 1u) : (dist == W);      // deflate lz77.c:223 / lz77.c:290
+            if (!literal) {
+                len = 4;                                                        // the words are equal
+                while (len < max_len && s_r0[c + len] == s_r0[p + len]) ++len;  // no `p < size` bound: zero tail
+            }
+        }
+        s_L[p] = (uint8_t)len;
+    }
+    __syncthreads();
+
+    // ---- B: exit offset of every position of a 64-position chunk into the next chunk
+    uint8_t *ex = s_r0;                       // ex[o * 1024 + chunk]
+    {
+        const uint32_t c = tid;
+        for (int o = 63; o >= 0; --o) {
+            const uint32_t p = c * 64u + (uint32_t)o;
+            uint32_t e = 0;
+            if (p < n) {
+                const uint32_t l = s_L[p];
+                const uint32_t nx = (uint32_t)o + (l ? l : 1u);
+                e = nx >= 64u ? nx - 64u : ex[nx * 1024u + c];
+            }
+            ex[(uint32_t)o * 1024u + c] = (uint8_t)e;
+        }
+    }
+    __syncthreads();
+    // compose over super-chunks of 32 chunks.  A chunk is entered at offset <= max_len - 1 <= 30 for the
+    // reference's length fields (lbits 4 and 5); longer fields take the serial walk below.
+    const bool wide = max_len > 31u;
+    if (!wide) {
+        const uint32_t scn = tid >> 5, o = tid & 31u;
+        uint32_t x = o;
+        for (uint32_t c = scn * 32u; c < scn * 32u + 32u; ++c) x = ex[x * 1024u + c];
+        s_sexit[scn][o] = (uint8_t)x;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t e = 0;
+            for (uint32_t s = 0; s < 32; ++s) { s_sentry[s] = (uint8_t)e; e = s_sexit[s][e]; }
+        }
+        __syncthreads();
+        if (tid < 32) {
+            uint32_t xx = s_sentry[tid];
+            for (uint32_t c = tid * 32u; c < tid * 32u + 32u; ++c) { s_entry[c] = (uint8_t)xx; xx = ex[xx * 1024u + c]; }
+        }
+        __syncthreads();
+    }
+
+    // ---- C: token starts of each chunk
+    {
+        const uint32_t c = tid;
+        uint64_t tok = 0, mat = 0;
+        if (!wide) {
+            if (c * 64u < n) {
+                uint32_t o = s_entry[c];
+                while (o < 64u && c * 64u + o < n) {
+                    const uint32_t l = s_L[c * 64u + o];
+                    tok |= 1ull << o;
+                    if (l) mat |= 1ull << o;
+                    o += l ? l : 1u;
+                }
+            }
+            s_tok[c] = tok; s_mat[c] = mat;
+        } else {
+            s_tok[c] = 0; s_mat[c] = 0;
+        }
+    }
+    __syncthreads();
+    if (wide && tid == 0) {
+        // lbits > 5: a plain serial walk (not a reference configuration; kept for completeness)
+        uint32_t p = 0;
+        while (p < n) {
+            const uint32_t l = s_L[p];
+            s_tok[p >> 6] |= 1ull << (p & 63u);
+            if (l) s_mat[p >> 6] |= 1ull << (p & 63u);
+            p += l ? l : 1u;
+        }
+    }
+    __syncthreads();
+    const uint64_t my_tok = s_tok[tid], my_mat = s_mat[tid];
+    uint32_t ntok = 0, nmat = 0;
+    const uint32_t tbase = block_exclusive_scan<uint32_t>((uint32_t)__popcll(my_tok), OpAddU32(), 0u, s_scan, &ntok);
+    const uint32_t mbase = block_exclusive_scan<uint32_t>((uint32_t)__popcll(my_mat), OpAddU32(), 0u, s_scan, &nmat);
+    uint32_t *tb = reinterpret_cast<uint32_t *>(s_r0);            // [1025]
+    uint32_t *mb = tb + 1026;                                      // [1025]
+    uint32_t *stage = mb + 1026;                                   // [1024 + 4]
+    tb[tid] = tbase; mb[tid] = mbase;
+    if (tid == 0) { tb[1024] = ntok; mb[1024] = nmat; }
+    __syncthreads();
+
+    // ---- D: emit, 1024 tokens per window
+    const uint32_t LB = P.deflate ? 16u : 9u, MB = P.deflate ? 32u : (1u + P.wbits + P.lbits);
+    uint32_t *slot = sc.slot + (size_t)lb * LZ_SLOT_WORDS;
+    uint32_t carry = 0;
+    for (uint32_t t0 = 0; t0 < ntok; t0 += 1024u) {
+        const uint32_t t = t0 + tid;
+        const bool valid = t < ntok;
+        uint64_t q = 0; uint32_t v = 0, nbits = 0;
+        if (valid) {
+            uint32_t lo = 0, hi = 1023;                           // last chunk with tb[c] <= t
+            while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (tb[mid] <= t) lo = mid; else hi = mid - 1; }
+            const uint32_t c = lo, o = select_bit(s_tok[c], t - tb[c]);
+            const uint32_t p = c * 64u + o;
+            const uint64_t below = (1ull << o) - 1ull;
+            const uint32_t mbefore = mb[c] + (uint32_t)__popcll(s_mat[c] & below);
+            q = (uint64_t)(t - mbefore) * LB + (uint64_t)mbefore * MB;
+            if ((s_mat[c] >> o) & 1ull) {
+                const uint32_t d = p - cand[p], l = s_L[p];
+                v = P.deflate ? (1u | (d << 8) | (l << 24)) : (1u | (d << 1) | (l << (1u + P.wbits)));
+                nbits = MB;
+            } else {
+                const uint32_t byte = src[p];
+                v = P.deflate ? (byte << 8) : (byte << 1);
+                nbits = LB;
+            }
+            if (tid == 0) s_q0 = q;
+            if (t == ntok - 1 || tid == 1023) s_q1 = q + nbits;
+        }
+        __syncthreads();
+        const uint64_t q0 = s_q0, q1 = s_q1;
+        const uint64_t w0 = q0 >> 5;
+        const uint32_t nwords = (uint32_t)(((q1 + 31) >> 5) - w0);
+        for (uint32_t i = tid; i < nwords + 1; i += 1024u) stage[i] = (i == 0) ? carry : 0u;
+        __syncthreads();
+        if (valid) {
+            const uint32_t rel = (uint32_t)(q - (w0 << 5)), wi = rel >> 5, sh = rel & 31u;
+            atomicOr(&stage[wi], v << sh);
+            if (sh + nbits > 32u) atomicOr(&stage[wi + 1], v >> (32u - sh));
+        }
+        __syncthreads();
+        const uint32_t ncomplete = (uint32_t)((q1 >> 5) - w0);
+        for (uint32_t i = tid; i < ncomplete; i += 1024u) slot[w0 + i] = stage[i];
+        carry = stage[ncomplete];
+        __syncthreads();
+    }
+    const uint64_t total_bits = (uint64_t)(ntok - nmat) * LB + (uint64_t)nmat * MB;
+    if (tid == 0) {
+        slot[total_bits >> 5] = (total_bits & 31u) ? carry : 0u;
+        slot[(total_bits >> 5) + 1] = 0;
+        sc.block_bits[lb] = total_bits;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// single-workgroup exclusive scan of the batch's block bit counts; also publishes the global
+// exclusive offsets (base + local) to the caller's array
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024)
+void k_lz_scan_blocks(const uint64_t *__restrict__ bits, uint32_t nb, const uint64_t *__restrict__ base_bits,
+                      uint64_t *__restrict__ excl_local, uint64_t *__restrict__ excl_global)
+{
+    __shared__ uint64_t s_tmp[18];
+    const uint64_t v = threadIdx.x < nb ? bits[threadIdx.x] : 0;       // nb <= 1024 per batch
+    uint64_t inc = v;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint64_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) s_tmp[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint64_t run = 0; for (int w = 0; w < 16; ++w) { uint64_t t = s_tmp[w]; s_tmp[w] = run; run += t; } s_tmp[16] = run; }
+    __syncthreads();
+    const uint64_t exc = s_tmp[wave] + inc - v, base = *base_bits;
+    if (threadIdx.x < nb) { excl_local[threadIdx.x] = exc; excl_global[threadIdx.x] = base + exc; }
+    if (threadIdx.x == 0) { excl_local[nb] = s_tmp[16]; excl_global[nb] = base + s_tmp[16]; }
+}
+
+__global__ void k_lz_advance(uint64_t *base_bits, const uint64_t *excl_local, uint32_t nb) { *base_bits += excl_local[nb]; }
+
+__device__ __forceinline__ uint32_t extract_bits(const uint32_t *w, uint64_t lo, uint32_t k)   // k in 1..32
+{
+    const uint64_t wi = lo >> 5; const uint32_t sh = (uint32_t)(lo & 31u);
+    const uint64_t two = (uint64_t)w[wi] | ((uint64_t)w[wi + 1] << 32);
+    const uint64_t v = two >> sh;
+    return k >= 32 ? (uint32_t)v : ((uint32_t)v & ((1u << k) - 1u));
+}
+
+// one thread per output dword of the batch's bit range [base, base + total)
+__global__ __launch_bounds__(256)
+void k_lz_concat(const uint32_t *__restrict__ slots, const uint64_t *__restrict__ excl_local, uint32_t nb,
+                 const uint64_t *__restrict__ base_bits, uint32_t *__restrict__ out)
+{
+    const uint64_t base = *base_bits, total = excl_local[nb];
+    const uint64_t wfirst = base >> 5, wlast = (base + total + 31) >> 5;       // [wfirst, wlast)
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + wfirst;
+    if (j >= wlast) return;
+    const uint64_t g0 = j << 5, g1 = g0 + 32;
+    uint64_t pos = g0 > base ? g0 : base;
+    const uint64_t end = g1 < base + total ? g1 : base + total;
+    // largest i with base + excl[i] <= pos
+    uint32_t lo = 0, hi = nb - 1;
+    const uint64_t rel = pos - base;
+    while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (excl_local[mid] <= rel) lo = mid; else hi = mid - 1; }
+    uint32_t i = lo, word = 0;
+    while (pos < end) {
+        const uint64_t bs = base + excl_local[i], be = base + excl_local[i + 1];
+        const uint64_t se = be < end ? be : end;
+        if (se > pos) {
+            const uint32_t k = (uint32_t)(se - pos);
+            word |= extract_bits(slots + (size_t)i * LZ_SLOT_WORDS, pos - bs, k) << (uint32_t)(pos - g0);
+            pos = se;
+        }
+        if (pos == be) ++i;
+    }
+    if (j == wfirst && (base & 31u)) atomicOr(&out[j], word);      // shares a dword with the previous batch
+    else out[j] = word;
+}
+
+// ---------------------------------------------------------------------------------------------
+// decode: one wave per block, output staged in LDS.  A block stops at its original length: the
+// last match may overshoot (the encoder compares into the zero tail), SURVEY.md A.3.4.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t stream_bits(const uint8_t *s, uint64_t pos, uint32_t k)   // k <= 25
+{
+    const uint64_t byte = pos >> 3;
+    uint64_t v = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) v |= (uint64_t)s[byte + i] << (8 * i);
+    return (uint32_t)(v >> (pos & 7u)) & ((1u << k) - 1u);
+}
+
+__global__ __launch_bounds__(64)
+void k_lz_decode(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ block_bits, LzP P,
+                 uint8_t *__restrict__ out, uint64_t n_total, uint32_t *__restrict__ err)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[LZ_MAX_BLOCK + 256];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t b = blockIdx.x;
+    const uint64_t off = b * (uint64_t)P.block;
+    const uint32_t n = (uint32_t)((n_total - off) < P.block ? (n_total - off) : P.block);
+    uint64_t pos = block_bits[b];
+    const uint64_t end = block_bits[b + 1];
+    uint32_t o = 0;
+    bool bad = false;
+    while (o < n && pos < end) {
+        uint32_t flag, d = 0, len = 0, lit = 0;
+        if (P.deflate) {
+            const uint32_t t0 = stream_bits(stream, pos, 16);
+            flag = t0 & 0xFFu;
+            if (flag == 0) { lit = t0 >> 8; pos += 16; }
+            else { const uint32_t t1 = stream_bits(stream, pos + 16, 16); d = (t0 >> 8) | ((t1 & 0xFFu) << 8); len = t1 >> 8; pos += 32; }
+            if (flag > 1) { bad = true; break; }
+        } else {
+            flag = stream_bits(stream, pos, 1);
+            if (!flag) { lit = stream_bits(stream, pos + 1, 8); pos += 9; }
+            else { d = stream_bits(stream, pos + 1, P.wbits); len = stream_bits(stream, pos + 1 + P.wbits, P.lbits); pos += 1 + P.wbits + P.lbits; }
+        }
+        if (!flag) {
+            if (lane == 0) s_out[o] = (uint8_t)lit;
+            o += 1;
+        } else {
+            if (d == 0 || d > o) { bad = true; break; }
+            const uint32_t take = (o + len <= n) ? len : n - o;
+            for (uint32_t j = lane; j < take; j += 64) s_out[o + j] = s_out[o - d + (j % d)];
+            o += take;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (o != n) bad = true;
+    if (bad && lane == 0) atomicOr(err, 1u);
+    __syncthreads();
+    for (uint32_t i = lane; i < n; i += 64) out[off + i] = s_out[i];
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+size_t   lz_scratch_bytes(uint32_t nb);
+void     lz_carve(mi_ctx *ctx, uint32_t nb, LzScratch *sc);
+mi_status lz_check_params(const mi_lz_params *p);
+mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
+                        const LzScratch &sc, hipStream_t s);
+uint32_t lz_batch_blocks(uint64_t nblocks);
+
+extern "C" mi_status mi_lz_encode_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_in, uint64_t n,
+                                      uint8_t *d_out, uint64_t cap_bytes, uint64_t *d_block_bits, void *stream)
+{
+    if (!ctx || !d_out || !d_block_bits || (n && !d_in)) return MI_ERR_ARG;
+    mi_status st = lz_check_params(p);
+    if (st) return st;
+    if (((uintptr_t)d_out & 3u) != 0) return MI_ERR_ARG;
+    if (cap_bytes < mi_lz_bound_bytes(n, p)) return MI_ERR_CAPACITY;
+    hipStream_t s = (hipStream_t)stream;
+    const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block};
+    const uint64_t nblocks = (n + P.block - 1) / P.block;
+    const uint32_t nbmax = lz_batch_blocks(nblocks);
+    st = mi_ws_reserve(ctx, lz_scratch_bytes(nbmax) + 4096);
+    if (st) return st;
+    LzScratch sc;
+    lz_carve(ctx, nbmax, &sc);
+    // two small device words after the carve: running bit total, local exclusive offsets
+    uint64_t *base_bits = reinterpret_cast<uint64_t *>(sc.giant_count + 16);
+    uint64_t *excl_local = sc.block_bits;                       // reused: [nb+1] after the scan (in place is fine)
+    MI_HIP(ctx, hipMemsetAsync(base_bits, 0, 8, s));
+    if (nblocks == 0) { MI_HIP(ctx, hipMemsetAsync(d_block_bits, 0, 8, s)); return MI_OK; }
+    for (uint64_t b0 = 0; b0 < nblocks; b0 += nbmax) {
+        const uint32_t nb = (uint32_t)((nblocks - b0) < nbmax ? (nblocks - b0) : nbmax);
+        st = lz_find_batch(ctx, P, d_in, n, b0, nb, sc, s);
+        if (st) return st;
+        {
+            mi_prof_scope pr(ctx, "k_lz_parse_emit", s, (uint64_t)nb * P.block);
+            hipLaunchKernelGGL(k_lz_parse_emit, dim3(nb), dim3(1024), 0, s, d_in, n, P, sc, b0);
+        }
+        hipLaunchKernelGGL(k_lz_scan_blocks, dim3(1), dim3(1024), 0, s, sc.block_bits, nb, base_bits, excl_local, d_block_bits + b0);
+        {
+            mi_prof_scope pr(ctx, "k_lz_concat", s, (uint64_t)nb * P.block);
+            // upper bound on the dwords of this batch: every block at its worst case
+            const uint64_t maxw = (uint64_t)nb * LZ_SLOT_WORDS + 2;
+            hipLaunchKernelGGL(k_lz_concat, dim3((unsigned)((maxw + 255) / 256)), dim3(256), 0, s, sc.slot, excl_local, nb,
+                               base_bits, reinterpret_cast<uint32_t *>(d_out));
+        }
+        hipLaunchKernelGGL(k_lz_advance, dim3(1), dim3(1), 0, s, base_bits, excl_local, nb);
+    }
+    MI_HIP(ctx, hipGetLastError());
+    return MI_OK;
+}
+
+extern "C" mi_status mi_lz_encode(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *h_in, uint64_t n,
+                                  uint8_t *h_out, uint64_t cap_bytes, uint64_t *h_block_bits)
+{
+    if (!ctx || !h_out || !h_block_bits || (n && !h_in) || !p) return MI_ERR_ARG;
+    const uint64_t nblocks = p->block ? (n + p->block - 1) / p->block : 0;
+    const uint64_t bound = mi_lz_bound_bytes(n, p);
+    if (cap_bytes < bound) return MI_ERR_CAPACITY;
+    uint8_t *d_in = nullptr, *d_out = nullptr; uint64_t *d_bits = nullptr;
+    mi_status st = MI_OK;
+    hipStream_t s = ctx->stream;
+    if (hipMalloc(&d_in, n + 64) != hipSuccess || hipMalloc(&d_out, bound + 64) != hipSuccess ||
+        hipMalloc(&d_bits, (nblocks + 1) * 8) != hipSuccess) st = MI_ERR_NOMEM;
+    if (st == MI_OK && n && hipMemcpyAsync(d_in, h_in, n, hipMemcpyHostToDevice, s) != hipSuccess) st = MI_ERR_HIP;
+    if (st == MI_OK) st = mi_lz_encode_dev(ctx, p, d_in, n, d_out, bound + 64, d_bits, s);
+    if (st == MI_OK && hipMemcpyAsync(h_block_bits, d_bits, (nblocks + 1) * 8, hipMemcpyDeviceToHost, s) != hipSuccess) st = MI_ERR_HIP;
+    if (st == MI_OK && hipStreamSynchronize(s) != hipSuccess) st = MI_ERR_HIP;
+    if (st == MI_OK) {
+        const uint64_t bytes = (h_block_bits[nblocks] + 7) / 8;
+        if (bytes && hipMemcpy(h_out, d_out, bytes, hipMemcpyDeviceToHost) != hipSuccess) st = MI_ERR_HIP;
+    }
+    (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_bits);
+    return st;
+}
+
+extern "C" mi_status mi_lz_decode_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_stream,
+                                      const uint64_t *d_block_bits, uint8_t *d_out, uint64_t n, void *stream)
+{
+    if (!ctx || !d_stream || !d_block_bits || (n && !d_out)) return MI_ERR_ARG;
+    mi_status st = lz_check_params(p);
+    if (st) return st;
+    if (n == 0) return MI_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block};
+    const uint64_t nblocks = (n + P.block - 1) / P.block;
+    st = mi_ws_reserve(ctx, 4096);
+    if (st) return st;
+    uint32_t *err = reinterpret_cast<uint32_t *>(ctx->ws);
+    MI_HIP(ctx, hipMemsetAsync(err, 0, 4, s));
+    {
+        mi_prof_scope pr(ctx, "k_lz_decode", s, n);
+        hipLaunchKernelGGL(k_lz_decode, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, d_block_bits, P, d_out, n, err);
+    }
+    uint32_t h_err = 0;
+    MI_HIP(ctx, hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, s));
+    MI_HIP(ctx, hipStreamSynchronize(s));
+    return h_err ? MI_ERR_CORRUPT : MI_OK;
+}

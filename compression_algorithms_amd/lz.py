@@ -34,3 +34,53 @@ def find_all(data, p, ctx=None):
                                   ctx.stream_ptr())
     _lib.check(st, "mi_lz_find_all_dev")
     return cand[:n]
+
+
+class LzStream:
+    """A block-parallel LZ77 stream on the device.
+
+    data        uint8 tensor, the concatenated block streams (lz77 flavour: bit-contiguous)
+    block_bits  int64 tensor [nblocks+1], exclusive prefix of per-block lengths in BITS
+    """
+
+    def __init__(self, data, block_bits, n, p):
+        self.data, self.block_bits, self.n, self.p = data, block_bits, n, p
+
+    @property
+    def total_bits(self):
+        return int(self.block_bits[-1])
+
+    @property
+    def nbytes(self):
+        return (self.total_bits + 7) // 8
+
+    def tobytes(self):
+        return self.data[: self.nbytes].cpu().numpy().tobytes()
+
+
+def bound_bytes(n, p):
+    return 2 * n + 8 if p.deflate else (9 * n + 7) // 8 + 16
+
+
+def compress(data, p, ctx=None):
+    """Encode `data` as independent `p.block`-byte blocks (reference semantics per block)."""
+    ctx = ctx or default_context()
+    d_in = as_device_bytes(data, ctx.device)
+    n = d_in.numel()
+    nblocks = (n + p.block - 1) // p.block
+    cap = bound_bytes(n, p) + 64
+    out = torch.empty(cap, dtype=torch.uint8, device=ctx.device)
+    bits = torch.zeros(nblocks + 1, dtype=torch.int64, device=ctx.device)
+    st = ctx.L.mi_lz_encode_dev(ctx.h, C.byref(p), C.c_void_p(d_in.data_ptr() if n else 0), n, C.c_void_p(out.data_ptr()), cap,
+                                C.c_void_p(bits.data_ptr()), ctx.stream_ptr())
+    _lib.check(st, "mi_lz_encode_dev")
+    return LzStream(out, bits, n, p)
+
+
+def decompress(stream, ctx=None):
+    ctx = ctx or default_context()
+    out = torch.empty(max(stream.n, 1), dtype=torch.uint8, device=ctx.device)
+    st = ctx.L.mi_lz_decode_dev(ctx.h, C.byref(stream.p), C.c_void_p(stream.data.data_ptr()),
+                                C.c_void_p(stream.block_bits.data_ptr()), C.c_void_p(out.data_ptr()), stream.n, ctx.stream_ptr())
+    _lib.check(st, "mi_lz_decode_dev")
+    return out[: stream.n]
