@@ -15,6 +15,7 @@
 // Output: cand[p] = what find(word at p) returns in the table state after positions 0..p-1
 // were inserted (0xFFFF = none).  The parse consumes it in lz_emit.hip.
 #include "lz_common.h"
+#include <stdlib.h>
 
 // =============================================================================================
 // k_lz_sort_home
@@ -197,6 +198,8 @@ void k_lz_sort_cluster(LzScratch sc)
 struct TileView {
     uint16_t *pos, *rs, *pid, *occ;
     uint32_t *bm;           // occupancy bits, one per slot
+    uint32_t *bm1;          // one bit per bm word: "word is full"; kept only for words that lie entirely
+                            // inside one cluster (their owner lane is the only writer), so it is exact
     uint32_t  n;            // entries (= slots) in the view
 };
 #define RS_HEAD 0x8000u
@@ -204,13 +207,24 @@ struct TileView {
 
 __device__ __forceinline__ bool bm_test(const uint32_t *bm, uint32_t b) { return (bm[b >> 5] >> (b & 31u)) & 1u; }
 
-// first zero bit at or after r (exists inside the cluster by the parking bound)
-__device__ __forceinline__ uint32_t bm_next_zero(const uint32_t *bm, uint32_t r)
+// first zero bit at or after r (exists inside the cluster by the parking bound).  Full words
+// that the summary level knows about are skipped 32 at a time: a pile of several hundred
+// copies of one word costs a couple of reads per insert instead of a walk over the pile.
+__device__ __forceinline__ uint32_t bm_next_zero(const uint32_t *bm, const uint32_t *bm1, uint32_t r)
 {
     uint32_t wi = r >> 5;
     uint32_t w = bm[wi] | ((1u << (r & 31u)) - 1u);
-    while (w == 0xFFFFFFFFu) w = bm[++wi];
-    return (wi << 5) + (uint32_t)__builtin_ctz(~w);
+    if (w != 0xFFFFFFFFu) return (wi << 5) + (uint32_t)__builtin_ctz(~w);
+    ++wi;
+    for (;;) {
+        const uint32_t sh = wi & 31u;
+        const uint32_t notfull = ~(bm1[wi >> 5] >> sh) & (sh ? ((1u << (32u - sh)) - 1u) : 0xFFFFFFFFu);
+        if (!notfull) { wi = (wi | 31u) + 1u; continue; }
+        wi += (uint32_t)__builtin_ctz(notfull);
+        w = bm[wi];
+        if (w != 0xFFFFFFFFu) return (wi << 5) + (uint32_t)__builtin_ctz(~w);
+        ++wi;                                    // a word shared with a neighbour cluster: full but unmarked
+    }
 }
 
 // replay entries [s, e) of the view (one cluster) in time order.  anom / limit: slot of bucket 0 /
@@ -218,6 +232,28 @@ __device__ __forceinline__ uint32_t bm_next_zero(const uint32_t *bm, uint32_t r)
 __device__ void replay_cluster(const TileView &v, uint32_t s, uint32_t e, uint32_t W, uint32_t anom, uint32_t limit,
                                uint16_t *__restrict__ cand)
 {
+    // bm words [wlo, whi) belong to this cluster alone
+    const uint32_t wlo = (s + 31u) >> 5, whi = e >> 5;
+    auto clear_slot = [&](uint32_t b) {
+        const uint32_t wi = b >> 5, bit = 1u << (b & 31u);
+        if (wi >= wlo && wi < whi) {
+            const uint32_t w = v.bm[wi];
+            v.bm[wi] = w & ~bit;
+            if (w == 0xFFFFFFFFu) atomicAnd(&v.bm1[wi >> 5], ~(1u << (wi & 31u)));
+        } else {
+            atomicAnd(&v.bm[wi], ~bit);
+        }
+    };
+    auto set_slot = [&](uint32_t b) {
+        const uint32_t wi = b >> 5, bit = 1u << (b & 31u);
+        if (wi >= wlo && wi < whi) {
+            const uint32_t w = v.bm[wi] | bit;
+            v.bm[wi] = w;
+            if (w == 0xFFFFFFFFu) atomicOr(&v.bm1[wi >> 5], 1u << (wi & 31u));
+        } else {
+            atomicOr(&v.bm[wi], bit);
+        }
+    };
     uint32_t ev = s;
     bool anom_pending = anom != ~0u;
     for (uint32_t i = s; i < e; ++i) {
@@ -226,17 +262,11 @@ __device__ void replay_cluster(const TileView &v, uint32_t s, uint32_t e, uint32
         const uint32_t r = rsv & RS_MASK;
         const uint32_t pid = v.pid[i];
         // FIFO eviction: insertion k retires insertion k-W *after* writing, so what find/insert at
-        // p see is everything inserted at or after p-W  (lz77.c:70-76)
-        while (ev < i && (uint32_t)v.pos[ev] + W < p) {
-            const uint32_t b = v.rs[ev] & RS_MASK;
-            atomicAnd(&v.bm[b >> 5], ~(1u << (b & 31u)));       // clears the BUCKET, whoever sits there
-            ++ev;
-        }
+        // p see is everything inserted at or after p-W  (lz77.c:70-76).  It clears the BUCKET,
+        // whoever sits there.
+        while (ev < i && (uint32_t)v.pos[ev] + W < p) { clear_slot(v.rs[ev] & RS_MASK); ++ev; }
         // the ring starts zero-filled, so insertion W-1 clears bucket 0 once
-        if (anom_pending && p > W - 1u) {
-            atomicAnd(&v.bm[anom >> 5], ~(1u << (anom & 31u)));
-            anom_pending = false;
-        }
+        if (anom_pending && p > W - 1u) { clear_slot(anom); anom_pending = false; }
         // find: first slot from the home that is empty (-> none) or holds the same word
         uint32_t res = LZ_NONE16;
         for (uint32_t b = r;; ++b) {
@@ -247,8 +277,8 @@ __device__ void replay_cluster(const TileView &v, uint32_t s, uint32_t e, uint32
         }
         if (res != LZ_NONE16) cand[p] = (uint16_t)res;
         // insert: first free slot from the home
-        const uint32_t b = bm_next_zero(v.bm, r);
-        atomicOr(&v.bm[b >> 5], 1u << (b & 31u));
+        const uint32_t b = bm_next_zero(v.bm, v.bm1, r);
+        set_slot(b);
         v.occ[b] = (uint16_t)i;
         v.rs[i] = (uint16_t)((rsv & RS_HEAD) | b);
     }
@@ -259,7 +289,8 @@ void k_lz_emulate(LzP P, LzScratch sc)
 {
     __shared__ uint16_t s_pos[LZ_TILE_CAP], s_rs[LZ_TILE_CAP], s_pid[LZ_TILE_CAP], s_occ[LZ_TILE_CAP];
     __shared__ uint32_t s_bm[LZ_TILE_CAP / 32 + 2];
-    __shared__ uint32_t s_a, s_b, s_lasthead, s_giant;
+    __shared__ uint32_t s_bm1[LZ_TILE_CAP / 1024 + 2];
+    __shared__ uint32_t s_a, s_b, s_lasthead;
 
     const int tid = threadIdx.x;
     const uint32_t lb = blockIdx.y, t = blockIdx.x;
@@ -271,7 +302,7 @@ void k_lz_emulate(LzP P, LzScratch sc)
     auto gid_at = [&](uint32_t i) { return (uint32_t)E[i] & 0xFFFFu; };
     auto is_head = [&](uint32_t i) { return i == 0 || gid_at(i) != gid_at(i - 1); };
 
-    if (tid == 0) { s_a = ~0u; s_b = ~0u; s_lasthead = 0; s_giant = 0; }
+    if (tid == 0) { s_a = ~0u; s_b = ~0u; s_lasthead = 0; }
     __syncthreads();
     // a = first head in [lo, hi)
     for (uint32_t i = lo + tid; i < hi; i += 512) if (is_head(i)) atomicMin(&s_a, i);
@@ -305,9 +336,10 @@ void k_lz_emulate(LzP P, LzScratch sc)
         s_pid[i] = (uint16_t)(e >> 48);
     }
     for (uint32_t i = tid; i < LZ_TILE_CAP / 32 + 2; i += 512) s_bm[i] = 0;
+    if (tid < LZ_TILE_CAP / 1024 + 2) s_bm1[tid] = 0;
     __syncthreads();
     // pid is a POSITION (first occurrence of the word); compare through it directly
-    TileView v{s_pos, s_rs, s_pid, s_occ, s_bm, m};
+    TileView v{s_pos, s_rs, s_pid, s_occ, s_bm, s_bm1, m};
     const uint32_t W = 1u << P.wbits;
     uint16_t *cand = sc.cand + (size_t)lb * LZ_MAX_BLOCK;
     for (uint32_t s = tid; s < m; s += 512) {
@@ -327,6 +359,7 @@ void k_lz_emulate_giant(LzP P, LzScratch sc)
 {
     __shared__ uint16_t s_pos[LZ_GIANT_CAP], s_rs[LZ_GIANT_CAP], s_pid[LZ_GIANT_CAP], s_occ[LZ_GIANT_CAP];
     __shared__ uint32_t s_bm[LZ_MAX_BLOCK / 32 + 2];
+    __shared__ uint32_t s_bm1[LZ_MAX_BLOCK / 1024 + 2];
     __shared__ uint32_t s_end;
     const int tid = threadIdx.x;
     const uint32_t count = *sc.giant_count;
@@ -347,6 +380,7 @@ void k_lz_emulate_giant(LzP P, LzScratch sc)
         const bool first = a == 0;
         const uint32_t anom = first ? mt.anom_idx : ~0u, limit = first ? mt.limit_idx : ~0u;
         for (uint32_t i = tid; i < LZ_MAX_BLOCK / 32 + 2; i += 256) s_bm[i] = 0;
+        if (tid < LZ_MAX_BLOCK / 1024 + 2) s_bm1[tid] = 0;
         if (m <= LZ_GIANT_CAP) {
             for (uint32_t i = tid; i < m; i += 256) {
                 const uint64_t e = E[a + i];
@@ -356,7 +390,7 @@ void k_lz_emulate_giant(LzP P, LzScratch sc)
             }
             __syncthreads();
             if (tid == 0) {
-                TileView v{s_pos, s_rs, s_pid, s_occ, s_bm, m};
+                TileView v{s_pos, s_rs, s_pid, s_occ, s_bm, s_bm1, m};
                 replay_cluster(v, 0, m, W, anom, limit, cand);
             }
         } else {
@@ -374,9 +408,14 @@ void k_lz_emulate_giant(LzP P, LzScratch sc)
                     while (ev < i && (((uint32_t)(E[a + ev] >> 16)) & 0xFFFFu) + W < p) {
                         const uint32_t bb = slot[ev];
                         s_bm[bb >> 5] &= ~(1u << (bb & 31u));
+                        s_bm1[bb >> 10] &= ~(1u << ((bb >> 5) & 31u));
                         ++ev;
                     }
-                    if (anom_pending && p > W - 1u) { s_bm[anom >> 5] &= ~(1u << (anom & 31u)); anom_pending = false; }
+                    if (anom_pending && p > W - 1u) {
+                        s_bm[anom >> 5] &= ~(1u << (anom & 31u));
+                        s_bm1[anom >> 10] &= ~(1u << ((anom >> 5) & 31u));
+                        anom_pending = false;
+                    }
                     uint32_t res = LZ_NONE16;
                     for (uint32_t bb = r;; ++bb) {
                         if (bb == limit && r < limit) break;
@@ -385,8 +424,9 @@ void k_lz_emulate_giant(LzP P, LzScratch sc)
                         if ((uint32_t)(oe >> 48) == pid) { res = (uint32_t)(oe >> 16) & 0xFFFFu; break; }
                     }
                     if (res != LZ_NONE16) cand[p] = (uint16_t)res;
-                    const uint32_t bb = bm_next_zero(s_bm, r);
+                    const uint32_t bb = bm_next_zero(s_bm, s_bm1, r);
                     s_bm[bb >> 5] |= 1u << (bb & 31u);
+                    if (s_bm[bb >> 5] == 0xFFFFFFFFu) s_bm1[bb >> 10] |= 1u << ((bb >> 5) & 31u);
                     occ[bb] = (uint16_t)i;
                     slot[i] = (uint16_t)bb;
                 }
@@ -461,7 +501,8 @@ mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t
 
 uint32_t lz_batch_blocks(uint64_t nblocks)
 {
-    const uint64_t cap = 512;
+    uint64_t cap = 512;
+    if (const char *e = getenv("MI_LZ_BATCH")) { long v = atol(e); if (v >= 1 && v <= 1024) cap = (uint64_t)v; }
     return (uint32_t)(nblocks < cap ? (nblocks ? nblocks : 1) : cap);
 }
 
