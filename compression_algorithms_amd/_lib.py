@@ -87,10 +87,10 @@ def lib():
         L.mi_set_profiling.argtypes = [vp, C.c_int]
         L.mi_get_kernel_times.argtypes = [vp, C.POINTER(KernelTime), C.c_int]
         if hasattr(L, "mi_huffman_encode_dev"):
-            L.mi_huffman_encode_dev.argtypes = [vp, vp, u64, vp, u64, vp, vp, vp]
+            L.mi_huffman_encode_dev.argtypes = [vp, vp, u64, vp, u64, vp, vp, vp, vp]
             L.mi_huffman_encode.argtypes = [vp, vp, u64, vp, u64, C.POINTER(HuffmanInfo), C.POINTER(HuffmanTree)]
         if hasattr(L, "mi_huffman_decode_dev"):
-            L.mi_huffman_decode_dev.argtypes = [vp, vp, u64, vp, C.c_uint32, vp, u64, vp]
+            L.mi_huffman_decode_dev.argtypes = [vp, vp, u64, vp, C.c_uint32, vp, vp, u64, vp]
         if hasattr(L, "mi_lz_encode_dev"):
             L.mi_lz_encode_dev.argtypes = [vp, C.POINTER(LzParams), vp, u64, vp, u64, vp, vp]
             L.mi_lz_encode.argtypes = [vp, C.POINTER(LzParams), vp, u64, vp, u64, vp]

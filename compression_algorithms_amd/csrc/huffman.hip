@@ -339,7 +339,7 @@ static inline uint64_t huff_ntiles(uint64_t n) { return (n + HUFF_TILE - 1) / HU
 
 extern "C" mi_status mi_huffman_encode_dev(mi_ctx *ctx, const uint8_t *d_in, uint64_t n, uint32_t *d_words,
                                            uint64_t cap_words, mi_huffman_info *d_info, mi_huffman_tree *d_tree,
-                                           void *stream)
+                                           uint64_t *d_tile_off, void *stream)
 {
     if (!ctx || !d_words || !d_info || !d_tree || (n && !d_in) || cap_words < 2) return MI_ERR_ARG;
     if (((uintptr_t)d_in & 15) != 0) return MI_ERR_ARG;        // 16-B loads
@@ -368,6 +368,7 @@ extern "C" mi_status mi_huffman_encode_dev(mi_ctx *ctx, const uint8_t *d_in, uin
         hipLaunchKernelGGL(k_huff_tile_bits, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, s, tile_hist, len, ntiles, tile_bits);
     }
     hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, s, tile_bits, ntiles, tile_off);
+    if (d_tile_off) MI_HIP(ctx, hipMemcpyAsync(d_tile_off, tile_off, (ntiles + 1) * 8, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(k_huff_finish_info, dim3((unsigned)((ntiles + 1 + 255) / 256)), dim3(256), 0, s,
                        tile_off, ntiles, d_words, cap_words, d_info);
     if (ntiles) {
@@ -397,7 +398,7 @@ extern "C" mi_status mi_huffman_encode(mi_ctx *ctx, const uint8_t *h_in, uint64_
         st = MI_ERR_NOMEM;
     }
     if (st == MI_OK && n && hipMemcpyAsync(d_in, h_in, n, hipMemcpyHostToDevice, s) != hipSuccess) st = MI_ERR_HIP;
-    if (st == MI_OK) st = mi_huffman_encode_dev(ctx, d_in, n, d_words, cap_words, d_info, d_tree, s);
+    if (st == MI_OK) st = mi_huffman_encode_dev(ctx, d_in, n, d_words, cap_words, d_info, d_tree, nullptr, s);
     if (st == MI_OK && hipMemcpyAsync(h_info, d_info, sizeof(*h_info), hipMemcpyDeviceToHost, s) != hipSuccess) st = MI_ERR_HIP;
     if (st == MI_OK && hipStreamSynchronize(s) != hipSuccess) st = MI_ERR_HIP;
     if (st == MI_OK && h_tree && hipMemcpy(h_tree, d_tree, sizeof(*h_tree), hipMemcpyDeviceToHost) != hipSuccess) st = MI_ERR_HIP;
@@ -409,4 +410,87 @@ extern "C" mi_status mi_huffman_encode(mi_ctx *ctx, const uint8_t *h_in, uint64_
     }
     (void)hipFree(d_in); (void)hipFree(d_words); (void)hipFree(d_info); (void)hipFree(d_tree);
     return st;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// decode (replaces huffman_decompress, huffman.c:330-364; the 12-bit lookup table is what the
+// reference's unfinished huffman_decompress_lookup_table, :366-401, was reaching for).
+// One lane per encoder tile: the encoder's tile bit offsets are the only sync points a
+// variable-length code offers.  Without them (d_tile_off == NULL) a single lane walks the stream.
+// ---------------------------------------------------------------------------------------------
+#define HUFF_LUT_BITS 12
+__global__ __launch_bounds__(64)
+void k_huff_decode(const uint32_t *__restrict__ words, uint64_t total_bits, const mi_huffman_tree *__restrict__ tree,
+                   uint32_t n_nodes, const uint64_t *__restrict__ tile_off, uint64_t ntiles, uint32_t tile_bytes,
+                   uint8_t *__restrict__ out, uint64_t n, uint32_t *__restrict__ err)
+{
+    __shared__ uint16_t s_lut[1 << HUFF_LUT_BITS];      // len << 8 | symbol; 0 = longer than the table: walk
+    __shared__ int16_t  s_left[511], s_right[511];
+    __shared__ uint8_t  s_val[511];
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t i = lane; i < (1u << HUFF_LUT_BITS); i += 64) s_lut[i] = 0;
+    for (uint32_t i = lane; i < 511; i += 64) { s_left[i] = tree->left[i]; s_right[i] = tree->right[i]; s_val[i] = tree->value[i]; }
+    __syncthreads();
+    for (uint32_t s = lane; s < 256; s += 64) {
+        const uint32_t l = tree->length[s], c = tree->code[s];
+        if (l && l <= HUFF_LUT_BITS) {
+            const uint32_t lo = c << (HUFF_LUT_BITS - l), cnt = 1u << (HUFF_LUT_BITS - l);
+            for (uint32_t k = 0; k < cnt; ++k) s_lut[lo + k] = (uint16_t)((l << 8) | s);
+        }
+    }
+    __syncthreads();
+    const uint64_t t = (uint64_t)blockIdx.x * 64 + lane;
+    if (t >= ntiles) return;
+    const uint64_t o0 = t * tile_bytes, o1 = (o0 + tile_bytes < n) ? o0 + tile_bytes : n;
+    uint64_t bit = tile_off ? tile_off[t] : 0;
+    const int root = (int)n_nodes - 1;
+    uint32_t pack = 0;
+    bool bad = false;
+    for (uint64_t o = o0; o < o1; ++o) {
+        // next 32 stream bits, MSB first: bit j of the stream is bit 31 - j%32 of word j/32
+        const uint64_t wi = bit >> 5; const uint32_t sh = (uint32_t)(bit & 31u);
+        const uint64_t two = ((uint64_t)words[wi] << 32) | words[wi + 1];
+        const uint32_t peek = (uint32_t)((two << sh) >> 32);
+        const uint32_t e = s_lut[peek >> (32 - HUFF_LUT_BITS)];
+        uint32_t sym, len;
+        if (e) { sym = e & 0xFFu; len = e >> 8; }
+        else {
+            int node = root; len = 0;
+            while (s_left[node] >= 0 && len < 32) { node = ((peek >> (31 - len)) & 1u) ? s_right[node] : s_left[node]; ++len; }
+            if (s_left[node] >= 0) { bad = true; break; }
+            sym = s_val[node];
+        }
+        bit += len;
+        if (bit > total_bits) { bad = true; break; }
+        pack |= sym << (8 * (uint32_t)(o & 3u));                 // tiles start 4-byte aligned
+        if ((o & 3u) == 3u) { *reinterpret_cast<uint32_t *>(out + o - 3) = pack; pack = 0; }
+    }
+    if (!bad) for (uint64_t q = o1 & ~3ull; q < o1; ++q) out[q] = (uint8_t)(pack >> (8 * (uint32_t)(q & 3u)));
+    if (bad) atomicOr(err, 1u);
+}
+
+extern "C" mi_status mi_huffman_decode_dev(mi_ctx *ctx, const uint32_t *d_words, uint64_t total_bits,
+                                           const mi_huffman_tree *d_tree, uint32_t n_nodes, const uint64_t *d_tile_off,
+                                           uint8_t *d_out, uint64_t n, void *stream)
+{
+    if (!ctx || !d_words || !d_tree || (n && !d_out) || n_nodes < 3 || n_nodes > 511) return MI_ERR_ARG;
+    if (n == 0) return MI_OK;
+    if (((uintptr_t)d_out & 3u) != 0) return MI_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    mi_status st = mi_ws_reserve(ctx, 4096);
+    if (st) return st;
+    uint32_t *err = reinterpret_cast<uint32_t *>(ctx->ws);
+    MI_HIP(ctx, hipMemsetAsync(err, 0, 4, s));
+    const uint64_t ntiles = d_tile_off ? huff_ntiles(n) : 1;
+    const uint32_t tile_bytes = d_tile_off ? HUFF_TILE : 0xFFFFFFFFu;
+    {
+        mi_prof_scope p(ctx, "k_huff_decode", s, n);
+        hipLaunchKernelGGL(k_huff_decode, dim3((unsigned)((ntiles + 63) / 64)), dim3(64), 0, s, d_words, total_bits, d_tree,
+                           n_nodes, d_tile_off, ntiles, tile_bytes, d_out, d_tile_off ? n : (n < 0xFFFFFFFFull ? n : 0xFFFFFFFFull), err);
+    }
+    uint32_t h_err = 0;
+    MI_HIP(ctx, hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, s));
+    MI_HIP(ctx, hipStreamSynchronize(s));
+    return h_err ? MI_ERR_CORRUPT : MI_OK;
 }

@@ -11,6 +11,8 @@ import torch
 from . import _lib
 from .context import as_device_bytes, default_context
 
+TILE = 32768     # MI_HUFFMAN_TILE
+
 
 class HuffmanResult:
     def __init__(self, words, info, tree):
@@ -49,12 +51,34 @@ def huffman_compress(data, ctx=None):
     words = torch.empty(cap, dtype=torch.int32, device=ctx.device)
     d_info = torch.zeros(C.sizeof(_lib.HuffmanInfo), dtype=torch.uint8, device=ctx.device)
     d_tree = torch.zeros(C.sizeof(_lib.HuffmanTree), dtype=torch.uint8, device=ctx.device)
+    ntiles = (n + TILE - 1) // TILE
+    tile_off = torch.zeros(ntiles + 1, dtype=torch.int64, device=ctx.device)
     st = ctx.L.mi_huffman_encode_dev(ctx.h, C.c_void_p(d_in.data_ptr() if n else 0), n, C.c_void_p(words.data_ptr()), cap,
-                                     C.c_void_p(d_info.data_ptr()), C.c_void_p(d_tree.data_ptr()), ctx.stream_ptr())
+                                     C.c_void_p(d_info.data_ptr()), C.c_void_p(d_tree.data_ptr()),
+                                     C.c_void_p(tile_off.data_ptr()), ctx.stream_ptr())
     _lib.check(st, "mi_huffman_encode_dev")
     info = _lib.HuffmanInfo.from_buffer_copy(d_info.cpu().numpy().tobytes())
     if info.status != _lib.MI_OK:
         raise _lib.MiError(info.status, "huffman_compress")
     tree = _lib.HuffmanTree.from_buffer_copy(d_tree.cpu().numpy().tobytes())
     nw = (info.total_bits + 31) // 32
-    return HuffmanResult(words[:nw], info, tree)
+    words[nw:nw + 1] = 0            # the decoder peeks one word past the stream
+    r = HuffmanResult(words[:nw + 1][:nw], info, tree)
+    r._words_padded = words[:nw + 1]
+    r.tile_off = tile_off
+    r.n = n
+    r._d_tree = d_tree
+    return r
+
+
+def huffman_decompress(result, use_tiles=True, ctx=None):
+    """decode exactly result.n symbols (the reference decoder, huffman.c:330-364, overruns into the
+    pad bits; the original length is what `*output_size` carries on entry there)"""
+    ctx = ctx or default_context()
+    out = torch.empty(max(result.n, 1), dtype=torch.uint8, device=ctx.device)
+    st = ctx.L.mi_huffman_decode_dev(ctx.h, C.c_void_p(result._words_padded.data_ptr()), result.total_bits,
+                                     C.c_void_p(result._d_tree.data_ptr()), result.n_nodes,
+                                     C.c_void_p(result.tile_off.data_ptr() if use_tiles else 0),
+                                     C.c_void_p(out.data_ptr()), result.n, ctx.stream_ptr())
+    _lib.check(st, "mi_huffman_decode_dev")
+    return out[: result.n]

@@ -86,17 +86,24 @@ static inline uint64_t mi_huffman_bound_words(uint64_t n) { return n + 2; }
 /* d_words must hold cap_words u32 (>= ceil(bits/32)+1).  Words [0, ceil(bits/32)) are fully defined
  * (unused low bits of the last one are 0, as after init_bitwriter's memset); words past that are not touched.
  * d_info / d_tree are device buffers of sizeof(mi_huffman_info) / sizeof(mi_huffman_tree). */
+#define MI_HUFFMAN_TILE 32768u   /* input bytes per encoder tile (one sync point each) */
+/* d_tile_off (optional, may be NULL): u64[ceil(n/MI_HUFFMAN_TILE)+1], bit offset at which each
+ * tile's codes start — the only sync points a variable-length code has; the parallel decoder
+ * needs them, the reference format has no place for them. */
 mi_status mi_huffman_encode_dev(mi_ctx *ctx, const uint8_t *d_in, uint64_t n,
                                 uint32_t *d_words, uint64_t cap_words,
-                                mi_huffman_info *d_info, mi_huffman_tree *d_tree, void *stream);
+                                mi_huffman_info *d_info, mi_huffman_tree *d_tree,
+                                uint64_t *d_tile_off, void *stream);
 /* host-buffer convenience: copies in, encodes, copies out, synchronises. h_words: cap_words u32. */
 mi_status mi_huffman_encode(mi_ctx *ctx, const uint8_t *h_in, uint64_t n,
                             uint32_t *h_words, uint64_t cap_words,
                             mi_huffman_info *h_info, mi_huffman_tree *h_tree);
-/* decode exactly n symbols with the tree arrays; replaces huffman.c:330-364 */
+/* decode exactly n symbols with the tree arrays; replaces huffman.c:330-364.  With d_tile_off
+ * (from the encoder) one lane per tile; with NULL a single lane walks the whole stream.
+ * d_words needs one readable word past the stream.  Synchronises (returns MI_ERR_CORRUPT). */
 mi_status mi_huffman_decode_dev(mi_ctx *ctx, const uint32_t *d_words, uint64_t total_bits,
                                 const mi_huffman_tree *d_tree, uint32_t n_nodes,
-                                uint8_t *d_out, uint64_t n, void *stream);
+                                const uint64_t *d_tile_off, uint8_t *d_out, uint64_t n, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * LZ77 greedy tokenisers, block-parallel.

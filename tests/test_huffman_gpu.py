@@ -29,6 +29,10 @@ def _check_against_oracle(hf, data):
     assert np.array_equal(got.words.cpu().numpy().view(np.uint32), want["words"])
     kinds, vals, frs = orc.huff_preorder(orc.huff_histogram(data))
     assert got.preorder() == [(int(a), int(b), int(c)) for a, b, c in zip(kinds, vals, frs)]
+    arr = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    assert np.array_equal(hf.huffman_decompress(got).cpu().numpy(), arr)
+    if len(arr) <= 70000:
+        assert np.array_equal(hf.huffman_decompress(got, use_tiles=False).cpu().numpy(), arr)
     return got
 
 
@@ -84,6 +88,7 @@ def test_full_size_properties(hf):
     assert abs(sum(2.0 ** -int(l) for l in r1.lengths[present]) - 1.0) < 1e-12
     r2 = hf.huffman_compress(x)
     assert torch.equal(r1.words, r2.words)
+    assert torch.equal(hf.huffman_decompress(r1), x)
     # the first 1 MB of symbols decode correctly from the stream head
     w = r1.words[: (8 * 1_000_000) // 32 + 64].cpu().numpy().view(np.uint32)
     head = orc.huff_decode(w, len(w) * 32, hist.astype(np.uint32), 1_000_000)
