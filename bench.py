@@ -146,20 +146,12 @@ def main():
             torch.cuda.synchronize()
 
     def gather_streams():
-        """north star: RCCL gather of the per-block compressed streams to rank 0 (sizes first)"""
+        """north star: RCCL gather of the per-block compressed streams to rank 0 (sizes and block
+        tables first, then the variable-length streams point to point: sharded.gather_streams)"""
+        from compression_algorithms_amd import sharded
         st = last()
-        nbytes = torch.tensor([out_bytes()], dtype=torch.int64, device=dev)
-        sizes = [torch.zeros_like(nbytes) for _ in range(world)]
-        dist.all_gather(sizes, nbytes)
-        data = st.data if hasattr(st, "data") else st.words.view(torch.uint8)
-        if rank == 0:
-            bufs = [torch.empty(int(s.item()), dtype=torch.uint8, device=dev) for s in sizes]
-            bufs[0] = data[: int(sizes[0].item())]
-            reqs = [dist.irecv(bufs[r], src=r) for r in range(1, world)]
-            for q in reqs:
-                q.wait()
-        else:
-            dist.send(data[: int(nbytes.item())].contiguous(), dst=0)
+        table = st.block_bits if hasattr(st, "block_bits") else st.offsets
+        sharded.gather_streams(st.data, table, dst=0)
 
     for _ in range(args.warmup):
         step()

@@ -51,9 +51,9 @@ class KernelTime(C.Structure):
 # every symbol include/mi_codec.h declares; tests check that the library exports them all
 EXPORTS = [
     "mi_ctx_create", "mi_ctx_destroy", "mi_status_str", "mi_last_hip_error", "mi_version", "mi_sync",
-    "mi_huffman_encode_dev", "mi_huffman_encode", "mi_huffman_decode_dev",
-    "mi_lz_encode_dev", "mi_lz_encode", "mi_lz_decode_dev", "mi_lz_find_all_dev",
-    "mi_fse_block_bound", "mi_fse_encode_dev", "mi_fse_decode_dev", "mi_fse_normalise_dev",
+    "mi_huffman_encode_dev", "mi_huffman_encode", "mi_huffman_encode2", "mi_huffman_decode_dev", "mi_huffman_decode",
+    "mi_lz_encode_dev", "mi_lz_encode", "mi_lz_decode_dev", "mi_lz_decode", "mi_lz_find_all_dev",
+    "mi_fse_block_bound", "mi_fse_encode_dev", "mi_fse_decode_dev", "mi_fse_encode", "mi_fse_decode", "mi_fse_normalise_dev",
     "mi_set_profiling", "mi_get_kernel_times",
 ]
 

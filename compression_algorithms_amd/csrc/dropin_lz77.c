@@ -1,0 +1,86 @@
+/* dropin_lz77.c — algorithms/lz77 entry points over the HIP path (see include/mi_lz77.h). */
+#include <string.h>
+#include "../../include/mi_lz77.h"
+#include "dropin_common.h"
+
+#define TRAILER_MAGIC 0x4C5A37374D49424Bull   /* "KBIM77ZL" */
+
+static uint32_t g_wbits = WINDOW_BITS;
+void mi_lz77_set_window_bits(uint32_t w) { g_wbits = w; }
+static uint32_t cur_wbits(void)
+{
+    const char *e = getenv("MI_LZ77_WINDOW_BITS");
+    return e ? (uint32_t)atoi(e) : g_wbits;
+}
+
+uint64_t min(uint64_t a, uint64_t b) { return a < b ? a : b; }
+uint64_t max(uint64_t a, uint64_t b) { return a > b ? a : b; }
+
+char *read_input_buffer(const char *filename, uint64_t *size)      /* lz77.c:121-137 */
+{
+    FILE *f = fopen(filename, "rb");
+    if (!f) { fprintf(stderr, "Error: could not open file %s\n", filename); exit(1); }
+    fseek(f, 0, SEEK_END); *size = (uint64_t)ftell(f); fseek(f, 0, SEEK_SET);
+    char *buf = (char *)malloc(*size + 1);
+    if (fread(buf, 1, *size, f) != *size) { fprintf(stderr, "Error: short read on %s\n", filename); exit(1); }
+    fclose(f);
+    return buf;
+}
+
+bool check_buffer_equivalence(const char *a, const char *b, uint64_t size)     /* lz77.c:379-392 */
+{
+    uint64_t diff = 0;
+    for (uint64_t i = 0; i < size; ++i) diff += a[i] != b[i];
+    printf("Number of differences: %lu\n", (unsigned long)diff);
+    return diff == 0;
+}
+
+/* data layout: [stream: bit_index/8+1 bytes][pad to 8][magic][wbits][block][nblocks][bits[nblocks+1]] */
+BitStream *lz77_compress(const char *buffer, uint64_t size)
+{
+    mi_ctx *ctx = dropin_ctx();
+    mi_lz_params p = mi_lz_params_lz77(cur_wbits());
+    p.block = MI_LZ77_BLOCK;
+    const uint64_t nblocks = mi_lz_num_blocks(size, &p);
+    const uint64_t cap = mi_lz_bound_bytes(size, &p) + 64;
+    const uint64_t trailer = 8 * (4 + nblocks + 1);
+    uint8_t *data = (uint8_t *)calloc(1, cap + 8 + trailer);
+    uint64_t *bits = (uint64_t *)malloc(8 * (nblocks + 1));
+    BitStream *s = (BitStream *)malloc(sizeof *s);
+    if (!data || !bits || !s) { fprintf(stderr, "lz77_compress: out of memory\n"); exit(1); }
+    mi_status st = mi_lz_encode(ctx, &p, (const uint8_t *)buffer, size, data, cap, bits);
+    if (st != MI_OK) { fprintf(stderr, "lz77_compress: %s\n", mi_status_str(st)); exit(1); }
+    s->bit_index = bits[nblocks];
+    uint64_t at = (s->bit_index / 8 + 1 + 7) & ~7ull;
+    uint64_t *t = (uint64_t *)(data + at);
+    t[0] = TRAILER_MAGIC; t[1] = p.wbits; t[2] = p.block; t[3] = nblocks;
+    memcpy(t + 4, bits, 8 * (nblocks + 1));
+    s->data = (uint8_t *)realloc(data, at + trailer);          /* lz77.c:341-342 shrinks too */
+    free(bits);
+    return s;
+}
+
+char *lz77_decompress(BitStream *cs, uint64_t size, uint64_t *decompressed_size)
+{
+    mi_ctx *ctx = dropin_ctx();
+    const uint64_t total = cs->bit_index;
+    cs->bit_index = 0;                                          /* lz77.c:355-356 */
+    char *out = (char *)malloc(size ? size : 1);
+    uint64_t at = (total / 8 + 1 + 7) & ~7ull;
+    const uint64_t *t = (const uint64_t *)(cs->data + at);
+    mi_lz_params p = mi_lz_params_lz77(cur_wbits());
+    p.block = MI_LZ77_BLOCK;
+    uint64_t one[2] = {0, total};
+    const uint64_t *bits = one;
+    if (size > p.block) {
+        /* more than one block: the offsets must be the ones lz77_compress stored behind the stream */
+        if (t[0] != TRAILER_MAGIC) { fprintf(stderr, "lz77_decompress: stream carries no block table\n"); exit(1); }
+        p.wbits = (uint32_t)t[1]; p.tbits = p.wbits + 6; p.block = (uint32_t)t[2];
+        bits = t + 4;
+    }
+    mi_status st = mi_lz_decode(ctx, &p, cs->data, total / 8 + 1, bits, (uint8_t *)out, size);
+    if (st != MI_OK) { fprintf(stderr, "lz77_decompress: %s\n", mi_status_str(st)); exit(1); }
+    cs->bit_index = total;
+    *decompressed_size = size;
+    return out;
+}

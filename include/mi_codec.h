@@ -105,6 +105,14 @@ mi_status mi_huffman_decode_dev(mi_ctx *ctx, const uint32_t *d_words, uint64_t t
                                 const mi_huffman_tree *d_tree, uint32_t n_nodes,
                                 const uint64_t *d_tile_off, uint8_t *d_out, uint64_t n, void *stream);
 
+/* host-buffer decode (copies in/out, synchronises).  h_tile_off may be NULL (single-lane decode). */
+mi_status mi_huffman_decode(mi_ctx *ctx, const uint32_t *h_words, uint64_t total_bits,
+                            const mi_huffman_tree *h_tree, uint32_t n_nodes,
+                            const uint64_t *h_tile_off, uint8_t *h_out, uint64_t n);
+/* like mi_huffman_encode, also returning the tile offsets (h_tile_off: u64[ceil(n/MI_HUFFMAN_TILE)+1] or NULL) */
+mi_status mi_huffman_encode2(mi_ctx *ctx, const uint8_t *h_in, uint64_t n, uint32_t *h_words, uint64_t cap_words,
+                             mi_huffman_info *h_info, mi_huffman_tree *h_tree, uint64_t *h_tile_off);
+
 /* ------------------------------------------------------------------------------------
  * LZ77 greedy tokenisers, block-parallel.
  *   deflate flavour: algorithms/deflate/lz77.c:199-280 per block of `block` bytes with a
@@ -148,6 +156,9 @@ mi_status mi_lz_encode(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *h_in, 
 mi_status mi_lz_decode_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_stream,
                            const uint64_t *d_block_bits, uint8_t *d_out, uint64_t n, void *stream);
 
+mi_status mi_lz_decode(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *h_stream, uint64_t stream_bytes,
+                       const uint64_t *h_block_bits, uint8_t *h_out, uint64_t n);
+
 /* debugging / parity hooks used by the tests: find() at every position of every block
  * (0xFFFF = none), i.e. the output of the match-finder stage alone. */
 mi_status mi_lz_find_all_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_in, uint64_t n,
@@ -172,6 +183,11 @@ mi_status mi_fse_encode_dev(mi_ctx *ctx, const mi_fse_params *p, const uint8_t *
                             uint8_t *d_packed, uint64_t cap_bytes, uint64_t *d_offsets, void *stream);
 mi_status mi_fse_decode_dev(mi_ctx *ctx, const mi_fse_params *p, const uint8_t *d_packed,
                             const uint64_t *d_offsets, uint8_t *d_out, uint64_t n, void *stream);
+/* host-buffer versions.  h_packed needs mi_fse_block_bound() * nblocks bytes; h_offsets u64[nblocks+1] (bits). */
+mi_status mi_fse_encode(mi_ctx *ctx, const mi_fse_params *p, const uint8_t *h_in, uint64_t n,
+                        uint8_t *h_packed, uint64_t cap_bytes, uint64_t *h_offsets);
+mi_status mi_fse_decode(mi_ctx *ctx, const mi_fse_params *p, const uint8_t *h_packed, const uint64_t *h_offsets,
+                        uint8_t *h_out, uint64_t n);
 /* the normalisation step alone (main.zig:106-149), for parity tests: d_freq u64[256] -> d_cnt u32[256] */
 mi_status mi_fse_normalise_dev(mi_ctx *ctx, const uint64_t *d_freq, uint32_t table_log, uint32_t *d_cnt, void *stream);
 

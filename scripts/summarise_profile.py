@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 output (kernel-trace stats + FETCH_SIZE / WRITE_SIZE passes) into a small
+text + JSON summary that is committed under profiles/.  HBM bytes follow MI355X_MICROARCH.md:
+FETCH_SIZE and WRITE_SIZE are reported in KiB-like units of 1024 B?  — no: rocprofv3 reports them
+in KB (x1024 -> bytes); on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x, so both the
+raw and the x2-corrected read figure are listed."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+out, tag = sys.argv[1], sys.argv[2]
+
+
+def find(pattern):
+    hits = glob.glob(os.path.join(out, pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+summary = {"tag": tag, "kernels": {}}
+ks = find("trace/**/*kernel_stats.csv")
+if ks:
+    for row in csv.DictReader(open(ks)):
+        name = row.get("Name") or row.get("KernelName")
+        summary["kernels"][name.split("(")[0]] = {
+            "calls": int(row["Calls"]), "total_ms": float(row["TotalDurationNs"]) / 1e6,
+            "avg_us": float(row["AverageNs"]) / 1e3, "pct": float(row["Percentage"])}
+for key, pat in (("FETCH_SIZE", "pmc_fetch/**/*counter_collection.csv"), ("WRITE_SIZE", "pmc_write/**/*counter_collection.csv")):
+    f = find(pat)
+    if not f:
+        continue
+    acc, cnt = defaultdict(float), defaultdict(int)
+    for row in csv.DictReader(open(f)):
+        if row.get("Counter_Name") != key:
+            continue
+        k = row["Kernel_Name"].split("(")[0]
+        acc[k] += float(row["Counter_Value"]); cnt[k] += 1
+    for k in acc:
+        d = summary["kernels"].setdefault(k, {})
+        d[key + "_KB_per_launch"] = acc[k] / cnt[k]
+        d[key + "_launches"] = cnt[k]
+for k, d in summary["kernels"].items():
+    f, w = d.get("FETCH_SIZE_KB_per_launch"), d.get("WRITE_SIZE_KB_per_launch")
+    if f is not None and w is not None:
+        d["hbm_bytes_per_launch_raw"] = (f + w) * 1024
+        d["hbm_bytes_per_launch_fetch_x2"] = (2 * f + w) * 1024
+for b in ("bench_trace.json", "bench_fetch.json", "bench_write.json"):
+    p = os.path.join(out, b)
+    if os.path.exists(p):
+        lines = [l for l in open(p) if l.startswith("{")]
+        if lines:
+            summary[b] = json.loads(lines[-1])
+os.makedirs("gpurun_out/profiles", exist_ok=True)
+with open(f"gpurun_out/profiles/{tag}_summary.json", "w") as fh:
+    json.dump(summary, fh, indent=1)
+with open(f"gpurun_out/profiles/{tag}_kernel_stats.txt", "w") as fh:
+    fh.write(f"rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE : {tag}\n")
+    fh.write(f"{'kernel':34s} {'calls':>7s} {'avg_us':>10s} {'total_ms':>10s} {'pct':>6s} {'fetchKB':>12s} {'writeKB':>12s}\n")
+    for k, d in sorted(summary["kernels"].items(), key=lambda kv: -kv[1].get("total_ms", 0)):
+        fh.write(f"{k[:34]:34s} {d.get('calls', 0):7d} {d.get('avg_us', 0):10.1f} {d.get('total_ms', 0):10.2f} {d.get('pct', 0):6.2f} "
+                 f"{d.get('FETCH_SIZE_KB_per_launch', float('nan')):12.0f} {d.get('WRITE_SIZE_KB_per_launch', float('nan')):12.0f}\n")
+print(open(f"gpurun_out/profiles/{tag}_kernel_stats.txt").read())

@@ -1,0 +1,157 @@
+"""The drop-in libraries (reference names and struct layouts over the C ABI).
+CPU part: they load and export what the reference headers declare for this path.
+GPU part: called the way the reference's main.c files call them, results checked against the oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from compression_algorithms_amd import _lib, synth
+
+LIBS = {
+    "lz77": ["lz77_compress", "lz77_decompress", "check_buffer_equivalence", "read_input_buffer", "min", "max"],
+    "huffman": ["huffman_compress", "huffman_decompress", "gather_codes", "read_input_buffer"],
+    "deflate": ["compress", "decompress", "lz77_compress"],
+    "fse": ["fse_compress", "fse_decompress", "fse_compress_bound"],
+}
+
+
+def _load(name):
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return C.CDLL(os.path.join(_lib.LIB_DIR, f"libmi_{name}.so"))
+
+
+@pytest.mark.parametrize("name", sorted(LIBS))
+def test_exports(name):
+    L = _load(name)
+    for sym in LIBS[name]:
+        assert hasattr(L, sym), f"libmi_{name}.so lacks {sym}"
+
+
+class BitStream(C.Structure):
+    _fields_ = [("data", C.POINTER(C.c_uint8)), ("bit_index", C.c_uint64)]
+
+
+class BitWriter(C.Structure):
+    _fields_ = [("buffer", C.POINTER(C.c_uint32)), ("bit_idx", C.c_uint64), ("word_idx", C.c_uint64), ("buffer_size", C.c_uint64)]
+
+
+class Node(C.Structure):
+    pass
+
+
+Node._fields_ = [("value", C.c_uint8), ("frequency", C.c_uint32), ("left", C.POINTER(Node)), ("right", C.POINTER(Node))]
+
+
+def test_struct_layouts_match_reference():
+    # x86-64 SysV sizes of the reference structs
+    assert C.sizeof(BitStream) == 16 and C.sizeof(BitWriter) == 32 and C.sizeof(Node) == 24
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [20, 65536, 200_000])
+def test_lz77_like_reference_main(n):
+    from oracle import orc
+    L = _load("lz77")
+    L.lz77_compress.restype = C.POINTER(BitStream)
+    L.lz77_compress.argtypes = [C.c_void_p, C.c_uint64]
+    L.lz77_decompress.restype = C.c_void_p
+    L.lz77_decompress.argtypes = [C.POINTER(BitStream), C.c_uint64, C.POINTER(C.c_uint64)]
+    L.check_buffer_equivalence.restype = C.c_bool
+    L.check_buffer_equivalence.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    data = synth.enwik_like(200_000, seed=4).numpy()[:n].copy()
+    bs = L.lz77_compress(data.ctypes.data_as(C.c_void_p), n)             # lz77/main.c:27
+    nbits = int(bs.contents.bit_index)
+    got = np.ctypeslib.as_array(bs.contents.data, shape=(nbits // 8 + 1,)).copy()
+    blocks = [orc.lz77_encode(data[a:a + 65536].tobytes(), 14, 4) for a in range(0, n, 65536)]
+    assert nbits == sum(b[1] for b in blocks)
+    if n <= 65536:                                                       # one block: the reference's stream itself
+        assert np.array_equal(got[: (nbits + 7) // 8], blocks[0][0][: (nbits + 7) // 8])
+    dsz = C.c_uint64(0)
+    out = L.lz77_decompress(bs, n, C.byref(dsz))                         # lz77/main.c:33-37
+    assert dsz.value == n
+    assert L.check_buffer_equivalence(data.ctypes.data_as(C.c_void_p), out, n)   # lz77/main.c:47
+    if n > 65536:
+        # the reference's own sequential decoder semantics (oracle) also decode the concatenation
+        assert np.array_equal(orc.lz77_decode(got, nbits, n, 14, 4), data)
+
+
+@pytest.mark.gpu
+def test_huffman_like_reference_main():
+    from oracle import orc
+    L = _load("huffman")
+    L.huffman_compress.restype = Node
+    L.huffman_compress.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(BitWriter)]
+    L.huffman_decompress.argtypes = [C.POINTER(BitWriter), C.POINTER(Node), C.c_void_p, C.POINTER(C.c_uint64)]
+    L.gather_codes.argtypes = [C.POINTER(Node), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    for data in (np.frombuffer(b"nine times", dtype=np.uint8).copy(), synth.enwik_like(300_000, seed=4).numpy().copy()):
+        n = len(data)
+        w = BitWriter()
+        root = L.huffman_compress(data.ctypes.data_as(C.c_void_p), n, C.byref(w))      # huffman/main.c:50-54
+        want = orc.huff_encode(data)
+        assert (w.word_idx, w.bit_idx, w.buffer_size) == (want["word_idx"], want["bit_idx"], want["buffer_size"])
+        nw = w.word_idx + (1 if w.bit_idx else 0)
+        assert np.array_equal(np.ctypeslib.as_array(w.buffer, shape=(nw,)), want["words"])
+        codes = np.zeros(256, np.uint32); lens = np.zeros(256, np.uint8)
+        L.gather_codes(C.byref(root), 0, 0, codes.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(codes, want["codes"]) and np.array_equal(lens, want["lens"])
+        out = np.zeros(n, dtype=np.uint8)
+        osz = C.c_uint64(n)
+        L.huffman_decompress(C.byref(w), C.byref(root), out.ctypes.data_as(C.c_void_p), C.byref(osz))   # main.c:70-76
+        assert osz.value == n and np.array_equal(out, data)
+
+
+@pytest.mark.gpu
+def test_deflate_compress_file(tmp_path):
+    from oracle import orc
+    L = _load("deflate")
+
+    class StateData(C.Structure):
+        _fields_ = [("table", C.c_void_p), ("huffman_root", C.c_void_p), ("compressed_filename", C.c_char_p)]
+
+    L.compress.restype = StateData
+    L.compress.argtypes = [C.c_char_p]
+    L.decompress.argtypes = [C.POINTER(StateData), C.c_char_p]
+    data = synth.enwik_like(300_000, seed=6).numpy()
+    src = tmp_path / "data" / "enwik_test"
+    src.parent.mkdir()
+    data.tofile(src)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        sd = L.compress(str(src).encode())                               # deflate/main.c:10
+        assert sd.compressed_filename == b"enwik_test.deflate" and not sd.table
+        got = np.fromfile(tmp_path / "enwik_test.deflate", dtype=np.uint8)
+        want, _ = orc.deflate_stream(data, 65536, True)
+        assert np.array_equal(got, want)
+        L.decompress(C.byref(sd), None)
+        assert np.array_equal(np.fromfile(tmp_path / "enwik_test.deflate.orig", dtype=np.uint8), data)
+    finally:
+        os.chdir(cwd)
+    # the per-block entry point
+    L.lz77_compress.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
+    blk = data[:65536].copy()
+    out = np.zeros(2 * 65536 + 8, dtype=np.uint8)
+    m = C.c_uint64(0)
+    L.lz77_compress(blk.ctypes.data_as(C.c_void_p), 65536, out.ctypes.data_as(C.c_void_p), C.byref(m), None)
+    assert np.array_equal(out[: m.value], orc.Deflate().block_encode(blk))
+
+
+@pytest.mark.gpu
+def test_fse_c_entry_points():
+    L = _load("fse")
+    L.fse_compress_bound.restype = C.c_size_t
+    L.fse_compress_bound.argtypes = [C.c_size_t]
+    L.fse_compress.restype = C.c_size_t
+    L.fse_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.fse_decompress.restype = C.c_size_t
+    L.fse_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    data = synth.enwik_like(200_000, seed=6).numpy().copy()
+    out = np.zeros(L.fse_compress_bound(len(data)), dtype=np.uint8)
+    m = L.fse_compress(data.ctypes.data_as(C.c_void_p), len(data), out.ctypes.data_as(C.c_void_p))
+    assert 0 < m < len(data) * 0.7
+    back = np.zeros(len(data), dtype=np.uint8)
+    assert L.fse_decompress(out.ctypes.data_as(C.c_void_p), m, back.ctypes.data_as(C.c_void_p), len(back)) == len(data)
+    assert np.array_equal(back, data)
