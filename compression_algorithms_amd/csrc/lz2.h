@@ -1,0 +1,47 @@
+// lz2.h — data structures of the LDS-resident match finder (lz2_partition.hip, lz2_find.hip).
+#pragma once
+#include "lz_common.h"
+
+#define LZ2_NG_BITS   14
+#define LZ2_NG        (1u << LZ2_NG_BITS)   // bucket groups per block for the overflow certificate
+#define LZ2_TS        3584u                 // target entries per part
+#define LZ2_CAP       6144u                 // LDS capacity of a part (entries)
+#define LZ2_MAXPARTS  32u
+#define LZ2_BIG       16u                   // clusters of at least this many entries leave k_lz2_find
+#define LZ2_WAVE      128u                  // ... and from this size on a whole wave replays one cluster
+#define LZ2_MAXBIG    (LZ2_CAP / LZ2_BIG)   // exported clusters per part, at most
+#define LZ2_DESC_SMALL (LZ_MAX_BLOCK / LZ2_BIG + 32u)   // exported clusters per block, at most
+// export classes: 0: 16..31, 1: 32..63, 2: 64..127 (a lane per cluster, 64 clusters per wave);
+//                 3: 128..1024, 4: > 1024 (a wave per cluster)
+#define LZ2_NCLASS    5u
+#define LZ2_BIG_SMALL 1024u                 // size classes of the wave replay (LDS per wave: 6 B per entry)
+#define LZ2_PENDING16 0xFFFEu               // cand placeholder of an entry whose cluster went to the wave replay
+
+struct Lz2BlockMeta {
+    uint32_t n, nparts, base, fallback;
+    uint32_t nbig, nbig_entries;            // filled with atomics by k_lz2_find
+    uint32_t pad[2];
+    uint32_t part_start[LZ2_MAXPARTS];      // offset of the part's list inside the block's plist
+    uint32_t part_count[LZ2_MAXPARTS];
+    uint32_t part_lo[LZ2_MAXPARTS];         // first home' of the part
+};
+
+struct Lz2BigDesc {
+    uint32_t block;                          // local block index in the batch
+    uint32_t start;                          // first entry in the block's big-entry arrays
+    uint32_t count;
+    uint32_t anom;                           // slot (relative to the cluster) of bucket 0, or ~0u
+    uint32_t limit;                          // slot of bucket T for deflate's non-wrapping find, or ~0u
+    uint32_t pad[3];
+};
+
+struct Lz2Scratch {
+    uint16_t     *plist;        // [nb][65536] positions, grouped by part, time order inside a part
+    uint16_t     *cand;         // [nb][65536] find() result aligned with plist (LZ2_PENDING16: see bigcand)
+    Lz2BlockMeta *meta;         // [nb]
+    uint32_t     *fallback_count, *fallback_list;    // blocks the first pipeline has to do
+    uint16_t     *bigpos, *bigrs, *bigpid, *bigcand; // [nb][65536] entries of exported clusters, (cluster, time) order
+    Lz2BigDesc   *desc[LZ2_NCLASS];                  // per class: [nb * LZ2_DESC_SMALL] (class 4: [nb * 64])
+    uint32_t     *big_count;                         // [LZ2_NCLASS]
+    uint64_t     *dbg;                               // phase cycle counters (MI_LZ_DEBUG=1), else NULL
+};

@@ -1,0 +1,592 @@
+// lz2_find.hip — stage 2 and 3 of the LDS-resident match finder.
+//
+//   k_lz2_find   one workgroup per part (<= LZ2_CAP positions whose clusters lie inside the
+//                part, certified by stage 1).  Everything happens in LDS: words gathered once,
+//                positions sorted by home (3 stable radix passes), clusters from the parking
+//                sweep, a second sort by (cluster, time), then every cluster below LZ2_BIG
+//                entries is replayed by one lane; larger ones are exported.
+//   k_lz2_big    one WAVE per exported cluster: the occupancy bitmap lives in registers
+//                (4 dwords per lane), first-fit is a wave min-reduction instead of LDS round
+//                trips, entries stream through registers 64 at a time.  LDS holds only
+//                slot -> (word id, position) and entry -> slot, 6 bytes per entry, so dozens
+//                of clusters are in flight per CU and the serial chain of one cluster hides
+//                behind the others.
+//
+// Replaces the same reference functions as lz_find.hip (hash / insert_hash_table / find,
+// algorithms/lz77/lz77.c:13-108 and algorithms/deflate/lz77.c:14-174).
+#include "lz_common.h"
+#include "lz2.h"
+#include <stdlib.h>
+
+#define RS_HEAD 0x8000u
+#define RS_MASK 0x7FFFu
+
+__device__ __forceinline__ bool bm2_test(const uint32_t *bm, uint32_t b) { return (bm[b >> 5] >> (b & 31u)) & 1u; }
+
+// lane-per-cluster replay of a SMALL cluster [s, e) (< LZ2_BIG entries): plain word scan is enough
+__device__ void replay_small(const uint16_t *pos, uint16_t *rs, const uint16_t *pid, uint16_t *occ, uint32_t *bm,
+                             uint32_t s, uint32_t e, uint32_t W, uint32_t anom, uint32_t limit, uint16_t *cand_i)
+{
+    uint32_t ev = s;
+    bool anom_pending = anom != ~0u;
+    for (uint32_t i = s; i < e; ++i) {
+        const uint32_t p = pos[i], rsv = rs[i], r = rsv & RS_MASK, id = pid[i];
+        while (ev < i && (uint32_t)pos[ev] + W < p) {                   // FIFO retirement, lz77.c:70-76
+            const uint32_t b = rs[ev] & RS_MASK;
+            atomicAnd(&bm[b >> 5], ~(1u << (b & 31u)));
+            ++ev;
+        }
+        if (anom_pending && p > W - 1u) { atomicAnd(&bm[anom >> 5], ~(1u << (anom & 31u))); anom_pending = false; }
+        uint32_t res = LZ_NONE16;
+        for (uint32_t b = r;; ++b) {
+            if (b == limit && r < limit) break;
+            if (!bm2_test(bm, b)) break;
+            const uint32_t o = occ[b];
+            if (pid[o] == id) { res = pos[o]; break; }
+        }
+        cand_i[i] = (uint16_t)res;
+        uint32_t wi = r >> 5;                                            // first fit: word scan (inside the cluster by the parking bound)
+        uint32_t wv = bm[wi] | ((1u << (r & 31u)) - 1u);
+        while (wv == 0xFFFFFFFFu) wv = bm[++wi];
+        const uint32_t b = (wi << 5) + (uint32_t)__builtin_ctz(~wv);
+        atomicOr(&bm[b >> 5], 1u << (b & 31u));
+        occ[b] = (uint16_t)i;
+        rs[i] = (uint16_t)((rsv & RS_HEAD) | b);
+    }
+}
+
+__global__ __launch_bounds__(1024)
+void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scratch sc, uint64_t block0)
+{
+    // 16 bytes per entry + radix counters
+    __shared__ uint16_t s_pos[LZ2_CAP];                 // position by time index j
+    __shared__ uint32_t s_word[LZ2_CAP];                // word by j; later e_pos / e_rs (replay order)
+    __shared__ uint16_t s_j0[LZ2_CAP], s_j1[LZ2_CAP];   // sort ping-pong; later e_pid / (free)
+    __shared__ uint16_t s_g[LZ2_CAP];                   // cluster number by j; later occ
+    __shared__ uint16_t s_r[LZ2_CAP];                   // dense home slot by j; later cand by replay index
+    __shared__ uint16_t s_pid[LZ2_CAP];                 // word id by j (j of the first occurrence); later cand by j
+    __shared__ uint32_t s_cnt[16][256];
+    __shared__ uint32_t s_bm[LZ2_CAP / 32 + 2];
+    __shared__ int32_t  s_i32[18];
+    __shared__ uint32_t s_u32[18];
+    __shared__ uint32_t s_zslot, s_zgid, s_nbigl, s_ngroups;
+    __shared__ uint16_t s_gstart[LZ2_CAP + 2];          // replay index of the head of every cluster
+    __shared__ uint32_t s_big[3 * LZ2_MAXBIG];          // clusters exported by this part: {s, e, global dst}
+
+    const int tid = threadIdx.x;
+    const uint32_t lb = blockIdx.y, part = blockIdx.x;
+    Lz2BlockMeta *mt = sc.meta + lb;
+    long long tk = clock64();
+#define LZ2_TICK(k) do { if (sc.dbg && tid == 0) { long long t2 = clock64(); atomicAdd((unsigned long long *)&sc.dbg[k], (unsigned long long)(t2 - tk)); tk = t2; } } while (0)
+    if (mt->fallback || part >= mt->nparts) return;
+    const uint32_t m = mt->part_count[part];
+    if (m == 0) return;
+    const uint32_t pstart = mt->part_start[part], base = mt->base;
+    const uint64_t off = (block0 + lb) * (uint64_t)P.block;
+    const uint32_t nblk = mt->n;
+    const uint8_t *src = in + off;
+    const uint32_t T = 1u << P.tbits, Tmask = T - 1u, W = 1u << P.wbits;
+    const uint16_t *plist = sc.plist + (size_t)lb * LZ_MAX_BLOCK + pstart;
+    (void)n_total;
+
+    // ---- gather: positions (coalesced) and their words (4 unaligned bytes each from the block; bytes
+    //      past the block end read as zero, the parity definition of the reference's over-read)
+    for (uint32_t j = tid; j < m; j += 1024) {
+        const uint32_t p = plist[j];
+        s_pos[j] = (uint16_t)p;
+        uint32_t w = 0;
+        if (p + 8 <= nblk && (((uintptr_t)src) & 3u) == 0) {
+            const uint8_t *q = src + p;
+            const uintptr_t a = (uintptr_t)q & ~(uintptr_t)3;
+            const uint32_t sh = ((uintptr_t)q & 3u) * 8u;
+            const uint32_t lo = *reinterpret_cast<const uint32_t *>(a);
+            if (sh == 0) w = lo;
+            else w = (lo >> sh) | (*reinterpret_cast<const uint32_t *>(a + 4) << (32u - sh));
+        } else {
+            for (uint32_t k = 0; k < 4 && p + k < nblk; ++k) w |= (uint32_t)src[p + k] << (8 * k);
+        }
+        s_word[j] = w;
+    }
+    for (uint32_t i = tid; i < LZ2_CAP / 32 + 2; i += 1024) s_bm[i] = 0;
+    if (tid == 0) { s_zslot = ~0u; s_zgid = ~0u; s_nbigl = 0; }
+    __syncthreads();
+    auto homep = [&](uint32_t j) -> uint32_t { return ((lz_mix32(s_word[j]) & Tmask) - base) & Tmask; };
+    LZ2_TICK(0);
+
+    // ---- sort time indices by home', stable: identity -> j0 -> j1 -> j0
+    radix_pass_1024<8, uint32_t>(m, s_cnt, [&](uint32_t i) { return i; },
+        [&](uint32_t e) { return homep(e) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; });
+    radix_pass_1024<8, uint32_t>(m, s_cnt, [&](uint32_t i) { return (uint32_t)s_j0[i]; },
+        [&](uint32_t e) { return (homep(e) >> 8) & 255u; }, [&](uint32_t d, uint32_t e) { s_j1[d] = (uint16_t)e; });
+    radix_pass_1024<8, uint32_t>(m, s_cnt, [&](uint32_t i) { return (uint32_t)s_j1[i]; },
+        [&](uint32_t e) { return (homep(e) >> 16) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; });
+
+    LZ2_TICK(1);
+    // ---- parking sweep over the sorted order: 6 consecutive entries per thread
+    constexpr uint32_t CH = LZ2_CAP / 1024;
+    const uint32_t k0 = tid * CH, k1 = (k0 + CH < m) ? k0 + CH : m;
+    {
+        int32_t mx = INT32_MIN;
+        for (uint32_t k = k0; k < k1; ++k) { const int32_t g = (int32_t)homep(s_j0[k]) - (int32_t)k; mx = g > mx ? g : mx; }
+        int32_t gmax_total;
+        const int32_t premax = block_exclusive_scan<int32_t>(mx, OpMaxI32(), INT32_MIN, s_i32, &gmax_total);
+        uint32_t nheads = 0; int32_t lasthead = -1, lastrun = -1;
+        {
+            int32_t run = premax, prev_h = 0;
+            if (k0 > 0 && k0 < m) prev_h = (int32_t)homep(s_j0[k0 - 1]);
+            for (uint32_t k = k0; k < k1; ++k) {
+                const int32_t h = (int32_t)homep(s_j0[k]), g = h - (int32_t)k;
+                const bool head = (k == 0) || (g >= run);
+                run = g > run ? g : run;
+                if (head) { ++nheads; lasthead = (int32_t)k; }
+                if (k == 0 || h != prev_h) lastrun = (int32_t)k;
+                prev_h = h;
+            }
+        }
+        uint32_t total_heads; int32_t d1, d2;
+        const uint32_t gid_base = block_exclusive_scan<uint32_t>(nheads, OpAddU32(), 0u, s_u32, &total_heads);
+        if (tid == 0) s_ngroups = total_heads;
+        const int32_t gs_carry = block_exclusive_scan<int32_t>(lasthead, OpMaxI32(), -1, s_i32, &d1);
+        const int32_t hs_carry = block_exclusive_scan<int32_t>(lastrun, OpMaxI32(), -1, s_i32, &d2);
+        int32_t run = premax, prev_h = 0;
+        uint32_t cur_gs = 0, cur_gid = gid_base; int32_t cur_base = 0;
+        uint32_t cur_hs = 0, hs_word = 0, hs_j = 0;
+        if (k0 < m) {
+            if (k0 > 0) prev_h = (int32_t)homep(s_j0[k0 - 1]);
+            if (gs_carry >= 0) { cur_gs = (uint32_t)gs_carry; cur_base = (int32_t)homep(s_j0[cur_gs]); cur_gid = gid_base - 1u; }
+            if (hs_carry >= 0) { cur_hs = (uint32_t)hs_carry; hs_j = s_j0[cur_hs]; hs_word = s_word[hs_j]; }
+        }
+        uint32_t seen = 0;
+        for (uint32_t k = k0; k < k1; ++k) {
+            const uint32_t j = s_j0[k];
+            const int32_t h = (int32_t)homep(j), g = h - (int32_t)k;
+            const bool head = (k == 0) || (g >= run);
+            run = g > run ? g : run;
+            const uint32_t w = s_word[j];
+            if (head) { cur_gs = k; cur_base = h; cur_gid = gid_base + seen; ++seen; }
+            uint32_t id;
+            if (k == 0 || h != prev_h) { cur_hs = k; hs_word = w; hs_j = j; id = j; }
+            else if (w == hs_word) id = hs_j;
+            else {                                      // two different words share a home bucket: rare
+                id = j;
+                for (uint32_t kk = cur_hs + 1; kk < k; ++kk) { const uint32_t j2 = s_j0[kk]; if (s_word[j2] == w) { id = j2; break; } }
+            }
+            prev_h = h;
+            s_g[j] = (uint16_t)cur_gid;
+            s_r[j] = (uint16_t)(cur_gs + (uint32_t)(h - cur_base));
+            s_pid[j] = (uint16_t)id;
+        }
+    }
+    __syncthreads();
+    // bucket 0 (= bucket T on deflate's ring) sits at home' Z: the cluster that covers it gets the one-time
+    // spurious clear and, for deflate, the point where find() stops instead of wrapping
+    if (tid == 0) {
+        const uint32_t Z = (0u - base) & Tmask;
+        const uint32_t plo = mt->part_lo[part];
+        const uint32_t phi = (part + 1 < mt->nparts) ? mt->part_lo[part + 1] : T;
+        if (Z >= plo && (Z < phi || phi == T)) {
+            // last sorted entry with home' <= Z
+            int32_t lo = -1, hi = (int32_t)m - 1;
+            while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (homep(s_j0[mid]) <= Z) lo = mid; else hi = mid - 1; }
+            if (lo >= 0) {
+                const uint32_t j = s_j0[lo], gid = s_g[j];
+                const uint32_t slot = (uint32_t)s_r[j] + (Z - homep(j));
+                // last sorted index of that cluster (cluster numbers are non-decreasing along the order)
+                int32_t a = lo, b = (int32_t)m - 1;
+                while (a < b) { const int32_t mid = (a + b + 1) >> 1; if (s_g[s_j0[mid]] == gid) a = mid; else b = mid - 1; }
+                if (slot <= (uint32_t)a) { s_zslot = slot; s_zgid = gid; }
+            }
+        }
+    }
+    __syncthreads();
+
+    LZ2_TICK(2);
+    // ---- sort time indices by cluster number (they start in time order): identity -> j0 -> j1
+    radix_pass_1024<8, uint32_t>(m, s_cnt, [&](uint32_t i) { return i; },
+        [&](uint32_t e) { return (uint32_t)s_g[e] & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; });
+    radix_pass_1024<8, uint32_t>(m, s_cnt, [&](uint32_t i) { return (uint32_t)s_j0[i]; },
+        [&](uint32_t e) { return (uint32_t)s_g[e] >> 8; }, [&](uint32_t d, uint32_t e) { s_j1[d] = (uint16_t)e; });
+
+    LZ2_TICK(3);
+    // ---- permute into replay order (cluster, time).  e_pos / e_rs overlay the dead word array.
+    uint16_t *e_pos = reinterpret_cast<uint16_t *>(s_word);
+    uint16_t *e_rs = e_pos + LZ2_CAP;
+    uint16_t *e_pid = s_j0;
+    uint32_t regs[CH][3];
+    for (uint32_t c = 0; c < CH; ++c) {
+        const uint32_t i = tid + c * 1024u;
+        if (i < m) {
+            const uint32_t j = s_j1[i];
+            const bool head = (i == 0) || (s_g[j] != s_g[s_j1[i - 1]]);
+            regs[c][0] = s_pos[j];
+            regs[c][1] = (uint32_t)s_r[j] | (head ? RS_HEAD : 0u);
+            regs[c][2] = (uint32_t)s_pid[j] | ((uint32_t)s_g[j] << 16);
+        }
+    }
+    __syncthreads();
+    uint16_t *occ = s_g;                    // cluster numbers are dead from here on, except the one remembered in s_zgid
+    uint16_t *cand_i = s_r;
+    __shared__ uint16_t s_zhead;            // replay index of the head of the cluster that covers bucket 0
+    if (tid == 0) { s_zhead = 0xFFFF; s_gstart[s_ngroups] = (uint16_t)m; }
+    __syncthreads();
+    for (uint32_t c = 0; c < CH; ++c) {
+        const uint32_t i = tid + c * 1024u;
+        if (i < m) {
+            e_pos[i] = (uint16_t)regs[c][0]; e_rs[i] = (uint16_t)regs[c][1]; e_pid[i] = (uint16_t)regs[c][2];
+            if (regs[c][1] & RS_HEAD) {
+                s_gstart[regs[c][2] >> 16] = (uint16_t)i;
+                if ((regs[c][2] >> 16) == s_zgid) s_zhead = (uint16_t)i;
+            }
+        }
+    }
+    __syncthreads();
+
+    LZ2_TICK(4);
+    // ---- replay.  Clusters below LZ2_BIG entries: one lane each, lanes sorted by cluster size so that the
+    //      64 lanes of a wave run the same number of steps.  Larger clusters are exported by size class.
+    {
+        // cluster heads -> compact list (order irrelevant), sizes from the next head
+        __shared__ uint32_t s_ncl, s_bin[LZ2_BIG + 1];
+        if (tid == 0) s_ncl = 0;
+        if (tid <= (int)LZ2_BIG) s_bin[tid] = 0;
+        __syncthreads();
+        uint16_t *c_start = s_j1 + 0;                        // (s_j1 is still needed: cand back to time order) -> use s_pos, dead now
+        c_start = s_pos;                                     // [<= m/2] start of each lane-replayed cluster, bucketed by size
+        uint32_t my_s[CH], my_n[CH];
+        for (uint32_t c = 0; c < CH; ++c) {
+            const uint32_t i = tid + c * 1024u;
+            my_n[c] = 0; my_s[c] = i;
+            if (i < m && (e_rs[i] & RS_HEAD)) {
+                const uint32_t e = s_gstart[(regs[c][2] >> 16) + 1];      // clusters are contiguous and in cluster-number order
+                const uint32_t size = e - i;
+                my_n[c] = size;
+                if (size == 1) cand_i[i] = LZ_NONE16;
+                else if (size < LZ2_BIG) atomicAdd(&s_bin[size], 1u);
+                else {
+                    const uint32_t q = atomicAdd(&s_nbigl, 1u);
+                    if (q < LZ2_MAXBIG) { s_big[3 * q] = i; s_big[3 * q + 1] = e; }
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {                                      // bucket offsets, largest size first
+            uint32_t run = 0;
+            for (int sz = (int)LZ2_BIG - 1; sz >= 2; --sz) { const uint32_t t = s_bin[sz]; s_bin[sz] = run; run += t; }
+            s_ncl = run;
+        }
+        __syncthreads();
+        for (uint32_t c = 0; c < CH; ++c)
+            if (my_n[c] >= 2 && my_n[c] < LZ2_BIG) c_start[atomicAdd(&s_bin[my_n[c]], 1u)] = (uint16_t)my_s[c];
+        __syncthreads();
+        const uint32_t ncl = s_ncl;
+        for (uint32_t q = tid; q < ncl; q += 1024) {
+            const uint32_t s = c_start[q];
+            uint32_t e = s + 1;
+            while (e < m && !(e_rs[e] & RS_HEAD)) ++e;
+            const bool zc = (s == s_zhead);
+            replay_small(e_pos, e_rs, e_pid, occ, s_bm, s, e, W, zc ? s_zslot : ~0u, (zc && P.deflate) ? s_zslot : ~0u, cand_i);
+        }
+    }
+    __syncthreads();
+    LZ2_TICK(5);
+    // ---- export the larger clusters (cooperatively, coalesced)
+    const uint32_t nbig = s_nbigl < LZ2_MAXBIG ? s_nbigl : LZ2_MAXBIG;   // LZ2_CAP / LZ2_BIG clusters at most
+    for (uint32_t q = tid; q < nbig; q += 1024) {
+        const uint32_t s = s_big[3 * q], e = s_big[3 * q + 1], cnt = e - s;
+        const uint32_t dst = atomicAdd(&mt->nbig_entries, cnt);
+        s_big[3 * q + 2] = dst;
+        const uint32_t cls = cnt < 32 ? 0u : cnt < 64 ? 1u : cnt < LZ2_WAVE ? 2u : cnt <= LZ2_BIG_SMALL ? 3u : 4u;
+        const uint32_t k = atomicAdd(&sc.big_count[cls], 1u);
+        Lz2BigDesc d;
+        d.block = lb; d.start = dst; d.count = cnt;
+        const bool zc = (s == s_zhead);
+        d.anom = zc ? s_zslot - s : ~0u;
+        d.limit = (zc && P.deflate) ? s_zslot - s : ~0u;
+        d.pad[0] = pstart; d.pad[1] = d.pad[2] = 0;
+        sc.desc[cls][k] = d;
+        atomicAdd(&mt->nbig, 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = 0; b < nbig; ++b) {
+        const uint32_t s = s_big[3 * b], e = s_big[3 * b + 1];
+        for (uint32_t i = s + tid; i < e; i += 1024) cand_i[i] = LZ2_PENDING16;
+    }
+    for (uint32_t b = 0; b < nbig; ++b) {
+        const uint32_t s = s_big[3 * b], e = s_big[3 * b + 1], dst = s_big[3 * b + 2];
+        uint16_t *bp = sc.bigpos + (size_t)lb * LZ_MAX_BLOCK + dst;
+        uint16_t *br = sc.bigrs + (size_t)lb * LZ_MAX_BLOCK + dst;
+        uint16_t *bi = sc.bigpid + (size_t)lb * LZ_MAX_BLOCK + dst;
+        for (uint32_t i = s + tid; i < e; i += 1024) {
+            bp[i - s] = e_pos[i];
+            br[i - s] = (uint16_t)((e_rs[i] & RS_MASK) - s);    // home slot relative to the cluster
+            bi[i - s] = e_pid[i];
+        }
+    }
+    // ---- cand back to time order and out (coalesced)
+    uint16_t *cand_j = s_pid;
+    __syncthreads();
+    for (uint32_t i = tid; i < m; i += 1024) cand_j[s_j1[i]] = cand_i[i];
+    __syncthreads();
+    uint16_t *cout = sc.cand + (size_t)lb * LZ_MAX_BLOCK + pstart;
+    for (uint32_t j = tid; j < m; j += 1024) cout[j] = cand_j[j];
+    LZ2_TICK(6);
+    if (sc.dbg && tid == 0) atomicAdd((unsigned long long *)&sc.dbg[15], 1ull);
+}
+
+// =============================================================================================
+// wave-per-cluster replay
+// =============================================================================================
+#define RLANE(v, l) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (int)(l)))
+
+// occupancy bitmap of one cluster held in registers: slot s = bit (s & 31) of word (s >> 5); word w lives in
+// lane (w & 63), register (w >> 6).  Every index into w[] is a compile-time constant (unrolled), so the
+// array stays in VGPRs; all cross-lane traffic is v_readlane / ballots on wave-uniform indices.
+template <int NW>
+struct WaveBitmap {
+    uint32_t w[NW];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int q = 0; q < NW; ++q) w[q] = 0;
+    }
+    __device__ __forceinline__ uint32_t word(uint32_t wi) const {
+        const uint32_t wq = wi >> 6, ln = wi & 63u;
+        uint32_t r = 0;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) { const uint32_t t = RLANE(w[q], ln); if ((uint32_t)q == wq) r = t; }
+        return r;
+    }
+    __device__ __forceinline__ bool test(uint32_t slot) const { return (word(slot >> 5) >> (slot & 31u)) & 1u; }
+    __device__ __forceinline__ void flip(uint32_t slot, uint32_t lane) {
+        const uint32_t wi = slot >> 5, wq = wi >> 6;
+        const uint32_t bit = (lane == (wi & 63u)) ? (1u << (slot & 31u)) : 0u;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) w[q] ^= ((uint32_t)q == wq) ? bit : 0u;
+    }
+    __device__ __forceinline__ uint32_t first_zero_from(uint32_t r, uint32_t lane) const {
+        const uint32_t rw = r >> 5, lowmask = (1u << (r & 31u)) - 1u;
+        uint32_t res = ~0u;
+        bool found = false;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            const uint32_t wi = (uint32_t)q * 64u + lane;
+            uint32_t v = w[q];
+            if (wi < rw) v = 0xFFFFFFFFu; else if (wi == rw) v |= lowmask;
+            const uint64_t nz = __ballot(v != 0xFFFFFFFFu);
+            if (!found && nz) {
+                const uint32_t ln = (uint32_t)__builtin_ctzll(nz);
+                const uint32_t mv = RLANE(v, ln);
+                res = (((uint32_t)q * 64u + ln) << 5) + (uint32_t)__builtin_ctz(~mv);
+                found = true;
+            }
+        }
+        return res;
+    }
+};
+
+template <int LDS_ENTRIES, int NW>
+__global__ __launch_bounds__(64)
+void k_lz2_big(LzP P, Lz2Scratch sc, int large)
+{
+    __shared__ uint16_t s_opid[LDS_ENTRIES], s_opos[LDS_ENTRIES], s_slot[LDS_ENTRIES];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t ncl = sc.big_count[large ? 4 : 3];
+    const Lz2BigDesc *list = sc.desc[large ? 4 : 3];
+    const uint32_t W = 1u << P.wbits;
+    for (uint32_t ci = blockIdx.x; ci < ncl; ci += gridDim.x) {
+        const uint32_t d_block = list[ci].block, d_start = list[ci].start, n = list[ci].count;
+        const uint32_t d_anom = list[ci].anom, d_limit = list[ci].limit;
+        const uint16_t *bp = sc.bigpos + (size_t)d_block * LZ_MAX_BLOCK + d_start;
+        const uint16_t *br = sc.bigrs + (size_t)d_block * LZ_MAX_BLOCK + d_start;
+        const uint16_t *bi = sc.bigpid + (size_t)d_block * LZ_MAX_BLOCK + d_start;
+        uint16_t *bc = sc.bigcand + (size_t)d_block * LZ_MAX_BLOCK + d_start;
+        WaveBitmap<NW> bm;
+        bm.clear();
+        uint32_t ev = 0;
+        bool anom_pending = d_anom != ~0u;
+        uint32_t c_pos = 0, c_rs = 0, c_pid = 0, ev_pos = 0, ev_base = ~0u, out_acc = 0;
+        for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+            const uint32_t ii = i0 + lane;
+            if (ii < n) { c_pos = bp[ii]; c_rs = br[ii]; c_pid = bi[ii]; }
+            const uint32_t lim = (n - i0) < 64u ? (n - i0) : 64u;
+            for (uint32_t t = 0; t < lim; ++t) {
+                const uint32_t i = i0 + t;
+                const uint32_t p = RLANE(c_pos, t), r = RLANE(c_rs, t), id = RLANE(c_pid, t);
+                for (;;) {                                              // FIFO retirement (lz77.c:70-76)
+                    if (ev >= i) break;
+                    if ((ev & ~63u) != ev_base) { ev_base = ev & ~63u; const uint32_t q = ev_base + lane; ev_pos = q < n ? bp[q] : 0u; }
+                    const uint32_t pe = RLANE(ev_pos, ev & 63u);
+                    if (pe + W >= p) break;
+                    const uint32_t sl = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_slot[ev]);
+                    if (bm.test(sl)) bm.flip(sl, lane);                 // clears the bucket, whoever sits there
+                    ++ev;
+                }
+                if (anom_pending && p > W - 1u) { if (bm.test(d_anom)) bm.flip(d_anom, lane); anom_pending = false; }
+                uint32_t res = LZ_NONE16;
+                for (uint32_t b = r;; ++b) {                            // find
+                    if (b == d_limit && r < d_limit) break;
+                    if (!bm.test(b)) break;
+                    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)s_opid[b]) == id) {
+                        res = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_opos[b]);
+                        break;
+                    }
+                }
+                const uint32_t b = bm.first_zero_from(r, lane);         // insert: first fit
+                bm.flip(b, lane);
+                if (lane == 0) { s_opid[b] = (uint16_t)id; s_opos[b] = (uint16_t)p; s_slot[i] = (uint16_t)b; }
+                if (lane == t) out_acc = res;
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (ii < n) bc[ii] = (uint16_t)out_acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// =============================================================================================
+// lane-per-cluster replay of exported clusters of one size class [16,32) / [32,64) / [64,128):
+// 64 clusters per wave, every lane owns a private LDS region (slot -> word id, slot -> position,
+// entry -> slot, occupancy bits).  All lanes of a wave step through clusters of similar size.
+// =============================================================================================
+template <int CMAX>
+__global__ __launch_bounds__(64)
+void k_lz2_mid(LzP P, Lz2Scratch sc, int cls)
+{
+    constexpr int STRIDE = CMAX + 1;                      // odd stride in 16-bit units: spreads the lanes over the banks
+    __shared__ uint16_t s_opid[64 * STRIDE], s_opos[64 * STRIDE], s_slot[64 * STRIDE];
+    __shared__ uint32_t s_bits[64 * (CMAX / 32 + 1)];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t ncl = sc.big_count[cls];
+    const uint32_t ci = blockIdx.x * 64u + lane;
+    if (blockIdx.x * 64u >= ncl) return;
+    const bool active = ci < ncl;
+    Lz2BigDesc d;
+    d.block = 0; d.start = 0; d.count = 0; d.anom = ~0u; d.limit = ~0u;
+    if (active) d = sc.desc[cls][ci];
+    const uint32_t n = d.count, W = 1u << P.wbits;
+    const uint16_t *bp = sc.bigpos + (size_t)d.block * LZ_MAX_BLOCK + d.start;
+    const uint16_t *br = sc.bigrs + (size_t)d.block * LZ_MAX_BLOCK + d.start;
+    const uint16_t *bi = sc.bigpid + (size_t)d.block * LZ_MAX_BLOCK + d.start;
+    uint16_t *bc = sc.bigcand + (size_t)d.block * LZ_MAX_BLOCK + d.start;
+    uint16_t *opid = s_opid + lane * STRIDE, *opos = s_opos + lane * STRIDE, *slot = s_slot + lane * STRIDE;
+    uint32_t *bits = s_bits + lane * (CMAX / 32 + 1);
+    for (int k = 0; k < CMAX / 32 + 1; ++k) bits[k] = 0;
+    uint32_t ev = 0, ev_p = active && n ? bp[0] : 0u;
+    bool anom_pending = d.anom != ~0u;
+    for (uint32_t i = 0; i < (uint32_t)CMAX; ++i) {
+        if (i >= n) continue;                              // lanes with shorter clusters idle (same size class: < 2x)
+        const uint32_t p = bp[i], r = br[i], id = bi[i];
+        while (ev < i && ev_p + W < p) {                   // FIFO retirement
+            const uint32_t b = slot[ev];
+            bits[b >> 5] &= ~(1u << (b & 31u));
+            ++ev; ev_p = bp[ev];
+        }
+        if (anom_pending && p > W - 1u) { bits[d.anom >> 5] &= ~(1u << (d.anom & 31u)); anom_pending = false; }
+        uint32_t res = LZ_NONE16;
+        for (uint32_t b = r;; ++b) {
+            if (b == d.limit && r < d.limit) break;
+            if (!((bits[b >> 5] >> (b & 31u)) & 1u)) break;
+            if (opid[b] == id) { res = opos[b]; break; }
+        }
+        bc[i] = (uint16_t)res;
+        uint32_t wi = r >> 5;
+        uint32_t wv = bits[wi] | ((1u << (r & 31u)) - 1u);
+        while (wv == 0xFFFFFFFFu) wv = bits[++wi];
+        const uint32_t b = (wi << 5) + (uint32_t)__builtin_ctz(~wv);
+        bits[b >> 5] |= 1u << (b & 31u);
+        opid[b] = (uint16_t)id; opos[b] = (uint16_t)p; slot[i] = (uint16_t)b;
+    }
+}
+
+// lists -> by-position array (test hook mi_lz_find_all_dev and the fallback boundary)
+__global__ __launch_bounds__(1024)
+void k_lz2_scatter(Lz2Scratch sc, uint16_t *__restrict__ cand_by_pos /* [nb][65536] */)
+{
+    const uint32_t lb = blockIdx.x;
+    const Lz2BlockMeta *mt = sc.meta + lb;
+    if (mt->fallback) return;
+    const uint32_t n = mt->n;
+    const uint16_t *pl = sc.plist + (size_t)lb * LZ_MAX_BLOCK, *cd = sc.cand + (size_t)lb * LZ_MAX_BLOCK;
+    uint16_t *out = cand_by_pos + (size_t)lb * LZ_MAX_BLOCK;
+    for (uint32_t j = threadIdx.x; j < n; j += 1024) { const uint32_t c = cd[j]; if (c != LZ2_PENDING16) out[pl[j]] = (uint16_t)c; }
+    const uint32_t nb = mt->nbig_entries;
+    const uint16_t *bp = sc.bigpos + (size_t)lb * LZ_MAX_BLOCK, *bc = sc.bigcand + (size_t)lb * LZ_MAX_BLOCK;
+    for (uint32_t j = threadIdx.x; j < nb; j += 1024) out[bp[j]] = bc[j];
+}
+
+template __global__ void k_lz2_mid<32>(LzP, Lz2Scratch, int);
+template __global__ void k_lz2_mid<64>(LzP, Lz2Scratch, int);
+template __global__ void k_lz2_mid<128>(LzP, Lz2Scratch, int);
+template __global__ void k_lz2_big<LZ2_BIG_SMALL, 1>(LzP, Lz2Scratch, int);
+template __global__ void k_lz2_big<LZ2_CAP, 4>(LzP, Lz2Scratch, int);
+
+
+// =============================================================================================
+// host side
+// =============================================================================================
+size_t lz2_scratch_bytes(uint32_t nb)
+{
+    return (size_t)nb * (LZ_MAX_BLOCK * 2 * 6 + sizeof(Lz2BlockMeta) + 4 + 4 * LZ2_DESC_SMALL * sizeof(Lz2BigDesc) + 64 * sizeof(Lz2BigDesc)) + 16 * 256 + 4096;
+}
+
+void lz2_carve(mi_carver &cv, uint32_t nb, Lz2Scratch *sc)
+{
+    sc->plist = cv.take<uint16_t>((size_t)nb * LZ_MAX_BLOCK);
+    sc->cand = cv.take<uint16_t>((size_t)nb * LZ_MAX_BLOCK);
+    sc->meta = cv.take<Lz2BlockMeta>(nb);
+    sc->fallback_count = cv.take<uint32_t>(64);
+    sc->fallback_list = cv.take<uint32_t>(nb);
+    sc->bigpos = cv.take<uint16_t>((size_t)nb * LZ_MAX_BLOCK);
+    sc->bigrs = cv.take<uint16_t>((size_t)nb * LZ_MAX_BLOCK);
+    sc->bigpid = cv.take<uint16_t>((size_t)nb * LZ_MAX_BLOCK);
+    sc->bigcand = cv.take<uint16_t>((size_t)nb * LZ_MAX_BLOCK);
+    for (uint32_t c = 0; c < LZ2_NCLASS; ++c) sc->desc[c] = cv.take<Lz2BigDesc>((size_t)nb * (c == 4 ? 64 : LZ2_DESC_SMALL));
+    sc->big_count = sc->fallback_count + 16;
+    sc->dbg = getenv("MI_LZ_DEBUG") ? cv.take<uint64_t>(32) : nullptr;
+}
+
+static uint64_t *g_dbg_ptr = nullptr;
+extern "C" int mi_lz_debug_counters(uint64_t *out32)
+{
+    if (!g_dbg_ptr) return 0;
+    (void)hipDeviceSynchronize();
+    return hipMemcpy(out32, g_dbg_ptr, 32 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 1 : 0;
+}
+
+void lz2_launch_partition(const uint8_t *d_in, uint64_t n, const LzP &P, const Lz2Scratch &sc, uint64_t block0, uint32_t nb, hipStream_t s);
+
+mi_status lz2_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
+                         const Lz2Scratch &sc, hipStream_t s)
+{
+    MI_HIP(ctx, hipMemsetAsync(sc.fallback_count, 0, 256, s));      // fallback_count and big_count[2]
+    if (sc.dbg && g_dbg_ptr != sc.dbg) { g_dbg_ptr = sc.dbg; MI_HIP(ctx, hipMemsetAsync(sc.dbg, 0, 256, s)); }
+    {
+        mi_prof_scope p(ctx, "k_lz2_partition", s, (uint64_t)nb * P.block);
+        lz2_launch_partition(d_in, n, P, sc, block0, nb, s);
+    }
+    {
+        mi_prof_scope p(ctx, "k_lz2_find", s, (uint64_t)nb * P.block);
+        const uint32_t parts = (P.block + LZ2_TS - 1) / LZ2_TS;
+        hipLaunchKernelGGL(k_lz2_find, dim3(parts, nb), dim3(1024), 0, s, d_in, n, P, sc, block0);
+    }
+    {
+        mi_prof_scope p(ctx, "k_lz2_mid", s, (uint64_t)nb * P.block);
+        // grids cover the worst case; surplus workgroups read the class count and leave
+        const uint32_t gm = (nb * LZ2_DESC_SMALL + 63u) / 64u;
+        hipLaunchKernelGGL((k_lz2_mid<32>), dim3(gm), dim3(64), 0, s, P, sc, 0);
+        hipLaunchKernelGGL((k_lz2_mid<64>), dim3(gm / 2 + 1), dim3(64), 0, s, P, sc, 1);
+        hipLaunchKernelGGL((k_lz2_mid<128>), dim3(gm / 4 + 1), dim3(64), 0, s, P, sc, 2);
+    }
+    {
+        mi_prof_scope p(ctx, "k_lz2_big", s, (uint64_t)nb * P.block);
+        const uint32_t g1 = nb * 64u < 65536u ? nb * 64u : 65536u;
+        hipLaunchKernelGGL((k_lz2_big<LZ2_BIG_SMALL, 1>), dim3(g1), dim3(64), 0, s, P, sc, 0);
+        hipLaunchKernelGGL((k_lz2_big<LZ2_CAP, 4>), dim3(nb < 1024 ? nb : 1024), dim3(64), 0, s, P, sc, 1);
+    }
+    MI_HIP(ctx, hipGetLastError());
+    return MI_OK;
+}
+
+void lz2_launch_scatter(const Lz2Scratch &sc, uint16_t *cand_by_pos, uint32_t nb, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_lz2_scatter, dim3(nb), dim3(1024), 0, s, sc, cand_by_pos);
+}

@@ -1,0 +1,221 @@
+// lz2_partition.hip — stage 1 of the LDS-resident match finder: cut a block's positions into
+// home-bucket ranges ("parts") that no probe cluster can span, and write each part's positions,
+// in time order, to one contiguous list.
+//
+// Why: the first pipeline (lz_find.hip, kept as the fallback) sorts a whole 64 KiB block through
+// global scratch; rocprofv3 shows 170x HBM traffic amplification from its scattered 2-byte
+// stores (profiles/r01a).  A part of <= LZ2_CAP entries fits in LDS with everything the replay
+// needs, so the sorts of stage 2 never leave the CU.
+//
+// A part boundary must not be crossed by a cluster.  Cluster extents are only known after the
+// sort, so the boundary is certified conservatively from per-group counts (group = T/16384
+// consecutive buckets, c_g entries):  overflow out of a group is at most
+//     out_g = max(in_g + c_g - Gw, c_g - 1, 0)            (all entries on the last bucket)
+// a composition of x -> max(x + a, b) maps, i.e. a parallel prefix scan.  Wherever out_g == 0
+// no cluster crosses the end of group g.  The deflate flavour's insert wraps modulo T, so its
+// bucket space is a ring: the ring is cut at the first certified point and every home is
+// re-expressed relative to it (home' = home - base mod T); the lz77 flavour never wraps and
+// keeps base = 0.
+#include "lz_common.h"
+#include "lz2.h"
+
+struct AffMax { int32_t a, b; };                     // x -> max(x + a, b)
+__device__ __forceinline__ uint64_t am_pack(AffMax f) { return ((uint64_t)(uint32_t)f.a << 32) | (uint32_t)f.b; }
+__device__ __forceinline__ AffMax am_unpack(uint64_t v) { AffMax f; f.a = (int32_t)(v >> 32); f.b = (int32_t)(uint32_t)v; return f; }
+#define AM_NEG (-(1 << 28))
+// (second after first)
+__device__ __forceinline__ AffMax am_then(AffMax first, AffMax second)
+{
+    AffMax r;
+    r.a = first.a + second.a;
+    if (r.a < AM_NEG) r.a = AM_NEG;
+    int32_t t = first.b + second.a;
+    if (t < AM_NEG) t = AM_NEG;
+    r.b = t > second.b ? t : second.b;
+    return r;
+}
+struct OpAm { __device__ uint64_t operator()(uint64_t earlier, uint64_t later) const { return am_pack(am_then(am_unpack(earlier), am_unpack(later))); } };
+
+__global__ __launch_bounds__(1024)
+void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scratch sc, uint64_t block0)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[LZ_MAX_BLOCK + LZ_TAIL + 16];
+    __shared__ uint32_t s_grp[LZ2_NG];               // counts -> inclusive prefix; later the staging area
+    __shared__ uint32_t s_safe[LZ2_NG / 32];
+    __shared__ uint32_t s_cnt[16][256];
+    __shared__ uint64_t s_scan64[18];
+    __shared__ uint32_t s_scan32[18];
+    __shared__ uint32_t s_thr[LZ2_MAXPARTS + 1];     // part k = home' in [s_thr[k], s_thr[k+1])
+    __shared__ uint32_t s_pstart[LZ2_MAXPARTS + 1], s_pdone[LZ2_MAXPARTS], s_seg[LZ2_MAXPARTS + 1];
+    __shared__ uint32_t s_s0, s_flag;
+
+    const int tid = threadIdx.x;
+    const uint32_t lb = blockIdx.x;
+    const uint64_t off = (block0 + lb) * (uint64_t)P.block;
+    const uint32_t n = (uint32_t)((n_total - off) < P.block ? (n_total - off) : P.block);
+    const uint8_t *src = in + off;
+    const uint32_t T = 1u << P.tbits, Tmask = T - 1u;
+    const uint32_t gshift = P.tbits - LZ2_NG_BITS, Gw = 1u << gshift;
+
+    const bool vec_ok = (((uintptr_t)src) & 15u) == 0;
+    for (uint32_t i = tid * 16u; i < LZ_MAX_BLOCK + LZ_TAIL; i += 1024u * 16u) {
+        if (vec_ok && i + 16u <= n) *reinterpret_cast<uint4 *>(s_in + i) = *reinterpret_cast<const uint4 *>(src + i);
+        else {
+#pragma unroll
+            for (uint32_t k = 0; k < 16; ++k) s_in[i + k] = (i + k < n) ? src[i + k] : (uint8_t)0;
+        }
+    }
+    for (uint32_t i = tid; i < LZ2_NG; i += 1024) s_grp[i] = 0;
+    for (uint32_t i = tid; i < LZ2_NG / 32; i += 1024) s_safe[i] = 0;
+    if (tid == 0) { s_s0 = ~0u; s_flag = 0; }
+    __syncthreads();
+    auto home_of = [&](uint32_t p) -> uint32_t { return lz_mix32(lds_word(s_in, p)) & Tmask; };
+    for (uint32_t p = tid; p < n; p += 1024) atomicAdd(&s_grp[home_of(p) >> gshift], 1u);
+    __syncthreads();
+
+    // ---- overflow certificate: 16 consecutive groups per thread
+    const uint32_t g0 = tid * (LZ2_NG / 1024);
+    AffMax mine{0, AM_NEG};
+    for (uint32_t k = 0; k < LZ2_NG / 1024; ++k) {
+        const int32_t c = (int32_t)s_grp[g0 + k];
+        mine = am_then(mine, AffMax{c - (int32_t)Gw, c > 0 ? c - 1 : 0});
+    }
+    uint64_t tot64;
+    const uint64_t pre64 = block_exclusive_scan<uint64_t>(am_pack(mine), OpAm(), am_pack(AffMax{0, AM_NEG}), s_scan64, &tot64);
+    const AffMax pre = am_unpack(pre64), total = am_unpack(tot64);
+    // carry into group 0: the ring's fixed point for deflate (F(0) = total.b since total.a = n - T < 0), 0 for lz77
+    const int32_t x0 = P.deflate ? (total.b > 0 ? total.b : 0) : 0;
+    {
+        int32_t x = x0 + pre.a > pre.b ? x0 + pre.a : pre.b;
+        if (x < 0) x = 0;
+        uint32_t safe_bits = 0;
+        for (uint32_t k = 0; k < LZ2_NG / 1024; ++k) {
+            const int32_t c = (int32_t)s_grp[g0 + k];
+            int32_t o = x + c - (int32_t)Gw;
+            const int32_t o2 = c > 0 ? c - 1 : 0;
+            o = o > o2 ? o : o2;
+            if (o < 0) o = 0;
+            if (o == 0) safe_bits |= 1u << k;
+            x = o;
+        }
+        // 16 groups per thread: two threads share a 32-bit word
+        atomicOr(&s_safe[g0 >> 5], safe_bits << (g0 & 31u));
+        if (safe_bits) atomicMin(&s_s0, g0 + (uint32_t)__builtin_ctz(safe_bits));
+    }
+    // inclusive prefix of counts, in place
+    {
+        uint32_t sum = 0;
+        for (uint32_t k = 0; k < LZ2_NG / 1024; ++k) sum += s_grp[g0 + k];
+        uint32_t tot;
+        uint32_t run = block_exclusive_scan<uint32_t>(sum, OpAddU32(), 0u, s_scan32, &tot);
+        for (uint32_t k = 0; k < LZ2_NG / 1024; ++k) { run += s_grp[g0 + k]; s_grp[g0 + k] = run; }
+    }
+    __syncthreads();
+
+    // ---- cut the ring / choose the parts
+    Lz2BlockMeta *mt = sc.meta + lb;
+    const uint32_t s0 = s_s0;
+    const bool no_safe = (s0 == ~0u);
+    // rotated group order starts after s0 (deflate) or at group 0 (lz77: nothing wraps into bucket 0)
+    const uint32_t gstart = P.deflate ? (no_safe ? 0u : ((s0 + 1u) & (LZ2_NG - 1u))) : 0u;
+    const uint32_t base = gstart << gshift;
+    auto cum_incl = [&](uint32_t gr) -> uint32_t {      // entries in rotated groups 0..gr
+        const uint32_t g = (gstart + gr) & (LZ2_NG - 1u);
+        const uint32_t before = gstart ? s_grp[gstart - 1] : 0u;
+        return g >= gstart ? s_grp[g] - before : s_grp[g] + (n - before);
+    };
+    auto is_safe = [&](uint32_t gr) -> bool {
+        const uint32_t g = (gstart + gr) & (LZ2_NG - 1u);
+        return (s_safe[g >> 5] >> (g & 31u)) & 1u;
+    };
+    const uint32_t K = (n + LZ2_TS - 1) / LZ2_TS;       // <= LZ2_MAXPARTS
+    if (tid < K + 1) {
+        uint32_t thr;
+        if (tid == 0) thr = 0;
+        else if ((uint32_t)tid == K) thr = T;           // the last part takes everything up to the cut
+        else {
+            const uint32_t target = tid * LZ2_TS;
+            uint32_t lo = 0, hi = LZ2_NG - 1;           // first rotated group whose inclusive count exceeds target
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cum_incl(mid) > target) hi = mid; else lo = mid + 1; }
+            // boundary after the last certified group strictly before `lo`
+            int32_t gr = (int32_t)lo - 1;
+            while (gr >= 0 && !is_safe((uint32_t)gr)) --gr;
+            thr = gr < 0 ? 0u : ((uint32_t)gr + 1u) << gshift;
+        }
+        s_thr[tid] = thr;
+    }
+    __syncthreads();
+    // part sizes; refuse the block if any part exceeds the LDS capacity of stage 2
+    if (tid < K) {
+        const uint32_t a = s_thr[tid], b = s_thr[tid + 1];
+        auto cnt_below = [&](uint32_t h) -> uint32_t {  // entries with home' < h (h is a multiple of Gw or T)
+            if (h == 0) return 0u;
+            return cum_incl((h >> gshift) - 1u);
+        };
+        const uint32_t cnt = b > a ? cnt_below(b) - cnt_below(a) : 0u;
+        s_pstart[tid] = cnt_below(a);
+        s_pdone[tid] = 0;
+        if (cnt > LZ2_CAP) atomicOr(&s_flag, 1u);
+        mt->part_start[tid] = cnt_below(a);
+        mt->part_count[tid] = cnt;
+        mt->part_lo[tid] = a;
+    }
+    if (tid == 0) {
+        s_pstart[K] = n;
+        mt->n = n; mt->nparts = K; mt->base = base;
+        mt->nbig = 0; mt->nbig_entries = 0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const bool fb = (s_flag != 0) || (P.deflate && no_safe);
+        mt->fallback = fb ? 1u : 0u;
+        if (fb) { const uint32_t k = atomicAdd(sc.fallback_count, 1u); sc.fallback_list[k] = lb; }
+    }
+    if (s_flag != 0 || (P.deflate && no_safe)) return;
+
+    // ---- positions -> part lists, time order kept: 8192 positions at a time through LDS
+    uint16_t *stage = reinterpret_cast<uint16_t *>(s_grp);              // [8192], the group array is dead now
+    uint8_t  *stage_part = reinterpret_cast<uint8_t *>(s_grp) + 16384;  // [8192]
+    uint16_t *plist = sc.plist + (size_t)lb * LZ_MAX_BLOCK;
+    auto part_of = [&](uint32_t p) -> uint32_t {
+        const uint32_t h = (home_of(p) - base) & Tmask;
+        uint32_t lo = 0, hi = K - 1;                    // last k with thr[k] <= h
+        while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (s_thr[mid] <= h) lo = mid; else hi = mid - 1; }
+        return lo;
+    };
+    for (uint32_t e0 = 0; e0 < n; e0 += 8192u) {
+        const uint32_t en = (n - e0) < 8192u ? (n - e0) : 8192u;
+        radix_pass_1024<5, uint32_t>(en, s_cnt,
+            [&](uint32_t i) { const uint32_t p = e0 + i; return p | (part_of(p) << 16); },
+            [&](uint32_t e) { return e >> 16; },
+            [&](uint32_t j, uint32_t e) { stage[j] = (uint16_t)e; stage_part[j] = (uint8_t)(e >> 16); });
+        // segment starts of this slab: first index of each part in the staged order
+        if (tid <= (int)K) s_seg[tid] = en;
+        __syncthreads();
+        for (uint32_t i = tid; i < en; i += 1024) {
+            const uint32_t pk = stage_part[i];
+            if (i == 0 || stage_part[i - 1] != pk) s_seg[pk] = i;
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < en; i += 1024) {
+            const uint32_t pk = stage_part[i];
+            plist[s_pstart[pk] + s_pdone[pk] + (i - s_seg[pk])] = stage[i];
+        }
+        __syncthreads();
+        if (tid < (int)K) {
+            // count of part tid in this slab = next present segment start - own start
+            uint32_t nxt = en;
+            if (s_seg[tid] != en) {
+                for (uint32_t k2 = tid + 1; k2 < K; ++k2) if (s_seg[k2] != en) { nxt = s_seg[k2]; break; }
+                s_pdone[tid] += nxt - s_seg[tid];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+
+void lz2_launch_partition(const uint8_t *d_in, uint64_t n, const LzP &P, const Lz2Scratch &sc, uint64_t block0, uint32_t nb, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_lz2_partition, dim3(nb), dim3(1024), 0, s, d_in, n, P, sc, block0);
+}

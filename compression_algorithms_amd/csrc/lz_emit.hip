@@ -13,6 +13,7 @@
 //                    thread per output dword)
 //   k_lz_decode      one wave per block; replaces lz77_decompress (lz77.c:347-377)
 #include "lz_common.h"
+#include "lz2.h"
 
 __device__ __forceinline__ uint32_t select_bit(uint64_t m, uint32_t r)   // index of the r-th set bit
 {
@@ -21,7 +22,8 @@ __device__ __forceinline__ uint32_t select_bit(uint64_t m, uint32_t r)   // inde
 }
 
 __global__ __launch_bounds__(1024)
-void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, LzScratch sc, uint64_t block0)
+void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, LzScratch sc, Lz2Scratch s2, int use_v2,
+                     uint64_t block0)
 {
     // region0: input bytes -> exit tables [64][1024] -> {token base, match base, staging window}
     __shared__ __attribute__((aligned(16))) uint8_t s_r0[LZ_MAX_BLOCK + LZ_TAIL + 16];
@@ -53,9 +55,10 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     }
     __syncthreads();
 
-    // ---- A: token length at every position, were a token to start there
-    for (uint32_t p = tid; p < n; p += 1024u) {
-        const uint32_t c = cand[p];
+    // ---- A: token length at every position, were a token to start there.  The LDS-resident finder hands
+    //      over (position, candidate) LISTS (coalesced); the first pipeline an array indexed by position.
+    const bool lists = use_v2 && !s2.meta[lb].fallback;
+    auto token_len = [&](uint32_t p, uint32_t c) -> uint32_t {
         uint32_t len = 0;
         if (c != LZ_NONE16) {
             const uint32_t dist = p - c;
@@ -65,7 +68,19 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
                 while (len < max_len && s_r0[c + len] == s_r0[p + len]) ++len;  // no `p < size` bound: zero tail
             }
         }
-        s_L[p] = (uint8_t)len;
+        return len;
+    };
+    const uint16_t *l_pos = s2.plist + (size_t)lb * LZ_MAX_BLOCK, *l_cand = s2.cand + (size_t)lb * LZ_MAX_BLOCK;
+    const uint16_t *b_pos = s2.bigpos + (size_t)lb * LZ_MAX_BLOCK, *b_cand = s2.bigcand + (size_t)lb * LZ_MAX_BLOCK;
+    const uint32_t nbig = lists ? s2.meta[lb].nbig_entries : 0u;
+    if (lists) {
+        for (uint32_t j = tid; j < n; j += 1024u) {
+            const uint32_t c = l_cand[j];
+            if (c != LZ2_PENDING16) { const uint32_t p = l_pos[j]; s_L[p] = (uint8_t)token_len(p, c); }
+        }
+        for (uint32_t j = tid; j < nbig; j += 1024u) { const uint32_t p = b_pos[j]; s_L[p] = (uint8_t)token_len(p, b_cand[j]); }
+    } else {
+        for (uint32_t p = tid; p < n; p += 1024u) s_L[p] = (uint8_t)token_len(p, cand[p]);
     }
     __syncthreads();
 
@@ -144,9 +159,19 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     uint32_t *tb = reinterpret_cast<uint32_t *>(s_r0);            // [1025]
     uint32_t *mb = tb + 1026;                                      // [1025]
     uint32_t *stage = mb + 1026;                                   // [1024 + 4]
+    uint16_t *md = reinterpret_cast<uint16_t *>(stage + 1032);   // [<= 16384] distance of the k-th match token
     tb[tid] = tbase; mb[tid] = mbase;
     if (tid == 0) { tb[1024] = ntok; mb[1024] = nmat; }
     __syncthreads();
+    if (lists) {
+        auto put = [&](uint32_t p, uint32_t c) {
+            const uint32_t ch = p >> 6, o = p & 63u;
+            if ((s_mat[ch] >> o) & 1ull) md[mb[ch] + (uint32_t)__popcll(s_mat[ch] & ((1ull << o) - 1ull))] = (uint16_t)(p - c);
+        };
+        for (uint32_t j = tid; j < n; j += 1024u) { const uint32_t c = l_cand[j]; if (c != LZ2_PENDING16 && c != LZ_NONE16) put(l_pos[j], c); }
+        for (uint32_t j = tid; j < nbig; j += 1024u) { const uint32_t c = b_cand[j]; if (c != LZ_NONE16) put(b_pos[j], c); }
+        __syncthreads();
+    }
 
     // ---- D: emit, 1024 tokens per window
     const uint32_t LB = P.deflate ? 16u : 9u, MB = P.deflate ? 32u : (1u + P.wbits + P.lbits);
@@ -165,7 +190,7 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
             const uint32_t mbefore = mb[c] + (uint32_t)__popcll(s_mat[c] & below);
             q = (uint64_t)(t - mbefore) * LB + (uint64_t)mbefore * MB;
             if ((s_mat[c] >> o) & 1ull) {
-                const uint32_t d = p - cand[p], l = s_L[p];
+                const uint32_t d = lists ? (uint32_t)md[mbefore] : p - cand[p], l = s_L[p];
                 v = P.deflate ? (1u | (d << 8) | (l << 24)) : (1u | (d << 1) | (l << (1u + P.wbits)));
                 nbits = MB;
             } else {
@@ -325,7 +350,10 @@ void k_lz_decode(const uint8_t *__restrict__ stream, const uint64_t *__restrict_
 // host side
 // =============================================================================================
 size_t   lz_scratch_bytes(uint32_t nb);
-void     lz_carve(mi_ctx *ctx, uint32_t nb, LzScratch *sc);
+void     lz_carve(mi_ctx *ctx, uint32_t nb, LzScratch *sc, Lz2Scratch *sc2);
+bool     lz_use_v2();
+mi_status lz_run_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
+                      const LzScratch &sc, const Lz2Scratch &sc2, hipStream_t s);
 mi_status lz_check_params(const mi_lz_params *p);
 mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
                         const LzScratch &sc, hipStream_t s);
@@ -345,8 +373,8 @@ extern "C" mi_status mi_lz_encode_dev(mi_ctx *ctx, const mi_lz_params *p, const 
     const uint32_t nbmax = lz_batch_blocks(nblocks);
     st = mi_ws_reserve(ctx, lz_scratch_bytes(nbmax) + 4096);
     if (st) return st;
-    LzScratch sc;
-    lz_carve(ctx, nbmax, &sc);
+    LzScratch sc; Lz2Scratch sc2;
+    lz_carve(ctx, nbmax, &sc, &sc2);
     // two small device words after the carve: running bit total, local exclusive offsets
     uint64_t *base_bits = reinterpret_cast<uint64_t *>(sc.giant_count + 16);
     uint64_t *excl_local = sc.block_bits;                       // reused: [nb+1] after the scan (in place is fine)
@@ -354,11 +382,11 @@ extern "C" mi_status mi_lz_encode_dev(mi_ctx *ctx, const mi_lz_params *p, const 
     if (nblocks == 0) { MI_HIP(ctx, hipMemsetAsync(d_block_bits, 0, 8, s)); return MI_OK; }
     for (uint64_t b0 = 0; b0 < nblocks; b0 += nbmax) {
         const uint32_t nb = (uint32_t)((nblocks - b0) < nbmax ? (nblocks - b0) : nbmax);
-        st = lz_find_batch(ctx, P, d_in, n, b0, nb, sc, s);
+        st = lz_run_find(ctx, P, d_in, n, b0, nb, sc, sc2, s);
         if (st) return st;
         {
             mi_prof_scope pr(ctx, "k_lz_parse_emit", s, (uint64_t)nb * P.block);
-            hipLaunchKernelGGL(k_lz_parse_emit, dim3(nb), dim3(1024), 0, s, d_in, n, P, sc, b0);
+            hipLaunchKernelGGL(k_lz_parse_emit, dim3(nb), dim3(1024), 0, s, d_in, n, P, sc, sc2, lz_use_v2() ? 1 : 0, b0);
         }
         hipLaunchKernelGGL(k_lz_scan_blocks, dim3(1), dim3(1024), 0, s, sc.block_bits, nb, base_bits, excl_local, d_block_bits + b0);
         {

@@ -15,13 +15,15 @@
 // Output: cand[p] = what find(word at p) returns in the table state after positions 0..p-1
 // were inserted (0xFFFF = none).  The parse consumes it in lz_emit.hip.
 #include "lz_common.h"
+#include "lz2.h"
 #include <stdlib.h>
 
 // =============================================================================================
 // k_lz_sort_home
 // =============================================================================================
 __global__ __launch_bounds__(1024)
-void k_lz_sort_home(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, LzScratch sc, uint64_t block0)
+void k_lz_sort_home(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, LzScratch sc, uint64_t block0,
+                    const uint32_t *__restrict__ blist, const uint32_t *__restrict__ bcount)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_in[LZ_MAX_BLOCK + LZ_TAIL + 16];
     __shared__ uint32_t s_cnt[16][256];
@@ -30,7 +32,8 @@ void k_lz_sort_home(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, LzS
     __shared__ uint32_t s_rot;
 
     const int tid = threadIdx.x;
-    const uint32_t lb = blockIdx.x;
+    if (bcount && blockIdx.x >= *bcount) return;          // only the listed blocks (fallback of the LDS-resident finder)
+    const uint32_t lb = blist ? blist[blockIdx.x] : blockIdx.x;
     const uint64_t off = (block0 + lb) * (uint64_t)P.block;
     const uint32_t n = (uint32_t)((n_total - off) < P.block ? (n_total - off) : P.block);
     const uint8_t *src = in + off;
@@ -172,10 +175,11 @@ void k_lz_sort_home(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, LzS
 // time order, so two stable passes over the 16-bit cluster number are enough.
 // =============================================================================================
 __global__ __launch_bounds__(1024)
-void k_lz_sort_cluster(LzScratch sc)
+void k_lz_sort_cluster(LzScratch sc, const uint32_t *__restrict__ blist, const uint32_t *__restrict__ bcount)
 {
     __shared__ uint32_t s_cnt[16][256];
-    const uint32_t lb = blockIdx.x;
+    if (bcount && blockIdx.x >= *bcount) return;
+    const uint32_t lb = blist ? blist[blockIdx.x] : blockIdx.x;
     const uint32_t n = sc.meta[lb].n;
     uint64_t *A = sc.eA + (size_t)lb * LZ_MAX_BLOCK;
     uint64_t *B = sc.eB + (size_t)lb * LZ_MAX_BLOCK;
@@ -285,7 +289,7 @@ __device__ void replay_cluster(const TileView &v, uint32_t s, uint32_t e, uint32
 }
 
 __global__ __launch_bounds__(512)
-void k_lz_emulate(LzP P, LzScratch sc)
+void k_lz_emulate(LzP P, LzScratch sc, const uint32_t *__restrict__ blist, const uint32_t *__restrict__ bcount)
 {
     __shared__ uint16_t s_pos[LZ_TILE_CAP], s_rs[LZ_TILE_CAP], s_pid[LZ_TILE_CAP], s_occ[LZ_TILE_CAP];
     __shared__ uint32_t s_bm[LZ_TILE_CAP / 32 + 2];
@@ -293,7 +297,8 @@ void k_lz_emulate(LzP P, LzScratch sc)
     __shared__ uint32_t s_a, s_b, s_lasthead;
 
     const int tid = threadIdx.x;
-    const uint32_t lb = blockIdx.y, t = blockIdx.x;
+    if (bcount && blockIdx.y >= *bcount) return;
+    const uint32_t lb = blist ? blist[blockIdx.y] : blockIdx.y, t = blockIdx.x;
     const LzBlockMeta mt = sc.meta[lb];
     const uint32_t n = mt.n;
     const uint32_t lo = t * LZ_TILE_NOM, hi = (lo + LZ_TILE_NOM < n) ? lo + LZ_TILE_NOM : n;
@@ -439,14 +444,29 @@ void k_lz_emulate_giant(LzP P, LzScratch sc)
 // =============================================================================================
 // host side of the match finder
 // =============================================================================================
+size_t lz2_scratch_bytes(uint32_t nb);
 size_t lz_scratch_bytes(uint32_t nb)
 {
     size_t per = (size_t)LZ_MAX_BLOCK * (2 + 2 + 8 + 8 + 2) + sizeof(LzBlockMeta) + LZ_MAX_GIANTS_PER_BLOCK * 8 +
                  (size_t)LZ_SLOT_WORDS * 4 + 8;
-    return per * nb + 16 * 256 + 4096;
+    return per * nb + 16 * 256 + 4096 + lz2_scratch_bytes(nb) + 64 * 256;
 }
 
-void lz_carve(mi_ctx *ctx, uint32_t nb, LzScratch *sc)
+mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
+                        const LzScratch &sc, hipStream_t s, const uint32_t *blist, const uint32_t *bcount);
+size_t lz2_scratch_bytes(uint32_t nb);
+void   lz2_carve(mi_carver &cv, uint32_t nb, Lz2Scratch *sc);
+mi_status lz2_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
+                         const Lz2Scratch &sc, hipStream_t s);
+void   lz2_launch_scatter(const Lz2Scratch &sc, uint16_t *cand_by_pos, uint32_t nb, hipStream_t s);
+
+bool lz_use_v2()
+{
+    const char *e = getenv("MI_LZ_V2");
+    return !(e && e[0] == '0');
+}
+
+void lz_carve(mi_ctx *ctx, uint32_t nb, LzScratch *sc, Lz2Scratch *sc2)
 {
     mi_carver cv(ctx->ws);
     sc->posA = cv.take<uint16_t>((size_t)nb * LZ_MAX_BLOCK);
@@ -459,6 +479,18 @@ void lz_carve(mi_ctx *ctx, uint32_t nb, LzScratch *sc)
     sc->giant_list = cv.take<uint32_t>((size_t)nb * LZ_MAX_GIANTS_PER_BLOCK * 2);
     sc->slot = cv.take<uint32_t>((size_t)nb * LZ_SLOT_WORDS);
     sc->block_bits = cv.take<uint64_t>(nb + 1);
+    if (sc2) lz2_carve(cv, nb, sc2);
+}
+
+// match finder for blocks [block0, block0+nb): the LDS-resident path, and the first pipeline for the blocks
+// it hands back (a part that does not fit in LDS), or for everything when MI_LZ_V2=0
+mi_status lz_run_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
+                      const LzScratch &sc, const Lz2Scratch &sc2, hipStream_t s)
+{
+    if (!lz_use_v2()) return lz_find_batch(ctx, P, d_in, n, block0, nb, sc, s, nullptr, nullptr);
+    mi_status st = lz2_find_batch(ctx, P, d_in, n, block0, nb, sc2, s);
+    if (st) return st;
+    return lz_find_batch(ctx, P, d_in, n, block0, nb, sc, s, sc2.fallback_list, sc2.fallback_count);
 }
 
 mi_status lz_check_params(const mi_lz_params *p)
@@ -474,21 +506,23 @@ mi_status lz_check_params(const mi_lz_params *p)
 
 // runs the match finder for blocks [block0, block0+nb) of the input; cand lands in sc->cand
 mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
-                        const LzScratch &sc, hipStream_t s)
+                        const LzScratch &sc, hipStream_t s, const uint32_t *blist, const uint32_t *bcount);
+mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
+                        const LzScratch &sc, hipStream_t s, const uint32_t *blist, const uint32_t *bcount)
 {
     MI_HIP(ctx, hipMemsetAsync(sc.giant_count, 0, 4, s));
     {
         mi_prof_scope p(ctx, "k_lz_sort_home", s, (uint64_t)nb * P.block);
-        hipLaunchKernelGGL(k_lz_sort_home, dim3(nb), dim3(1024), 0, s, d_in, n, P, sc, block0);
+        hipLaunchKernelGGL(k_lz_sort_home, dim3(nb), dim3(1024), 0, s, d_in, n, P, sc, block0, blist, bcount);
     }
     {
         mi_prof_scope p(ctx, "k_lz_sort_cluster", s, (uint64_t)nb * P.block);
-        hipLaunchKernelGGL(k_lz_sort_cluster, dim3(nb), dim3(1024), 0, s, sc);
+        hipLaunchKernelGGL(k_lz_sort_cluster, dim3(nb), dim3(1024), 0, s, sc, blist, bcount);
     }
     {
         mi_prof_scope p(ctx, "k_lz_emulate", s, (uint64_t)nb * P.block);
         const uint32_t tiles = (P.block + LZ_TILE_NOM - 1) / LZ_TILE_NOM;
-        hipLaunchKernelGGL(k_lz_emulate, dim3(tiles, nb), dim3(512), 0, s, P, sc);
+        hipLaunchKernelGGL(k_lz_emulate, dim3(tiles, nb), dim3(512), 0, s, P, sc, blist, bcount);
     }
     {
         mi_prof_scope p(ctx, "k_lz_emulate_giant", s, (uint64_t)nb * P.block);
@@ -519,12 +553,13 @@ extern "C" mi_status mi_lz_find_all_dev(mi_ctx *ctx, const mi_lz_params *p, cons
     const uint32_t nbmax = lz_batch_blocks(nblocks);
     st = mi_ws_reserve(ctx, lz_scratch_bytes(nbmax));
     if (st) return st;
-    LzScratch sc;
-    lz_carve(ctx, nbmax, &sc);
+    LzScratch sc; Lz2Scratch sc2;
+    lz_carve(ctx, nbmax, &sc, &sc2);
     for (uint64_t b0 = 0; b0 < nblocks; b0 += nbmax) {
         const uint32_t nb = (uint32_t)((nblocks - b0) < nbmax ? (nblocks - b0) : nbmax);
-        st = lz_find_batch(ctx, P, d_in, n, b0, nb, sc, s);
+        st = lz_run_find(ctx, P, d_in, n, b0, nb, sc, sc2, s);
         if (st) return st;
+        if (lz_use_v2()) lz2_launch_scatter(sc2, sc.cand, nb, s);
         // cand rows are LZ_MAX_BLOCK apart in scratch; the caller's array is block-size apart
         for (uint32_t i = 0; i < nb; ++i) {
             const uint64_t off = (b0 + i) * (uint64_t)P.block;
