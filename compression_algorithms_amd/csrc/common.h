@@ -25,6 +25,8 @@ struct mi_prof_entry {
 struct mi_ctx {
     int         device = 0;
     hipStream_t stream = nullptr;       // the context's own stream
+    hipStream_t side = nullptr;         // second stream: overlaps the replay/parse of batch i with the find of batch i+1
+    hipEvent_t  ev_find[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_fork = nullptr;
     int         last_hip = 0;
     int         profiling = 0;
     int         num_cu = 256;

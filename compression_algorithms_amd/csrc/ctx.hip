@@ -36,6 +36,12 @@ mi_status mi_ctx_create(mi_ctx **out, int device)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MI_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { hipStreamDestroy(c->stream); delete c; return MI_ERR_HIP; }
+    for (int i = 0; i < 2; ++i) {
+        hipEventCreateWithFlags(&c->ev_find[i], hipEventDisableTiming);
+        hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming);
+    }
+    hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     c->h_pinned_bytes = 1 << 16;
     if (hipHostMalloc(&c->h_pinned, c->h_pinned_bytes, hipHostMallocDefault) != hipSuccess) {
         hipStreamDestroy(c->stream); delete c; return MI_ERR_NOMEM;
@@ -55,6 +61,9 @@ void mi_ctx_destroy(mi_ctx *c)
     if (c->ws) hipFree(c->ws);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->stream) hipStreamDestroy(c->stream);
+    if (c->side) hipStreamDestroy(c->side);
+    for (int i = 0; i < 2; ++i) { if (c->ev_find[i]) hipEventDestroy(c->ev_find[i]); if (c->ev_done[i]) hipEventDestroy(c->ev_done[i]); }
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
     delete c;
 }
 

@@ -4,8 +4,10 @@
 
 #define LZ2_NG_BITS   14
 #define LZ2_NG        (1u << LZ2_NG_BITS)   // bucket groups per block for the overflow certificate
-#define LZ2_TS        3584u                 // target entries per part
-#define LZ2_CAP       6144u                 // LDS capacity of a part (entries)
+#define LZ2_TS        2304u                 // target entries per part
+#define LZ2_CAP       3584u                 // LDS capacity of a part (entries): 2 workgroups of k_lz2_find per CU
+#define LZ2_THREADS   512                   // k_lz2_find workgroup
+#define LZ2_NWAVES    (LZ2_THREADS / 64)
 #define LZ2_MAXPARTS  32u
 #define LZ2_BIG       16u                   // clusters of at least this many entries leave k_lz2_find
 #define LZ2_WAVE      128u                  // ... and from this size on a whole wave replays one cluster

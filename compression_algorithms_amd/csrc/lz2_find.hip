@@ -55,17 +55,17 @@ __device__ void replay_small(const uint16_t *pos, uint16_t *rs, const uint16_t *
     }
 }
 
-__global__ __launch_bounds__(1024)
+__global__ __launch_bounds__(LZ2_THREADS)
 void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scratch sc, uint64_t block0)
 {
     // 16 bytes per entry + radix counters
     __shared__ uint16_t s_pos[LZ2_CAP];                 // position by time index j
-    __shared__ uint32_t s_word[LZ2_CAP];                // word by j; later e_pos / e_rs (replay order)
+    __shared__ uint32_t s_word[LZ2_CAP];                // mix32(word) by j; later e_pos / e_rs (replay order)
     __shared__ uint16_t s_j0[LZ2_CAP], s_j1[LZ2_CAP];   // sort ping-pong; later e_pid / (free)
     __shared__ uint16_t s_g[LZ2_CAP];                   // cluster number by j; later occ
     __shared__ uint16_t s_r[LZ2_CAP];                   // dense home slot by j; later cand by replay index
     __shared__ uint16_t s_pid[LZ2_CAP];                 // word id by j (j of the first occurrence); later cand by j
-    __shared__ uint32_t s_cnt[16][256];
+    __shared__ uint32_t s_cnt[LZ2_NWAVES][256];
     __shared__ uint32_t s_bm[LZ2_CAP / 32 + 2];
     __shared__ int32_t  s_i32[18];
     __shared__ uint32_t s_u32[18];
@@ -91,7 +91,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
 
     // ---- gather: positions (coalesced) and their words (4 unaligned bytes each from the block; bytes
     //      past the block end read as zero, the parity definition of the reference's over-read)
-    for (uint32_t j = tid; j < m; j += 1024) {
+    for (uint32_t j = tid; j < m; j += LZ2_THREADS) {
         const uint32_t p = plist[j];
         s_pos[j] = (uint16_t)p;
         uint32_t w = 0;
@@ -105,25 +105,41 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
         } else {
             for (uint32_t k = 0; k < 4 && p + k < nblk; ++k) w |= (uint32_t)src[p + k] << (8 * k);
         }
-        s_word[j] = w;
+        // every step of the reference hash is invertible (odd multipliers, rotations, xor-shifts), so the mixed
+        // value identifies the word: keep it instead of the word — the home is a mask away, equality is equality
+        s_word[j] = lz_mix32(w);
     }
-    for (uint32_t i = tid; i < LZ2_CAP / 32 + 2; i += 1024) s_bm[i] = 0;
+    for (uint32_t i = tid; i < LZ2_CAP / 32 + 2; i += LZ2_THREADS) s_bm[i] = 0;
     if (tid == 0) { s_zslot = ~0u; s_zgid = ~0u; s_nbigl = 0; }
     __syncthreads();
-    auto homep = [&](uint32_t j) -> uint32_t { return ((lz_mix32(s_word[j]) & Tmask) - base) & Tmask; };
+    auto homep = [&](uint32_t j) -> uint32_t { return ((s_word[j] & Tmask) - base) & Tmask; };
     LZ2_TICK(0);
 
-    // ---- sort time indices by home', stable: identity -> j0 -> j1 -> j0
-    radix_pass_1024<8, uint32_t>(m, s_cnt, [&](uint32_t i) { return i; },
-        [&](uint32_t e) { return homep(e) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; });
-    radix_pass_1024<8, uint32_t>(m, s_cnt, [&](uint32_t i) { return (uint32_t)s_j0[i]; },
-        [&](uint32_t e) { return (homep(e) >> 8) & 255u; }, [&](uint32_t d, uint32_t e) { s_j1[d] = (uint16_t)e; });
-    radix_pass_1024<8, uint32_t>(m, s_cnt, [&](uint32_t i) { return (uint32_t)s_j1[i]; },
-        [&](uint32_t e) { return (homep(e) >> 16) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; });
+    // ---- sort time indices by home', stable.  Keys are relative to the part's first home; a part of a
+    //      2^20-bucket table spans < 2^16 homes, so two 8-bit passes are enough (three otherwise).
+    const uint32_t plo_ = mt->part_lo[part];
+    const uint32_t phi_ = (part + 1 < mt->nparts) ? mt->part_lo[part + 1] : T;
+    const bool three = (phi_ - plo_) > 65536u;
+    auto keyp = [&](uint32_t j) -> uint32_t { return homep(j) - plo_; };
+    uint16_t *srt = s_j0;                                   // where the home order ends up
+    if (three) {
+        radix_pass<LZ2_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return i; },
+            [&](uint32_t e) { return keyp(e) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; });
+        radix_pass<LZ2_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return (uint32_t)s_j0[i]; },
+            [&](uint32_t e) { return (keyp(e) >> 8) & 255u; }, [&](uint32_t d, uint32_t e) { s_j1[d] = (uint16_t)e; });
+        radix_pass<LZ2_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return (uint32_t)s_j1[i]; },
+            [&](uint32_t e) { return (keyp(e) >> 16) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; });
+    } else {
+        radix_pass<LZ2_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return i; },
+            [&](uint32_t e) { return keyp(e) & 255u; }, [&](uint32_t d, uint32_t e) { s_j1[d] = (uint16_t)e; });
+        radix_pass<LZ2_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return (uint32_t)s_j1[i]; },
+            [&](uint32_t e) { return (keyp(e) >> 8) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; });
+    }
+    (void)srt;
 
     LZ2_TICK(1);
-    // ---- parking sweep over the sorted order: 6 consecutive entries per thread
-    constexpr uint32_t CH = LZ2_CAP / 1024;
+    // ---- parking sweep over the sorted order: CH consecutive entries per thread
+    constexpr uint32_t CH = LZ2_CAP / LZ2_THREADS;
     const uint32_t k0 = tid * CH, k1 = (k0 + CH < m) ? k0 + CH : m;
     {
         int32_t mx = INT32_MIN;
@@ -202,9 +218,9 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
 
     LZ2_TICK(2);
     // ---- sort time indices by cluster number (they start in time order): identity -> j0 -> j1
-    radix_pass_1024<8, uint32_t>(m, s_cnt, [&](uint32_t i) { return i; },
+    radix_pass<LZ2_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return i; },
         [&](uint32_t e) { return (uint32_t)s_g[e] & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; });
-    radix_pass_1024<8, uint32_t>(m, s_cnt, [&](uint32_t i) { return (uint32_t)s_j0[i]; },
+    radix_pass<LZ2_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return (uint32_t)s_j0[i]; },
         [&](uint32_t e) { return (uint32_t)s_g[e] >> 8; }, [&](uint32_t d, uint32_t e) { s_j1[d] = (uint16_t)e; });
 
     LZ2_TICK(3);
@@ -214,7 +230,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     uint16_t *e_pid = s_j0;
     uint32_t regs[CH][3];
     for (uint32_t c = 0; c < CH; ++c) {
-        const uint32_t i = tid + c * 1024u;
+        const uint32_t i = tid + c * (uint32_t)LZ2_THREADS;
         if (i < m) {
             const uint32_t j = s_j1[i];
             const bool head = (i == 0) || (s_g[j] != s_g[s_j1[i - 1]]);
@@ -230,7 +246,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     if (tid == 0) { s_zhead = 0xFFFF; s_gstart[s_ngroups] = (uint16_t)m; }
     __syncthreads();
     for (uint32_t c = 0; c < CH; ++c) {
-        const uint32_t i = tid + c * 1024u;
+        const uint32_t i = tid + c * (uint32_t)LZ2_THREADS;
         if (i < m) {
             e_pos[i] = (uint16_t)regs[c][0]; e_rs[i] = (uint16_t)regs[c][1]; e_pid[i] = (uint16_t)regs[c][2];
             if (regs[c][1] & RS_HEAD) {
@@ -254,7 +270,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
         c_start = s_pos;                                     // [<= m/2] start of each lane-replayed cluster, bucketed by size
         uint32_t my_s[CH], my_n[CH];
         for (uint32_t c = 0; c < CH; ++c) {
-            const uint32_t i = tid + c * 1024u;
+            const uint32_t i = tid + c * (uint32_t)LZ2_THREADS;
             my_n[c] = 0; my_s[c] = i;
             if (i < m && (e_rs[i] & RS_HEAD)) {
                 const uint32_t e = s_gstart[(regs[c][2] >> 16) + 1];      // clusters are contiguous and in cluster-number order
@@ -279,7 +295,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
             if (my_n[c] >= 2 && my_n[c] < LZ2_BIG) c_start[atomicAdd(&s_bin[my_n[c]], 1u)] = (uint16_t)my_s[c];
         __syncthreads();
         const uint32_t ncl = s_ncl;
-        for (uint32_t q = tid; q < ncl; q += 1024) {
+        for (uint32_t q = tid; q < ncl; q += LZ2_THREADS) {
             const uint32_t s = c_start[q];
             uint32_t e = s + 1;
             while (e < m && !(e_rs[e] & RS_HEAD)) ++e;
@@ -291,32 +307,50 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     LZ2_TICK(5);
     // ---- export the larger clusters (cooperatively, coalesced)
     const uint32_t nbig = s_nbigl < LZ2_MAXBIG ? s_nbigl : LZ2_MAXBIG;   // LZ2_CAP / LZ2_BIG clusters at most
-    for (uint32_t q = tid; q < nbig; q += 1024) {
-        const uint32_t s = s_big[3 * q], e = s_big[3 * q + 1], cnt = e - s;
-        const uint32_t dst = atomicAdd(&mt->nbig_entries, cnt);
-        s_big[3 * q + 2] = dst;
-        const uint32_t cls = cnt < 32 ? 0u : cnt < 64 ? 1u : cnt < LZ2_WAVE ? 2u : cnt <= LZ2_BIG_SMALL ? 3u : 4u;
-        const uint32_t k = atomicAdd(&sc.big_count[cls], 1u);
-        Lz2BigDesc d;
-        d.block = lb; d.start = dst; d.count = cnt;
-        const bool zc = (s == s_zhead);
-        d.anom = zc ? s_zslot - s : ~0u;
-        d.limit = (zc && P.deflate) ? s_zslot - s : ~0u;
-        d.pad[0] = pstart; d.pad[1] = d.pad[2] = 0;
-        sc.desc[cls][k] = d;
-        atomicAdd(&mt->nbig, 1u);
+    // reserve output space with ONE global atomic per part and class (the five class counters are shared by
+    // every workgroup of the batch): local ranks first, in LDS
+    __shared__ uint32_t s_cls[LZ2_NCLASS], s_clsbase[LZ2_NCLASS], s_ent, s_entbase;
+    if (tid < (int)LZ2_NCLASS) s_cls[tid] = 0;
+    if (tid == 0) s_ent = 0;
+    __syncthreads();
+    uint32_t my_rank[(LZ2_MAXBIG + LZ2_THREADS - 1) / LZ2_THREADS], my_dst[(LZ2_MAXBIG + LZ2_THREADS - 1) / LZ2_THREADS];
+    {
+        uint32_t it = 0;
+        for (uint32_t q = tid; q < nbig; q += LZ2_THREADS, ++it) {
+            const uint32_t cnt = s_big[3 * q + 1] - s_big[3 * q];
+            const uint32_t cls = cnt < 32 ? 0u : cnt < 64 ? 1u : cnt < LZ2_WAVE ? 2u : cnt <= LZ2_BIG_SMALL ? 3u : 4u;
+            my_rank[it] = atomicAdd(&s_cls[cls], 1u);
+            my_dst[it] = atomicAdd(&s_ent, cnt);
+        }
     }
     __syncthreads();
-    for (uint32_t b = 0; b < nbig; ++b) {
-        const uint32_t s = s_big[3 * b], e = s_big[3 * b + 1];
-        for (uint32_t i = s + tid; i < e; i += 1024) cand_i[i] = LZ2_PENDING16;
+    if (tid < (int)LZ2_NCLASS && s_cls[tid]) s_clsbase[tid] = atomicAdd(&sc.big_count[tid], s_cls[tid]);
+    if (tid == 32 && s_ent) { s_entbase = atomicAdd(&mt->nbig_entries, s_ent); atomicAdd(&mt->nbig, nbig); }
+    __syncthreads();
+    {
+        uint32_t it = 0;
+        for (uint32_t q = tid; q < nbig; q += LZ2_THREADS, ++it) {
+            const uint32_t s = s_big[3 * q], e = s_big[3 * q + 1], cnt = e - s;
+            const uint32_t cls = cnt < 32 ? 0u : cnt < 64 ? 1u : cnt < LZ2_WAVE ? 2u : cnt <= LZ2_BIG_SMALL ? 3u : 4u;
+            const uint32_t dst = s_entbase + my_dst[it];
+            s_big[3 * q + 2] = dst;
+            Lz2BigDesc d;
+            d.block = lb; d.start = dst; d.count = cnt;
+            const bool zc = (s == s_zhead);
+            d.anom = zc ? s_zslot - s : ~0u;
+            d.limit = (zc && P.deflate) ? s_zslot - s : ~0u;
+            d.pad[0] = pstart; d.pad[1] = d.pad[2] = 0;
+            sc.desc[cls][s_clsbase[cls] + my_rank[it]] = d;
+        }
     }
-    for (uint32_t b = 0; b < nbig; ++b) {
+    __syncthreads();
+    for (uint32_t b = tid >> 6; b < nbig; b += LZ2_NWAVES) {          // a wave per exported cluster
         const uint32_t s = s_big[3 * b], e = s_big[3 * b + 1], dst = s_big[3 * b + 2];
         uint16_t *bp = sc.bigpos + (size_t)lb * LZ_MAX_BLOCK + dst;
         uint16_t *br = sc.bigrs + (size_t)lb * LZ_MAX_BLOCK + dst;
         uint16_t *bi = sc.bigpid + (size_t)lb * LZ_MAX_BLOCK + dst;
-        for (uint32_t i = s + tid; i < e; i += 1024) {
+        for (uint32_t i = s + (tid & 63); i < e; i += 64) {
+            cand_i[i] = LZ2_PENDING16;
             bp[i - s] = e_pos[i];
             br[i - s] = (uint16_t)((e_rs[i] & RS_MASK) - s);    // home slot relative to the cluster
             bi[i - s] = e_pid[i];
@@ -325,10 +359,10 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     // ---- cand back to time order and out (coalesced)
     uint16_t *cand_j = s_pid;
     __syncthreads();
-    for (uint32_t i = tid; i < m; i += 1024) cand_j[s_j1[i]] = cand_i[i];
+    for (uint32_t i = tid; i < m; i += LZ2_THREADS) cand_j[s_j1[i]] = cand_i[i];
     __syncthreads();
     uint16_t *cout = sc.cand + (size_t)lb * LZ_MAX_BLOCK + pstart;
-    for (uint32_t j = tid; j < m; j += 1024) cout[j] = cand_j[j];
+    for (uint32_t j = tid; j < m; j += LZ2_THREADS) cout[j] = cand_j[j];
     LZ2_TICK(6);
     if (sc.dbg && tid == 0) atomicAdd((unsigned long long *)&sc.dbg[15], 1ull);
 }
@@ -554,10 +588,11 @@ extern "C" int mi_lz_debug_counters(uint64_t *out32)
 
 void lz2_launch_partition(const uint8_t *d_in, uint64_t n, const LzP &P, const Lz2Scratch &sc, uint64_t block0, uint32_t nb, hipStream_t s);
 
-mi_status lz2_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
-                         const Lz2Scratch &sc, hipStream_t s)
+// stage A: partition + per-part find (LDS heavy, one workgroup per CU)
+mi_status lz2_stage_a(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
+                      const Lz2Scratch &sc, hipStream_t s)
 {
-    MI_HIP(ctx, hipMemsetAsync(sc.fallback_count, 0, 256, s));      // fallback_count and big_count[2]
+    MI_HIP(ctx, hipMemsetAsync(sc.fallback_count, 0, 256, s));      // fallback_count and big_count[]
     if (sc.dbg && g_dbg_ptr != sc.dbg) { g_dbg_ptr = sc.dbg; MI_HIP(ctx, hipMemsetAsync(sc.dbg, 0, 256, s)); }
     {
         mi_prof_scope p(ctx, "k_lz2_partition", s, (uint64_t)nb * P.block);
@@ -566,8 +601,15 @@ mi_status lz2_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_
     {
         mi_prof_scope p(ctx, "k_lz2_find", s, (uint64_t)nb * P.block);
         const uint32_t parts = (P.block + LZ2_TS - 1) / LZ2_TS;
-        hipLaunchKernelGGL(k_lz2_find, dim3(parts, nb), dim3(1024), 0, s, d_in, n, P, sc, block0);
+        hipLaunchKernelGGL(k_lz2_find, dim3(parts, nb), dim3(LZ2_THREADS), 0, s, d_in, n, P, sc, block0);
     }
+    MI_HIP(ctx, hipGetLastError());
+    return MI_OK;
+}
+
+// stage B: replay of the exported clusters (almost no LDS: runs beside the next batch's stage A)
+mi_status lz2_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &sc, hipStream_t s)
+{
     {
         mi_prof_scope p(ctx, "k_lz2_mid", s, (uint64_t)nb * P.block);
         // grids cover the worst case; surplus workgroups read the class count and leave

@@ -126,27 +126,28 @@ struct OpMaxI32 { __device__ int32_t operator()(int32_t a, int32_t b) const { re
 //   load(i)  -> element (any trivially copyable type E) at input index i
 //   digit(e) -> 0 .. (1<<NBITS)-1
 //   store(j, e) writes element e to output index j
-template <int NBITS, typename E, typename Load, typename Digit, typename Store>
-__device__ __forceinline__ void radix_pass_1024(uint32_t n, uint32_t (*s_cnt)[256], Load load, Digit digit, Store store)
+template <int NWAVES, int NBITS, typename E, typename Load, typename Digit, typename Store>
+__device__ __forceinline__ void radix_pass(uint32_t n, uint32_t (*s_cnt)[256], Load load, Digit digit, Store store)
 {
     constexpr int ND = 1 << NBITS;
+    constexpr int NT = NWAVES * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t seg = ((n + 1023u) / 1024u) * 64u;
+    const uint32_t seg = ((n + (uint32_t)NT - 1u) / (uint32_t)NT) * 64u;
     const uint32_t a = wave * seg, b = (a + seg < n) ? a + seg : n;
-    for (int i = tid; i < 16 * 256; i += 1024) (&s_cnt[0][0])[i] = 0;
+    for (int i = tid; i < NWAVES * 256; i += NT) (&s_cnt[0][0])[i] = 0;
     __syncthreads();
     for (uint32_t i = a + lane; i < b; i += 64) atomicAdd(&s_cnt[wave][digit(load(i))], 1u);
     __syncthreads();
-    // offsets: thread d < ND walks the 16 waves of digit d; then an exclusive scan over digits
+    // offsets: thread d < ND walks the waves of digit d; then an exclusive scan over digits
     uint32_t tot = 0;
     if (tid < ND) {
-        for (int w = 0; w < 16; ++w) { uint32_t t = s_cnt[w][tid]; s_cnt[w][tid] = tot; tot += t; }
+        for (int w = 0; w < NWAVES; ++w) { uint32_t t = s_cnt[w][tid]; s_cnt[w][tid] = tot; tot += t; }
     }
     __shared__ uint32_t s_scan[18];
     uint32_t total;
     uint32_t base = block_exclusive_scan<uint32_t>(tid < ND ? tot : 0u, OpAddU32(), 0u, s_scan, &total);
     if (tid < ND) {
-        for (int w = 0; w < 16; ++w) s_cnt[w][tid] += base;
+        for (int w = 0; w < NWAVES; ++w) s_cnt[w][tid] += base;
     }
     __syncthreads();
     for (uint32_t i0 = a; i0 < b; i0 += 64) {
@@ -171,4 +172,10 @@ __device__ __forceinline__ void radix_pass_1024(uint32_t n, uint32_t (*s_cnt)[25
         if (valid) store(old + rank, e);
     }
     __syncthreads();
+}
+
+template <int NBITS, typename E, typename Load, typename Digit, typename Store>
+__device__ __forceinline__ void radix_pass_1024(uint32_t n, uint32_t (*s_cnt)[256], Load load, Digit digit, Store store)
+{
+    radix_pass<16, NBITS, E>(n, s_cnt, load, digit, store);
 }

@@ -14,6 +14,7 @@
 //   k_lz_decode      one wave per block; replaces lz77_decompress (lz77.c:347-377)
 #include "lz_common.h"
 #include "lz2.h"
+#include <stdlib.h>
 
 __device__ __forceinline__ uint32_t select_bit(uint64_t m, uint32_t r)   // index of the r-th set bit
 {
@@ -37,6 +38,8 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
 
     const int tid = threadIdx.x;
     const uint32_t lb = blockIdx.x;
+    long long tk = clock64();
+#define PE_TICK(k) do { if (s2.dbg && tid == 0) { long long t2 = clock64(); atomicAdd((unsigned long long *)&s2.dbg[16 + (k)], (unsigned long long)(t2 - tk)); tk = t2; } } while (0)
     const uint64_t off = (block0 + lb) * (uint64_t)P.block;
     const uint32_t n = (uint32_t)((n_total - off) < P.block ? (n_total - off) : P.block);
     const uint8_t *src = in + off;
@@ -55,6 +58,7 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     }
     __syncthreads();
 
+    PE_TICK(0);
     // ---- A: token length at every position, were a token to start there.  The LDS-resident finder hands
     //      over (position, candidate) LISTS (coalesced); the first pipeline an array indexed by position.
     const bool lists = use_v2 && !s2.meta[lb].fallback;
@@ -65,7 +69,13 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
             const bool literal = P.deflate ? (dist >= W - 1u) : (dist == W);      // deflate lz77.c:223 / lz77.c:290
             if (!literal) {
                 len = 4;                                                        // the words are equal
-                while (len < max_len && s_r0[c + len] == s_r0[p + len]) ++len;  // no `p < size` bound: zero tail
+                // extend 4 bytes at a time (no `p < size` bound: the zero tail is there); first differing byte by ctz
+                while (len < max_len) {
+                    const uint32_t x = lds_word(s_r0, c + len) ^ lds_word(s_r0, p + len);
+                    if (x) { len += (uint32_t)__builtin_ctz(x) >> 3; break; }
+                    len += 4;
+                }
+                if (len > max_len) len = max_len;
             }
         }
         return len;
@@ -73,17 +83,28 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     const uint16_t *l_pos = s2.plist + (size_t)lb * LZ_MAX_BLOCK, *l_cand = s2.cand + (size_t)lb * LZ_MAX_BLOCK;
     const uint16_t *b_pos = s2.bigpos + (size_t)lb * LZ_MAX_BLOCK, *b_cand = s2.bigcand + (size_t)lb * LZ_MAX_BLOCK;
     const uint32_t nbig = lists ? s2.meta[lb].nbig_entries : 0u;
-    if (lists) {
-        for (uint32_t j = tid; j < n; j += 1024u) {
-            const uint32_t c = l_cand[j];
-            if (c != LZ2_PENDING16) { const uint32_t p = l_pos[j]; s_L[p] = (uint8_t)token_len(p, c); }
+    // (position, candidate) pairs of a list, 8 per lane per step: two 16-byte loads instead of sixteen 2-byte ones
+    auto for_each_pair = [&](const uint16_t *lp, const uint16_t *lc, uint32_t cnt, auto &&fn) {
+        for (uint32_t j0 = tid * 8u; j0 < cnt; j0 += 1024u * 8u) {
+            if (j0 + 8u <= cnt) {
+                const uint4 vp = *reinterpret_cast<const uint4 *>(lp + j0), vc = *reinterpret_cast<const uint4 *>(lc + j0);
+                const uint32_t wp[4] = {vp.x, vp.y, vp.z, vp.w}, wc[4] = {vc.x, vc.y, vc.z, vc.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) fn((wp[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu, (wc[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu);
+            } else {
+                for (uint32_t j = j0; j < cnt; ++j) fn((uint32_t)lp[j], (uint32_t)lc[j]);
+            }
         }
-        for (uint32_t j = tid; j < nbig; j += 1024u) { const uint32_t p = b_pos[j]; s_L[p] = (uint8_t)token_len(p, b_cand[j]); }
+    };
+    if (lists) {
+        for_each_pair(l_pos, l_cand, n, [&](uint32_t p, uint32_t c) { if (c != LZ2_PENDING16) s_L[p] = (uint8_t)token_len(p, c); });
+        for_each_pair(b_pos, b_cand, nbig, [&](uint32_t p, uint32_t c) { s_L[p] = (uint8_t)token_len(p, c); });
     } else {
         for (uint32_t p = tid; p < n; p += 1024u) s_L[p] = (uint8_t)token_len(p, cand[p]);
     }
     __syncthreads();
 
+    PE_TICK(1);
     // ---- B: exit offset of every position of a 64-position chunk into the next chunk
     uint8_t *ex = s_r0;                       // ex[o * 1024 + chunk]
     {
@@ -100,6 +121,7 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
         }
     }
     __syncthreads();
+    PE_TICK(2);
     // compose over super-chunks of 32 chunks.  A chunk is entered at offset <= max_len - 1 <= 30 for the
     // reference's length fields (lbits 4 and 5); longer fields take the serial walk below.
     const bool wide = max_len > 31u;
@@ -121,6 +143,7 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
         __syncthreads();
     }
 
+    PE_TICK(3);
     // ---- C: token starts of each chunk
     {
         const uint32_t c = tid;
@@ -152,14 +175,15 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
         }
     }
     __syncthreads();
+    PE_TICK(4);
     const uint64_t my_tok = s_tok[tid], my_mat = s_mat[tid];
     uint32_t ntok = 0, nmat = 0;
     const uint32_t tbase = block_exclusive_scan<uint32_t>((uint32_t)__popcll(my_tok), OpAddU32(), 0u, s_scan, &ntok);
     const uint32_t mbase = block_exclusive_scan<uint32_t>((uint32_t)__popcll(my_mat), OpAddU32(), 0u, s_scan, &nmat);
     uint32_t *tb = reinterpret_cast<uint32_t *>(s_r0);            // [1025]
     uint32_t *mb = tb + 1026;                                      // [1025]
-    uint32_t *stage = mb + 1026;                                   // [1024 + 4]
-    uint16_t *md = reinterpret_cast<uint16_t *>(stage + 1032);   // [<= 16384] distance of the k-th match token
+    uint32_t *stage = mb + 1026;                                   // [2048 + 8]
+    uint16_t *md = reinterpret_cast<uint16_t *>(stage + 2064);   // [<= 16384] distance of the k-th match token
     tb[tid] = tbase; mb[tid] = mbase;
     if (tid == 0) { tb[1024] = ntok; mb[1024] = nmat; }
     __syncthreads();
@@ -168,38 +192,43 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
             const uint32_t ch = p >> 6, o = p & 63u;
             if ((s_mat[ch] >> o) & 1ull) md[mb[ch] + (uint32_t)__popcll(s_mat[ch] & ((1ull << o) - 1ull))] = (uint16_t)(p - c);
         };
-        for (uint32_t j = tid; j < n; j += 1024u) { const uint32_t c = l_cand[j]; if (c != LZ2_PENDING16 && c != LZ_NONE16) put(l_pos[j], c); }
-        for (uint32_t j = tid; j < nbig; j += 1024u) { const uint32_t c = b_cand[j]; if (c != LZ_NONE16) put(b_pos[j], c); }
+        for_each_pair(l_pos, l_cand, n, [&](uint32_t p, uint32_t c) { if (c != LZ2_PENDING16 && c != LZ_NONE16) put(p, c); });
+        for_each_pair(b_pos, b_cand, nbig, [&](uint32_t p, uint32_t c) { if (c != LZ_NONE16) put(p, c); });
         __syncthreads();
     }
 
-    // ---- D: emit, 1024 tokens per window
+    PE_TICK(5);
+    // ---- D: emit, 2048 tokens per barrier round (two per lane: their latencies overlap)
     const uint32_t LB = P.deflate ? 16u : 9u, MB = P.deflate ? 32u : (1u + P.wbits + P.lbits);
     uint32_t *slot = sc.slot + (size_t)lb * LZ_SLOT_WORDS;
     uint32_t carry = 0;
-    for (uint32_t t0 = 0; t0 < ntok; t0 += 1024u) {
-        const uint32_t t = t0 + tid;
-        const bool valid = t < ntok;
-        uint64_t q = 0; uint32_t v = 0, nbits = 0;
-        if (valid) {
-            uint32_t lo = 0, hi = 1023;                           // last chunk with tb[c] <= t
-            while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (tb[mid] <= t) lo = mid; else hi = mid - 1; }
-            const uint32_t c = lo, o = select_bit(s_tok[c], t - tb[c]);
-            const uint32_t p = c * 64u + o;
-            const uint64_t below = (1ull << o) - 1ull;
-            const uint32_t mbefore = mb[c] + (uint32_t)__popcll(s_mat[c] & below);
-            q = (uint64_t)(t - mbefore) * LB + (uint64_t)mbefore * MB;
-            if ((s_mat[c] >> o) & 1ull) {
-                const uint32_t d = lists ? (uint32_t)md[mbefore] : p - cand[p], l = s_L[p];
-                v = P.deflate ? (1u | (d << 8) | (l << 24)) : (1u | (d << 1) | (l << (1u + P.wbits)));
-                nbits = MB;
-            } else {
-                const uint32_t byte = src[p];
-                v = P.deflate ? (byte << 8) : (byte << 1);
-                nbits = LB;
+    for (uint32_t t0 = 0; t0 < ntok; t0 += 2048u) {
+        uint64_t q[2] = {0, 0}; uint32_t v[2] = {0, 0}, nbits[2] = {0, 0};
+        bool valid[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t t = t0 + (uint32_t)u * 1024u + tid;
+            valid[u] = t < ntok;
+            if (valid[u]) {
+                uint32_t lo = 0, hi = 1023;                           // last chunk with tb[c] <= t
+                while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (tb[mid] <= t) lo = mid; else hi = mid - 1; }
+                const uint32_t c = lo, o = select_bit(s_tok[c], t - tb[c]);
+                const uint32_t p = c * 64u + o;
+                const uint64_t below = (1ull << o) - 1ull;
+                const uint32_t mbefore = mb[c] + (uint32_t)__popcll(s_mat[c] & below);
+                q[u] = (uint64_t)(t - mbefore) * LB + (uint64_t)mbefore * MB;
+                if ((s_mat[c] >> o) & 1ull) {
+                    const uint32_t d = lists ? (uint32_t)md[mbefore] : p - cand[p], l = s_L[p];
+                    v[u] = P.deflate ? (1u | (d << 8) | (l << 24)) : (1u | (d << 1) | (l << (1u + P.wbits)));
+                    nbits[u] = MB;
+                } else {
+                    const uint32_t byte = src[p];
+                    v[u] = P.deflate ? (byte << 8) : (byte << 1);
+                    nbits[u] = LB;
+                }
+                if (u == 0 && tid == 0) s_q0 = q[0];
+                if (t == ntok - 1 || (u == 1 && tid == 1023)) s_q1 = q[u] + nbits[u];
             }
-            if (tid == 0) s_q0 = q;
-            if (t == ntok - 1 || tid == 1023) s_q1 = q + nbits;
         }
         __syncthreads();
         const uint64_t q0 = s_q0, q1 = s_q1;
@@ -207,10 +236,13 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
         const uint32_t nwords = (uint32_t)(((q1 + 31) >> 5) - w0);
         for (uint32_t i = tid; i < nwords + 1; i += 1024u) stage[i] = (i == 0) ? carry : 0u;
         __syncthreads();
-        if (valid) {
-            const uint32_t rel = (uint32_t)(q - (w0 << 5)), wi = rel >> 5, sh = rel & 31u;
-            atomicOr(&stage[wi], v << sh);
-            if (sh + nbits > 32u) atomicOr(&stage[wi + 1], v >> (32u - sh));
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (valid[u]) {
+                const uint32_t rel = (uint32_t)(q[u] - (w0 << 5)), wi = rel >> 5, sh = rel & 31u;
+                atomicOr(&stage[wi], v[u] << sh);
+                if (sh + nbits[u] > 32u) atomicOr(&stage[wi + 1], v[u] >> (32u - sh));
+            }
         }
         __syncthreads();
         const uint32_t ncomplete = (uint32_t)((q1 >> 5) - w0);
@@ -218,6 +250,8 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
         carry = stage[ncomplete];
         __syncthreads();
     }
+    PE_TICK(6);
+    if (s2.dbg && tid == 0) atomicAdd((unsigned long long *)&s2.dbg[31], 1ull);
     const uint64_t total_bits = (uint64_t)(ntok - nmat) * LB + (uint64_t)nmat * MB;
     if (tid == 0) {
         slot[total_bits >> 5] = (total_bits & 31u) ? carry : 0u;
@@ -350,7 +384,10 @@ void k_lz_decode(const uint8_t *__restrict__ stream, const uint64_t *__restrict_
 // host side
 // =============================================================================================
 size_t   lz_scratch_bytes(uint32_t nb);
-void     lz_carve(mi_ctx *ctx, uint32_t nb, LzScratch *sc, Lz2Scratch *sc2);
+void     lz_carve(mi_ctx *ctx, uint32_t nb, LzScratch *sc, Lz2Scratch *sc2, int set);
+mi_status lz_find_stage_a(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
+                          const LzScratch &sc, const Lz2Scratch &sc2, hipStream_t s);
+mi_status lz_find_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &sc2, hipStream_t s);
 bool     lz_use_v2();
 mi_status lz_run_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
                       const LzScratch &sc, const Lz2Scratch &sc2, hipStream_t s);
@@ -371,32 +408,47 @@ extern "C" mi_status mi_lz_encode_dev(mi_ctx *ctx, const mi_lz_params *p, const 
     const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block};
     const uint64_t nblocks = (n + P.block - 1) / P.block;
     const uint32_t nbmax = lz_batch_blocks(nblocks);
-    st = mi_ws_reserve(ctx, lz_scratch_bytes(nbmax) + 4096);
+    // two scratch sets: stage A of batch i+1 (partition + find, on `s`) overlaps stage B of batch i (replay of the
+    // exported clusters, parse, emit, concatenation, on the context's side stream).  Fork/join with events only.
+    const bool overlap = nblocks > nbmax && !getenv("MI_LZ_NO_OVERLAP");
+    const size_t set_bytes = mi_align_up(lz_scratch_bytes(nbmax), 4096);
+    st = mi_ws_reserve(ctx, set_bytes * (overlap ? 2 : 1) + 8192);
     if (st) return st;
-    LzScratch sc; Lz2Scratch sc2;
-    lz_carve(ctx, nbmax, &sc, &sc2);
-    // two small device words after the carve: running bit total, local exclusive offsets
-    uint64_t *base_bits = reinterpret_cast<uint64_t *>(sc.giant_count + 16);
-    uint64_t *excl_local = sc.block_bits;                       // reused: [nb+1] after the scan (in place is fine)
+    LzScratch sc[2]; Lz2Scratch sc2[2];
+    lz_carve(ctx, nbmax, &sc[0], &sc2[0], 0);
+    if (overlap) lz_carve(ctx, nbmax, &sc[1], &sc2[1], 1); else { sc[1] = sc[0]; sc2[1] = sc2[0]; }
+    uint64_t *base_bits = reinterpret_cast<uint64_t *>((uint8_t *)ctx->ws + set_bytes * (overlap ? 2 : 1));
     MI_HIP(ctx, hipMemsetAsync(base_bits, 0, 8, s));
     if (nblocks == 0) { MI_HIP(ctx, hipMemsetAsync(d_block_bits, 0, 8, s)); return MI_OK; }
-    for (uint64_t b0 = 0; b0 < nblocks; b0 += nbmax) {
+    hipStream_t sb = overlap ? ctx->side : s;
+    uint64_t batch = 0;
+    for (uint64_t b0 = 0; b0 < nblocks; b0 += nbmax, ++batch) {
         const uint32_t nb = (uint32_t)((nblocks - b0) < nbmax ? (nblocks - b0) : nbmax);
-        st = lz_run_find(ctx, P, d_in, n, b0, nb, sc, sc2, s);
+        const int k = overlap ? (int)(batch & 1) : 0;
+        if (overlap && batch >= 2) MI_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_done[k], 0));   // set k is free again
+        st = lz_find_stage_a(ctx, P, d_in, n, b0, nb, sc[k], sc2[k], s);
         if (st) return st;
+        if (overlap) { MI_HIP(ctx, hipEventRecord(ctx->ev_find[k], s)); MI_HIP(ctx, hipStreamWaitEvent(sb, ctx->ev_find[k], 0)); }
+        st = lz_find_stage_b(ctx, P, nb, sc2[k], sb);
+        if (st) return st;
+        uint64_t *excl_local = sc[k].block_bits;                   // reused in place by the scan
         {
-            mi_prof_scope pr(ctx, "k_lz_parse_emit", s, (uint64_t)nb * P.block);
-            hipLaunchKernelGGL(k_lz_parse_emit, dim3(nb), dim3(1024), 0, s, d_in, n, P, sc, sc2, lz_use_v2() ? 1 : 0, b0);
+            mi_prof_scope pr(ctx, "k_lz_parse_emit", sb, (uint64_t)nb * P.block);
+            hipLaunchKernelGGL(k_lz_parse_emit, dim3(nb), dim3(1024), 0, sb, d_in, n, P, sc[k], sc2[k], lz_use_v2() ? 1 : 0, b0);
         }
-        hipLaunchKernelGGL(k_lz_scan_blocks, dim3(1), dim3(1024), 0, s, sc.block_bits, nb, base_bits, excl_local, d_block_bits + b0);
+        hipLaunchKernelGGL(k_lz_scan_blocks, dim3(1), dim3(1024), 0, sb, sc[k].block_bits, nb, base_bits, excl_local, d_block_bits + b0);
         {
-            mi_prof_scope pr(ctx, "k_lz_concat", s, (uint64_t)nb * P.block);
-            // upper bound on the dwords of this batch: every block at its worst case
-            const uint64_t maxw = (uint64_t)nb * LZ_SLOT_WORDS + 2;
-            hipLaunchKernelGGL(k_lz_concat, dim3((unsigned)((maxw + 255) / 256)), dim3(256), 0, s, sc.slot, excl_local, nb,
+            mi_prof_scope pr(ctx, "k_lz_concat", sb, (uint64_t)nb * P.block);
+            const uint64_t maxw = (uint64_t)nb * LZ_SLOT_WORDS + 2;   // upper bound on the dwords of this batch
+            hipLaunchKernelGGL(k_lz_concat, dim3((unsigned)((maxw + 255) / 256)), dim3(256), 0, sb, sc[k].slot, excl_local, nb,
                                base_bits, reinterpret_cast<uint32_t *>(d_out));
         }
-        hipLaunchKernelGGL(k_lz_advance, dim3(1), dim3(1), 0, s, base_bits, excl_local, nb);
+        hipLaunchKernelGGL(k_lz_advance, dim3(1), dim3(1), 0, sb, base_bits, excl_local, nb);
+        if (overlap) MI_HIP(ctx, hipEventRecord(ctx->ev_done[k], sb));
+    }
+    if (overlap) {                                                 // join: everything on the side stream before `s` goes on
+        MI_HIP(ctx, hipEventRecord(ctx->ev_fork, sb));
+        MI_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_fork, 0));
     }
     MI_HIP(ctx, hipGetLastError());
     return MI_OK;

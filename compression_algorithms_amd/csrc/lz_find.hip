@@ -456,8 +456,9 @@ mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t
                         const LzScratch &sc, hipStream_t s, const uint32_t *blist, const uint32_t *bcount);
 size_t lz2_scratch_bytes(uint32_t nb);
 void   lz2_carve(mi_carver &cv, uint32_t nb, Lz2Scratch *sc);
-mi_status lz2_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
-                         const Lz2Scratch &sc, hipStream_t s);
+mi_status lz2_stage_a(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
+                      const Lz2Scratch &sc, hipStream_t s);
+mi_status lz2_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &sc, hipStream_t s);
 void   lz2_launch_scatter(const Lz2Scratch &sc, uint16_t *cand_by_pos, uint32_t nb, hipStream_t s);
 
 bool lz_use_v2()
@@ -466,9 +467,9 @@ bool lz_use_v2()
     return !(e && e[0] == '0');
 }
 
-void lz_carve(mi_ctx *ctx, uint32_t nb, LzScratch *sc, Lz2Scratch *sc2)
+void lz_carve(mi_ctx *ctx, uint32_t nb, LzScratch *sc, Lz2Scratch *sc2, int set)
 {
-    mi_carver cv(ctx->ws);
+    mi_carver cv((uint8_t *)ctx->ws + (size_t)set * mi_align_up(lz_scratch_bytes(nb), 4096));
     sc->posA = cv.take<uint16_t>((size_t)nb * LZ_MAX_BLOCK);
     sc->posB = cv.take<uint16_t>((size_t)nb * LZ_MAX_BLOCK);
     sc->eA = cv.take<uint64_t>((size_t)nb * LZ_MAX_BLOCK);
@@ -482,17 +483,27 @@ void lz_carve(mi_ctx *ctx, uint32_t nb, LzScratch *sc, Lz2Scratch *sc2)
     if (sc2) lz2_carve(cv, nb, sc2);
 }
 
-// match finder for blocks [block0, block0+nb): the LDS-resident path, and the first pipeline for the blocks
-// it hands back (a part that does not fit in LDS), or for everything when MI_LZ_V2=0
-mi_status lz_run_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
-                      const LzScratch &sc, const Lz2Scratch &sc2, hipStream_t s)
+// match finder for blocks [block0, block0+nb), in two stages so that a caller can overlap them across
+// batches: A = partition + find (+ the first pipeline for the blocks the LDS-resident path hands back, or
+// for everything when MI_LZ_V2=0); B = replay of the exported clusters.
+mi_status lz_find_stage_a(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
+                          const LzScratch &sc, const Lz2Scratch &sc2, hipStream_t s)
 {
     if (!lz_use_v2()) return lz_find_batch(ctx, P, d_in, n, block0, nb, sc, s, nullptr, nullptr);
-    mi_status st = lz2_find_batch(ctx, P, d_in, n, block0, nb, sc2, s);
+    mi_status st = lz2_stage_a(ctx, P, d_in, n, block0, nb, sc2, s);
     if (st) return st;
     return lz_find_batch(ctx, P, d_in, n, block0, nb, sc, s, sc2.fallback_list, sc2.fallback_count);
 }
-
+mi_status lz_find_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &sc2, hipStream_t s)
+{
+    return lz_use_v2() ? lz2_stage_b(ctx, P, nb, sc2, s) : MI_OK;
+}
+mi_status lz_run_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
+                      const LzScratch &sc, const Lz2Scratch &sc2, hipStream_t s)
+{
+    mi_status st = lz_find_stage_a(ctx, P, d_in, n, block0, nb, sc, sc2, s);
+    return st ? st : lz_find_stage_b(ctx, P, nb, sc2, s);
+}
 mi_status lz_check_params(const mi_lz_params *p)
 {
     if (!p) return MI_ERR_ARG;
@@ -500,11 +511,10 @@ mi_status lz_check_params(const mi_lz_params *p)
     if (p->lbits < 3 || p->lbits > 8) return MI_ERR_ARG;
     if (p->tbits < 17 || p->tbits > 24) return MI_ERR_ARG;
     if (p->block < 1 || p->block > LZ_MAX_BLOCK) return MI_ERR_ARG;
-    if (p->deflate && (1u + p->wbits + p->lbits > 32 || p->lbits > 8)) return MI_ERR_ARG;
+    if (1u + p->wbits + p->lbits > 32) return MI_ERR_ARG;
     return MI_OK;
 }
 
-// runs the match finder for blocks [block0, block0+nb) of the input; cand lands in sc->cand
 mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
                         const LzScratch &sc, hipStream_t s, const uint32_t *blist, const uint32_t *bcount);
 mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
@@ -554,7 +564,7 @@ extern "C" mi_status mi_lz_find_all_dev(mi_ctx *ctx, const mi_lz_params *p, cons
     st = mi_ws_reserve(ctx, lz_scratch_bytes(nbmax));
     if (st) return st;
     LzScratch sc; Lz2Scratch sc2;
-    lz_carve(ctx, nbmax, &sc, &sc2);
+    lz_carve(ctx, nbmax, &sc, &sc2, 0);
     for (uint64_t b0 = 0; b0 < nblocks; b0 += nbmax) {
         const uint32_t nb = (uint32_t)((nblocks - b0) < nbmax ? (nblocks - b0) : nbmax);
         st = lz_run_find(ctx, P, d_in, n, b0, nb, sc, sc2, s);
