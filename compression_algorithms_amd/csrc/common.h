@@ -26,7 +26,9 @@ struct mi_ctx {
     int         device = 0;
     hipStream_t stream = nullptr;       // the context's own stream
     hipStream_t side = nullptr;         // second stream: overlaps the replay/parse of batch i with the find of batch i+1
+    hipStream_t fb = nullptr;           // low priority: the (normally empty) fallback chain must not hold LDS-hungry launches in front of real work
     hipEvent_t  ev_find[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_fork = nullptr;
+    hipEvent_t  ev_part[2] = {nullptr, nullptr}, ev_fb[2] = {nullptr, nullptr};
     int         last_hip = 0;
     int         profiling = 0;
     int         num_cu = 256;

@@ -37,7 +37,14 @@ mi_status mi_ctx_create(mi_ctx **out, int device)
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MI_ERR_HIP; }
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { hipStreamDestroy(c->stream); delete c; return MI_ERR_HIP; }
+    {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // lo = least urgent
+        if (hipStreamCreateWithPriority(&c->fb, hipStreamNonBlocking, lo) != hipSuccess) { hipStreamDestroy(c->stream); hipStreamDestroy(c->side); delete c; return MI_ERR_HIP; }
+    }
     for (int i = 0; i < 2; ++i) {
+        hipEventCreateWithFlags(&c->ev_part[i], hipEventDisableTiming);
+        hipEventCreateWithFlags(&c->ev_fb[i], hipEventDisableTiming);
         hipEventCreateWithFlags(&c->ev_find[i], hipEventDisableTiming);
         hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming);
     }
@@ -62,7 +69,13 @@ void mi_ctx_destroy(mi_ctx *c)
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->side) hipStreamDestroy(c->side);
-    for (int i = 0; i < 2; ++i) { if (c->ev_find[i]) hipEventDestroy(c->ev_find[i]); if (c->ev_done[i]) hipEventDestroy(c->ev_done[i]); }
+    if (c->fb) hipStreamDestroy(c->fb);
+    for (int i = 0; i < 2; ++i) {
+        if (c->ev_find[i]) hipEventDestroy(c->ev_find[i]);
+        if (c->ev_done[i]) hipEventDestroy(c->ev_done[i]);
+        if (c->ev_part[i]) hipEventDestroy(c->ev_part[i]);
+        if (c->ev_fb[i]) hipEventDestroy(c->ev_fb[i]);
+    }
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     delete c;
 }

@@ -9,14 +9,20 @@
 #define LZ2_THREADS   512                   // k_lz2_find workgroup
 #define LZ2_NWAVES    (LZ2_THREADS / 64)
 #define LZ2_MAXPARTS  32u
-#define LZ2_BIG       16u                   // clusters of at least this many entries leave k_lz2_find
+#define LZ2_BIG       8u                    // clusters of at least this many entries leave k_lz2_find
 #define LZ2_WAVE      128u                  // ... and from this size on a whole wave replays one cluster
 #define LZ2_MAXBIG    (LZ2_CAP / LZ2_BIG)   // exported clusters per part, at most
 #define LZ2_DESC_SMALL (LZ_MAX_BLOCK / LZ2_BIG + 32u)   // exported clusters per block, at most
-// export classes: 0: 16..31, 1: 32..63, 2: 64..127 (a lane per cluster, 64 clusters per wave);
-//                 3: 128..1024, 4: > 1024 (a wave per cluster)
-#define LZ2_NCLASS    5u
-#define LZ2_BIG_SMALL 1024u                 // size classes of the wave replay (LDS per wave: 6 B per entry)
+// export classes: 0: 16..31, 1: 32..63, 2: 64..127, 3: 128..255 (a lane per cluster, 64 clusters per wave),
+//                 4: 256..511 (a lane per cluster, 32 per wave); 5: 512..1024, 6: > 1024 (a wave per cluster)
+#define LZ2_NCLASS    8u                    // class 7: 8..15 entries (a lane per cluster)
+#define LZ2_BIG_SMALL 1024u                 // boundary between the two wave-replay classes (1 vs 4 bitmap dwords per lane)
+__host__ __device__ __forceinline__ uint32_t lz2_class_of(uint32_t cnt)
+{
+    // classes 3 and 4 (lane replay of 128..511 entries) are built but not fed: with ~100 KiB of LDS per wave only one
+    // wave fits a CU and nothing hides its latency — measured 4x slower than the wave replay (profiles/r01b notes)
+    return cnt < 16 ? 7u : cnt < 32 ? 0u : cnt < 64 ? 1u : cnt < LZ2_WAVE ? 2u : cnt <= LZ2_BIG_SMALL ? 5u : 6u;
+}
 #define LZ2_PENDING16 0xFFFEu               // cand placeholder of an entry whose cluster went to the wave replay
 
 struct Lz2BlockMeta {
@@ -43,7 +49,7 @@ struct Lz2Scratch {
     Lz2BlockMeta *meta;         // [nb]
     uint32_t     *fallback_count, *fallback_list;    // blocks the first pipeline has to do
     uint16_t     *bigpos, *bigrs, *bigpid, *bigcand; // [nb][65536] entries of exported clusters, (cluster, time) order
-    Lz2BigDesc   *desc[LZ2_NCLASS];                  // per class: [nb * LZ2_DESC_SMALL] (class 4: [nb * 64])
+    Lz2BigDesc   *desc[LZ2_NCLASS];                  // per class: [nb * capacity of the class]
     uint32_t     *big_count;                         // [LZ2_NCLASS]
     uint64_t     *dbg;                               // phase cycle counters (MI_LZ_DEBUG=1), else NULL
 };

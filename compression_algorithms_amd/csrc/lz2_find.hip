@@ -318,7 +318,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
         uint32_t it = 0;
         for (uint32_t q = tid; q < nbig; q += LZ2_THREADS, ++it) {
             const uint32_t cnt = s_big[3 * q + 1] - s_big[3 * q];
-            const uint32_t cls = cnt < 32 ? 0u : cnt < 64 ? 1u : cnt < LZ2_WAVE ? 2u : cnt <= LZ2_BIG_SMALL ? 3u : 4u;
+            const uint32_t cls = lz2_class_of(cnt);
             my_rank[it] = atomicAdd(&s_cls[cls], 1u);
             my_dst[it] = atomicAdd(&s_ent, cnt);
         }
@@ -331,7 +331,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
         uint32_t it = 0;
         for (uint32_t q = tid; q < nbig; q += LZ2_THREADS, ++it) {
             const uint32_t s = s_big[3 * q], e = s_big[3 * q + 1], cnt = e - s;
-            const uint32_t cls = cnt < 32 ? 0u : cnt < 64 ? 1u : cnt < LZ2_WAVE ? 2u : cnt <= LZ2_BIG_SMALL ? 3u : 4u;
+            const uint32_t cls = lz2_class_of(cnt);
             const uint32_t dst = s_entbase + my_dst[it];
             s_big[3 * q + 2] = dst;
             Lz2BigDesc d;
@@ -423,8 +423,8 @@ void k_lz2_big(LzP P, Lz2Scratch sc, int large)
 {
     __shared__ uint16_t s_opid[LDS_ENTRIES], s_opos[LDS_ENTRIES], s_slot[LDS_ENTRIES];
     const uint32_t lane = threadIdx.x;
-    const uint32_t ncl = sc.big_count[large ? 4 : 3];
-    const Lz2BigDesc *list = sc.desc[large ? 4 : 3];
+    const uint32_t ncl = sc.big_count[large ? 6 : 5];
+    const Lz2BigDesc *list = sc.desc[large ? 6 : 5];
     const uint32_t W = 1u << P.wbits;
     for (uint32_t ci = blockIdx.x; ci < ncl; ci += gridDim.x) {
         const uint32_t d_block = list[ci].block, d_start = list[ci].start, n = list[ci].count;
@@ -481,18 +481,18 @@ void k_lz2_big(LzP P, Lz2Scratch sc, int large)
 // 64 clusters per wave, every lane owns a private LDS region (slot -> word id, slot -> position,
 // entry -> slot, occupancy bits).  All lanes of a wave step through clusters of similar size.
 // =============================================================================================
-template <int CMAX>
+template <int CMAX, int LANES>
 __global__ __launch_bounds__(64)
 void k_lz2_mid(LzP P, Lz2Scratch sc, int cls)
 {
     constexpr int STRIDE = CMAX + 1;                      // odd stride in 16-bit units: spreads the lanes over the banks
-    __shared__ uint16_t s_opid[64 * STRIDE], s_opos[64 * STRIDE], s_slot[64 * STRIDE];
-    __shared__ uint32_t s_bits[64 * (CMAX / 32 + 1)];
+    __shared__ uint16_t s_opid[LANES * STRIDE], s_opos[LANES * STRIDE], s_slot[LANES * STRIDE];
+    __shared__ uint32_t s_bits[LANES * (CMAX / 32 + 1)];
     const uint32_t lane = threadIdx.x;
     const uint32_t ncl = sc.big_count[cls];
-    const uint32_t ci = blockIdx.x * 64u + lane;
-    if (blockIdx.x * 64u >= ncl) return;
-    const bool active = ci < ncl;
+    const uint32_t ci = blockIdx.x * (uint32_t)LANES + lane;
+    if (blockIdx.x * (uint32_t)LANES >= ncl) return;
+    const bool active = ci < ncl && lane < (uint32_t)LANES;
     Lz2BigDesc d;
     d.block = 0; d.start = 0; d.count = 0; d.anom = ~0u; d.limit = ~0u;
     if (active) d = sc.desc[cls][ci];
@@ -501,14 +501,21 @@ void k_lz2_mid(LzP P, Lz2Scratch sc, int cls)
     const uint16_t *br = sc.bigrs + (size_t)d.block * LZ_MAX_BLOCK + d.start;
     const uint16_t *bi = sc.bigpid + (size_t)d.block * LZ_MAX_BLOCK + d.start;
     uint16_t *bc = sc.bigcand + (size_t)d.block * LZ_MAX_BLOCK + d.start;
-    uint16_t *opid = s_opid + lane * STRIDE, *opos = s_opos + lane * STRIDE, *slot = s_slot + lane * STRIDE;
-    uint32_t *bits = s_bits + lane * (CMAX / 32 + 1);
-    for (int k = 0; k < CMAX / 32 + 1; ++k) bits[k] = 0;
+    const uint32_t lr = lane < (uint32_t)LANES ? lane : 0u;  // surplus lanes (LANES < 64) idle on region 0: n = 0
+    uint16_t *opid = s_opid + lr * STRIDE, *opos = s_opos + lr * STRIDE, *slot = s_slot + lr * STRIDE;
+    uint32_t *bits = s_bits + lr * (CMAX / 32 + 1);
+    if (lane < (uint32_t)LANES) for (int k = 0; k < CMAX / 32 + 1; ++k) bits[k] = 0;
     uint32_t ev = 0, ev_p = active && n ? bp[0] : 0u;
     bool anom_pending = d.anom != ~0u;
+    // entry fields are fetched one step ahead: each lane walks its own cluster, so these loads do not coalesce
+    // and their latency would otherwise sit on every step
+    uint32_t nx_p = 0, nx_r = 0, nx_id = 0;
+    if (n) { nx_p = bp[0]; nx_r = br[0]; nx_id = bi[0]; }
     for (uint32_t i = 0; i < (uint32_t)CMAX; ++i) {
+        if (__ballot(i < n) == 0ull) break;                 // every cluster of this wave is done
         if (i >= n) continue;                              // lanes with shorter clusters idle (same size class: < 2x)
-        const uint32_t p = bp[i], r = br[i], id = bi[i];
+        const uint32_t p = nx_p, r = nx_r, id = nx_id;
+        if (i + 1 < n) { nx_p = bp[i + 1]; nx_r = br[i + 1]; nx_id = bi[i + 1]; }
         while (ev < i && ev_p + W < p) {                   // FIFO retirement
             const uint32_t b = slot[ev];
             bits[b >> 5] &= ~(1u << (b & 31u));
@@ -547,9 +554,12 @@ void k_lz2_scatter(Lz2Scratch sc, uint16_t *__restrict__ cand_by_pos /* [nb][655
     for (uint32_t j = threadIdx.x; j < nb; j += 1024) out[bp[j]] = bc[j];
 }
 
-template __global__ void k_lz2_mid<32>(LzP, Lz2Scratch, int);
-template __global__ void k_lz2_mid<64>(LzP, Lz2Scratch, int);
-template __global__ void k_lz2_mid<128>(LzP, Lz2Scratch, int);
+template __global__ void k_lz2_mid<16, 64>(LzP, Lz2Scratch, int);
+template __global__ void k_lz2_mid<32, 64>(LzP, Lz2Scratch, int);
+template __global__ void k_lz2_mid<64, 64>(LzP, Lz2Scratch, int);
+template __global__ void k_lz2_mid<128, 64>(LzP, Lz2Scratch, int);
+template __global__ void k_lz2_mid<256, 64>(LzP, Lz2Scratch, int);
+template __global__ void k_lz2_mid<512, 32>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_big<LZ2_BIG_SMALL, 1>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_big<LZ2_CAP, 4>(LzP, Lz2Scratch, int);
 
@@ -557,9 +567,16 @@ template __global__ void k_lz2_big<LZ2_CAP, 4>(LzP, Lz2Scratch, int);
 // =============================================================================================
 // host side
 // =============================================================================================
+// clusters of class c per block, at most (a block has 65536 entries)
+static uint32_t lz2_class_cap(uint32_t c)
+{
+    static const uint32_t lo[LZ2_NCLASS] = {16, 32, 64, 128, 256, 512, 1025, 8};
+    return LZ_MAX_BLOCK / lo[c] + 8;
+}
+
 size_t lz2_scratch_bytes(uint32_t nb)
 {
-    return (size_t)nb * (LZ_MAX_BLOCK * 2 * 6 + sizeof(Lz2BlockMeta) + 4 + 4 * LZ2_DESC_SMALL * sizeof(Lz2BigDesc) + 64 * sizeof(Lz2BigDesc)) + 16 * 256 + 4096;
+    return (size_t)nb * (LZ_MAX_BLOCK * 2 * 6 + sizeof(Lz2BlockMeta) + 4 + 3 * LZ2_DESC_SMALL * sizeof(Lz2BigDesc)) + 16 * 256 + 4096;
 }
 
 void lz2_carve(mi_carver &cv, uint32_t nb, Lz2Scratch *sc)
@@ -573,7 +590,7 @@ void lz2_carve(mi_carver &cv, uint32_t nb, Lz2Scratch *sc)
     sc->bigrs = cv.take<uint16_t>((size_t)nb * LZ_MAX_BLOCK);
     sc->bigpid = cv.take<uint16_t>((size_t)nb * LZ_MAX_BLOCK);
     sc->bigcand = cv.take<uint16_t>((size_t)nb * LZ_MAX_BLOCK);
-    for (uint32_t c = 0; c < LZ2_NCLASS; ++c) sc->desc[c] = cv.take<Lz2BigDesc>((size_t)nb * (c == 4 ? 64 : LZ2_DESC_SMALL));
+    for (uint32_t c = 0; c < LZ2_NCLASS; ++c) sc->desc[c] = cv.take<Lz2BigDesc>((size_t)nb * lz2_class_cap(c));
     sc->big_count = sc->fallback_count + 16;
     sc->dbg = getenv("MI_LZ_DEBUG") ? cv.take<uint64_t>(32) : nullptr;
 }
@@ -588,21 +605,25 @@ extern "C" int mi_lz_debug_counters(uint64_t *out32)
 
 void lz2_launch_partition(const uint8_t *d_in, uint64_t n, const LzP &P, const Lz2Scratch &sc, uint64_t block0, uint32_t nb, hipStream_t s);
 
-// stage A: partition + per-part find (LDS heavy, one workgroup per CU)
-mi_status lz2_stage_a(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
-                      const Lz2Scratch &sc, hipStream_t s)
+// stage A1: partition (also decides which blocks go to the fallback pipeline)
+mi_status lz2_stage_partition(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
+                              const Lz2Scratch &sc, hipStream_t s)
 {
     MI_HIP(ctx, hipMemsetAsync(sc.fallback_count, 0, 256, s));      // fallback_count and big_count[]
     if (sc.dbg && g_dbg_ptr != sc.dbg) { g_dbg_ptr = sc.dbg; MI_HIP(ctx, hipMemsetAsync(sc.dbg, 0, 256, s)); }
-    {
-        mi_prof_scope p(ctx, "k_lz2_partition", s, (uint64_t)nb * P.block);
-        lz2_launch_partition(d_in, n, P, sc, block0, nb, s);
-    }
-    {
-        mi_prof_scope p(ctx, "k_lz2_find", s, (uint64_t)nb * P.block);
-        const uint32_t parts = (P.block + LZ2_TS - 1) / LZ2_TS;
-        hipLaunchKernelGGL(k_lz2_find, dim3(parts, nb), dim3(LZ2_THREADS), 0, s, d_in, n, P, sc, block0);
-    }
+    mi_prof_scope p(ctx, "k_lz2_partition", s, (uint64_t)nb * P.block);
+    lz2_launch_partition(d_in, n, P, sc, block0, nb, s);
+    MI_HIP(ctx, hipGetLastError());
+    return MI_OK;
+}
+
+// stage A2: per-part find (LDS heavy: two workgroups per CU)
+mi_status lz2_stage_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
+                         const Lz2Scratch &sc, hipStream_t s)
+{
+    mi_prof_scope p(ctx, "k_lz2_find", s, (uint64_t)nb * P.block);
+    const uint32_t parts = (P.block + LZ2_TS - 1) / LZ2_TS;
+    hipLaunchKernelGGL(k_lz2_find, dim3(parts, nb), dim3(LZ2_THREADS), 0, s, d_in, n, P, sc, block0);
     MI_HIP(ctx, hipGetLastError());
     return MI_OK;
 }
@@ -613,16 +634,17 @@ mi_status lz2_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &
     {
         mi_prof_scope p(ctx, "k_lz2_mid", s, (uint64_t)nb * P.block);
         // grids cover the worst case; surplus workgroups read the class count and leave
-        const uint32_t gm = (nb * LZ2_DESC_SMALL + 63u) / 64u;
-        hipLaunchKernelGGL((k_lz2_mid<32>), dim3(gm), dim3(64), 0, s, P, sc, 0);
-        hipLaunchKernelGGL((k_lz2_mid<64>), dim3(gm / 2 + 1), dim3(64), 0, s, P, sc, 1);
-        hipLaunchKernelGGL((k_lz2_mid<128>), dim3(gm / 4 + 1), dim3(64), 0, s, P, sc, 2);
+        hipLaunchKernelGGL((k_lz2_mid<16, 64>), dim3(nb * lz2_class_cap(7) / 64 + 1), dim3(64), 0, s, P, sc, 7);
+        hipLaunchKernelGGL((k_lz2_mid<32, 64>), dim3(nb * lz2_class_cap(0) / 64 + 1), dim3(64), 0, s, P, sc, 0);
+        hipLaunchKernelGGL((k_lz2_mid<64, 64>), dim3(nb * lz2_class_cap(1) / 64 + 1), dim3(64), 0, s, P, sc, 1);
+        hipLaunchKernelGGL((k_lz2_mid<128, 64>), dim3(nb * lz2_class_cap(2) / 64 + 1), dim3(64), 0, s, P, sc, 2);
+        // classes 3 and 4 are never fed (lz2_class_of) and an empty launch that asks for 100 KiB of LDS per workgroup
+        // still queues behind k_lz2_find for that LDS: not launched
     }
     {
         mi_prof_scope p(ctx, "k_lz2_big", s, (uint64_t)nb * P.block);
-        const uint32_t g1 = nb * 64u < 65536u ? nb * 64u : 65536u;
-        hipLaunchKernelGGL((k_lz2_big<LZ2_BIG_SMALL, 1>), dim3(g1), dim3(64), 0, s, P, sc, 0);
-        hipLaunchKernelGGL((k_lz2_big<LZ2_CAP, 4>), dim3(nb < 1024 ? nb : 1024), dim3(64), 0, s, P, sc, 1);
+        hipLaunchKernelGGL((k_lz2_big<LZ2_BIG_SMALL, 1>), dim3(nb * lz2_class_cap(5)), dim3(64), 0, s, P, sc, 0);
+        hipLaunchKernelGGL((k_lz2_big<LZ2_CAP, 4>), dim3(nb * lz2_class_cap(6) < 4096 ? nb * lz2_class_cap(6) : 4096), dim3(64), 0, s, P, sc, 1);
     }
     MI_HIP(ctx, hipGetLastError());
     return MI_OK;

@@ -386,7 +386,7 @@ void k_lz_decode(const uint8_t *__restrict__ stream, const uint64_t *__restrict_
 size_t   lz_scratch_bytes(uint32_t nb);
 void     lz_carve(mi_ctx *ctx, uint32_t nb, LzScratch *sc, Lz2Scratch *sc2, int set);
 mi_status lz_find_stage_a(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
-                          const LzScratch &sc, const Lz2Scratch &sc2, hipStream_t s);
+                          const LzScratch &sc, const Lz2Scratch &sc2, hipStream_t s, hipStream_t sf, hipEvent_t ev_part, hipEvent_t ev_fb);
 mi_status lz_find_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &sc2, hipStream_t s);
 bool     lz_use_v2();
 mi_status lz_run_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
@@ -426,9 +426,13 @@ extern "C" mi_status mi_lz_encode_dev(mi_ctx *ctx, const mi_lz_params *p, const 
         const uint32_t nb = (uint32_t)((nblocks - b0) < nbmax ? (nblocks - b0) : nbmax);
         const int k = overlap ? (int)(batch & 1) : 0;
         if (overlap && batch >= 2) MI_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_done[k], 0));   // set k is free again
-        st = lz_find_stage_a(ctx, P, d_in, n, b0, nb, sc[k], sc2[k], s);
+        st = lz_find_stage_a(ctx, P, d_in, n, b0, nb, sc[k], sc2[k], s, overlap ? ctx->fb : s, ctx->ev_part[k], ctx->ev_fb[k]);
         if (st) return st;
-        if (overlap) { MI_HIP(ctx, hipEventRecord(ctx->ev_find[k], s)); MI_HIP(ctx, hipStreamWaitEvent(sb, ctx->ev_find[k], 0)); }
+        if (overlap) {
+            MI_HIP(ctx, hipEventRecord(ctx->ev_find[k], s));
+            MI_HIP(ctx, hipStreamWaitEvent(sb, ctx->ev_find[k], 0));
+            if (lz_use_v2()) MI_HIP(ctx, hipStreamWaitEvent(sb, ctx->ev_fb[k], 0));      // the fallback blocks' candidates
+        }
         st = lz_find_stage_b(ctx, P, nb, sc2[k], sb);
         if (st) return st;
         uint64_t *excl_local = sc[k].block_bits;                   // reused in place by the scan

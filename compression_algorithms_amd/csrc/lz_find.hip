@@ -456,8 +456,10 @@ mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t
                         const LzScratch &sc, hipStream_t s, const uint32_t *blist, const uint32_t *bcount);
 size_t lz2_scratch_bytes(uint32_t nb);
 void   lz2_carve(mi_carver &cv, uint32_t nb, Lz2Scratch *sc);
-mi_status lz2_stage_a(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
-                      const Lz2Scratch &sc, hipStream_t s);
+mi_status lz2_stage_partition(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
+                              const Lz2Scratch &sc, hipStream_t s);
+mi_status lz2_stage_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
+                         const Lz2Scratch &sc, hipStream_t s);
 mi_status lz2_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &sc, hipStream_t s);
 void   lz2_launch_scatter(const Lz2Scratch &sc, uint16_t *cand_by_pos, uint32_t nb, hipStream_t s);
 
@@ -486,13 +488,20 @@ void lz_carve(mi_ctx *ctx, uint32_t nb, LzScratch *sc, Lz2Scratch *sc2, int set)
 // match finder for blocks [block0, block0+nb), in two stages so that a caller can overlap them across
 // batches: A = partition + find (+ the first pipeline for the blocks the LDS-resident path hands back, or
 // for everything when MI_LZ_V2=0); B = replay of the exported clusters.
+// `sf` = stream of the fallback chain (may equal `s`); when it differs the caller joins it before the parse:
+// the chain is normally empty, but its launches ask for 82..155 KiB of LDS per workgroup and would otherwise
+// sit in front of the real work waiting for that LDS.
 mi_status lz_find_stage_a(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
-                          const LzScratch &sc, const Lz2Scratch &sc2, hipStream_t s)
+                          const LzScratch &sc, const Lz2Scratch &sc2, hipStream_t s, hipStream_t sf, hipEvent_t ev_part, hipEvent_t ev_fb)
 {
     if (!lz_use_v2()) return lz_find_batch(ctx, P, d_in, n, block0, nb, sc, s, nullptr, nullptr);
-    mi_status st = lz2_stage_a(ctx, P, d_in, n, block0, nb, sc2, s);
+    mi_status st = lz2_stage_partition(ctx, P, d_in, n, block0, nb, sc2, s);
     if (st) return st;
-    return lz_find_batch(ctx, P, d_in, n, block0, nb, sc, s, sc2.fallback_list, sc2.fallback_count);
+    if (sf != s) { MI_HIP(ctx, hipEventRecord(ev_part, s)); MI_HIP(ctx, hipStreamWaitEvent(sf, ev_part, 0)); }
+    st = lz_find_batch(ctx, P, d_in, n, block0, nb, sc, sf, sc2.fallback_list, sc2.fallback_count);
+    if (st) return st;
+    if (sf != s) MI_HIP(ctx, hipEventRecord(ev_fb, sf));
+    return lz2_stage_find(ctx, P, d_in, n, block0, nb, sc2, s);
 }
 mi_status lz_find_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &sc2, hipStream_t s)
 {
@@ -501,7 +510,7 @@ mi_status lz_find_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scrat
 mi_status lz_run_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
                       const LzScratch &sc, const Lz2Scratch &sc2, hipStream_t s)
 {
-    mi_status st = lz_find_stage_a(ctx, P, d_in, n, block0, nb, sc, sc2, s);
+    mi_status st = lz_find_stage_a(ctx, P, d_in, n, block0, nb, sc, sc2, s, s, nullptr, nullptr);
     return st ? st : lz_find_stage_b(ctx, P, nb, sc2, s);
 }
 mi_status lz_check_params(const mi_lz_params *p)
