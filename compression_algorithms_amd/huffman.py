@@ -47,7 +47,9 @@ def huffman_compress(data, ctx=None):
     ctx = ctx or default_context()
     d_in = as_device_bytes(data, ctx.device)
     n = d_in.numel()
-    cap = n + 2
+    # the ABI's worst case is 32 bits per byte; in practice a Huffman stream never exceeds 8 bits per byte of input
+    # (the fixed 8-bit code is a valid prefix code), so n/4 + slack words are enough
+    cap = n // 4 + 66
     words = torch.empty(cap, dtype=torch.int32, device=ctx.device)
     d_info = torch.zeros(C.sizeof(_lib.HuffmanInfo), dtype=torch.uint8, device=ctx.device)
     d_tree = torch.zeros(C.sizeof(_lib.HuffmanTree), dtype=torch.uint8, device=ctx.device)
