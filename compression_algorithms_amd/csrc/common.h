@@ -27,8 +27,10 @@ struct mi_ctx {
     hipStream_t stream = nullptr;       // the context's own stream
     hipStream_t side = nullptr;         // second stream: overlaps the replay/parse of batch i with the find of batch i+1
     hipStream_t fb = nullptr;           // low priority: the (normally empty) fallback chain must not hold LDS-hungry launches in front of real work
-    hipEvent_t  ev_find[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_fork = nullptr;
-    hipEvent_t  ev_part[2] = {nullptr, nullptr}, ev_fb[2] = {nullptr, nullptr};
+    hipStream_t parse = nullptr;        // third stage: parse / emit / concatenate
+#define MI_SETS 3
+    hipEvent_t  ev_find[MI_SETS] = {}, ev_done[MI_SETS] = {}, ev_part[MI_SETS] = {}, ev_fb[MI_SETS] = {}, ev_replay[MI_SETS] = {};
+    hipEvent_t  ev_fork = nullptr;
     int         last_hip = 0;
     int         profiling = 0;
     int         num_cu = 256;

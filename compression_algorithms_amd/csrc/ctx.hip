@@ -42,7 +42,9 @@ mi_status mi_ctx_create(mi_ctx **out, int device)
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // lo = least urgent
         if (hipStreamCreateWithPriority(&c->fb, hipStreamNonBlocking, lo) != hipSuccess) { hipStreamDestroy(c->stream); hipStreamDestroy(c->side); delete c; return MI_ERR_HIP; }
     }
-    for (int i = 0; i < 2; ++i) {
+    if (hipStreamCreateWithFlags(&c->parse, hipStreamNonBlocking) != hipSuccess) { delete c; return MI_ERR_HIP; }
+    for (int i = 0; i < MI_SETS; ++i) {
+        hipEventCreateWithFlags(&c->ev_replay[i], hipEventDisableTiming);
         hipEventCreateWithFlags(&c->ev_part[i], hipEventDisableTiming);
         hipEventCreateWithFlags(&c->ev_fb[i], hipEventDisableTiming);
         hipEventCreateWithFlags(&c->ev_find[i], hipEventDisableTiming);
@@ -70,7 +72,9 @@ void mi_ctx_destroy(mi_ctx *c)
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->side) hipStreamDestroy(c->side);
     if (c->fb) hipStreamDestroy(c->fb);
-    for (int i = 0; i < 2; ++i) {
+    if (c->parse) hipStreamDestroy(c->parse);
+    for (int i = 0; i < MI_SETS; ++i) {
+        if (c->ev_replay[i]) hipEventDestroy(c->ev_replay[i]);
         if (c->ev_find[i]) hipEventDestroy(c->ev_find[i]);
         if (c->ev_done[i]) hipEventDestroy(c->ev_done[i]);
         if (c->ev_part[i]) hipEventDestroy(c->ev_part[i]);

@@ -408,50 +408,54 @@ extern "C" mi_status mi_lz_encode_dev(mi_ctx *ctx, const mi_lz_params *p, const 
     const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block};
     const uint64_t nblocks = (n + P.block - 1) / P.block;
     const uint32_t nbmax = lz_batch_blocks(nblocks);
-    // two scratch sets: stage A of batch i+1 (partition + find, on `s`) overlaps stage B of batch i (replay of the
-    // exported clusters, parse, emit, concatenation, on the context's side stream).  Fork/join with events only.
+    // three stages on three streams, MI_SETS scratch sets in rotation:
+    //   `s`          partition + find of batch i+2          (LDS heavy, two workgroups per CU)
+    //   ctx->side    replay of the exported clusters of i+1 (almost no LDS: runs beside the find)
+    //   ctx->parse   parse / emit / concatenate of batch i  (one 150 KiB workgroup per CU)
+    // plus ctx->fb for the normally empty fallback chain.  Fork/join with events only: no host synchronisation.
     const bool overlap = nblocks > nbmax && !getenv("MI_LZ_NO_OVERLAP");
+    const int nsets = overlap ? MI_SETS : 1;
     const size_t set_bytes = mi_align_up(lz_scratch_bytes(nbmax), 4096);
-    st = mi_ws_reserve(ctx, set_bytes * (overlap ? 2 : 1) + 8192);
+    st = mi_ws_reserve(ctx, set_bytes * nsets + 8192);
     if (st) return st;
-    LzScratch sc[2]; Lz2Scratch sc2[2];
-    lz_carve(ctx, nbmax, &sc[0], &sc2[0], 0);
-    if (overlap) lz_carve(ctx, nbmax, &sc[1], &sc2[1], 1); else { sc[1] = sc[0]; sc2[1] = sc2[0]; }
-    uint64_t *base_bits = reinterpret_cast<uint64_t *>((uint8_t *)ctx->ws + set_bytes * (overlap ? 2 : 1));
+    LzScratch sc[MI_SETS]; Lz2Scratch sc2[MI_SETS];
+    for (int k = 0; k < nsets; ++k) lz_carve(ctx, nbmax, &sc[k], &sc2[k], k);
+    uint64_t *base_bits = reinterpret_cast<uint64_t *>((uint8_t *)ctx->ws + set_bytes * nsets);
     MI_HIP(ctx, hipMemsetAsync(base_bits, 0, 8, s));
     if (nblocks == 0) { MI_HIP(ctx, hipMemsetAsync(d_block_bits, 0, 8, s)); return MI_OK; }
-    hipStream_t sb = overlap ? ctx->side : s;
+    hipStream_t sb = overlap ? ctx->side : s, sp = overlap ? ctx->parse : s;
     uint64_t batch = 0;
     for (uint64_t b0 = 0; b0 < nblocks; b0 += nbmax, ++batch) {
         const uint32_t nb = (uint32_t)((nblocks - b0) < nbmax ? (nblocks - b0) : nbmax);
-        const int k = overlap ? (int)(batch & 1) : 0;
-        if (overlap && batch >= 2) MI_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_done[k], 0));   // set k is free again
+        const int k = (int)(batch % (uint64_t)nsets);
+        if (overlap && batch >= (uint64_t)nsets) MI_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_done[k], 0));   // set k is free again
         st = lz_find_stage_a(ctx, P, d_in, n, b0, nb, sc[k], sc2[k], s, overlap ? ctx->fb : s, ctx->ev_part[k], ctx->ev_fb[k]);
         if (st) return st;
-        if (overlap) {
-            MI_HIP(ctx, hipEventRecord(ctx->ev_find[k], s));
-            MI_HIP(ctx, hipStreamWaitEvent(sb, ctx->ev_find[k], 0));
-            if (lz_use_v2()) MI_HIP(ctx, hipStreamWaitEvent(sb, ctx->ev_fb[k], 0));      // the fallback blocks' candidates
-        }
+        if (overlap) { MI_HIP(ctx, hipEventRecord(ctx->ev_find[k], s)); MI_HIP(ctx, hipStreamWaitEvent(sb, ctx->ev_find[k], 0)); }
         st = lz_find_stage_b(ctx, P, nb, sc2[k], sb);
         if (st) return st;
+        if (overlap) {
+            MI_HIP(ctx, hipEventRecord(ctx->ev_replay[k], sb));
+            MI_HIP(ctx, hipStreamWaitEvent(sp, ctx->ev_replay[k], 0));
+            if (lz_use_v2()) MI_HIP(ctx, hipStreamWaitEvent(sp, ctx->ev_fb[k], 0));      // the fallback blocks' candidates
+        }
         uint64_t *excl_local = sc[k].block_bits;                   // reused in place by the scan
         {
-            mi_prof_scope pr(ctx, "k_lz_parse_emit", sb, (uint64_t)nb * P.block);
-            hipLaunchKernelGGL(k_lz_parse_emit, dim3(nb), dim3(1024), 0, sb, d_in, n, P, sc[k], sc2[k], lz_use_v2() ? 1 : 0, b0);
+            mi_prof_scope pr(ctx, "k_lz_parse_emit", sp, (uint64_t)nb * P.block);
+            hipLaunchKernelGGL(k_lz_parse_emit, dim3(nb), dim3(1024), 0, sp, d_in, n, P, sc[k], sc2[k], lz_use_v2() ? 1 : 0, b0);
         }
-        hipLaunchKernelGGL(k_lz_scan_blocks, dim3(1), dim3(1024), 0, sb, sc[k].block_bits, nb, base_bits, excl_local, d_block_bits + b0);
+        hipLaunchKernelGGL(k_lz_scan_blocks, dim3(1), dim3(1024), 0, sp, sc[k].block_bits, nb, base_bits, excl_local, d_block_bits + b0);
         {
-            mi_prof_scope pr(ctx, "k_lz_concat", sb, (uint64_t)nb * P.block);
+            mi_prof_scope pr(ctx, "k_lz_concat", sp, (uint64_t)nb * P.block);
             const uint64_t maxw = (uint64_t)nb * LZ_SLOT_WORDS + 2;   // upper bound on the dwords of this batch
-            hipLaunchKernelGGL(k_lz_concat, dim3((unsigned)((maxw + 255) / 256)), dim3(256), 0, sb, sc[k].slot, excl_local, nb,
+            hipLaunchKernelGGL(k_lz_concat, dim3((unsigned)((maxw + 255) / 256)), dim3(256), 0, sp, sc[k].slot, excl_local, nb,
                                base_bits, reinterpret_cast<uint32_t *>(d_out));
         }
-        hipLaunchKernelGGL(k_lz_advance, dim3(1), dim3(1), 0, sb, base_bits, excl_local, nb);
-        if (overlap) MI_HIP(ctx, hipEventRecord(ctx->ev_done[k], sb));
+        hipLaunchKernelGGL(k_lz_advance, dim3(1), dim3(1), 0, sp, base_bits, excl_local, nb);
+        if (overlap) MI_HIP(ctx, hipEventRecord(ctx->ev_done[k], sp));
     }
-    if (overlap) {                                                 // join: everything on the side stream before `s` goes on
-        MI_HIP(ctx, hipEventRecord(ctx->ev_fork, sb));
+    if (overlap) {                                                 // join: the last stage finishes everything
+        MI_HIP(ctx, hipEventRecord(ctx->ev_fork, sp));
         MI_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_fork, 0));
     }
     MI_HIP(ctx, hipGetLastError());
