@@ -13,8 +13,8 @@
 #define LZ2_WAVE      128u                  // ... and from this size on a whole wave replays one cluster
 #define LZ2_MAXBIG    (LZ2_CAP / LZ2_BIG)   // exported clusters per part, at most
 #define LZ2_DESC_SMALL (LZ_MAX_BLOCK / LZ2_BIG + 32u)   // exported clusters per block, at most
-// export classes: 0: 16..31, 1: 32..63, 2: 64..127, 3: 128..255 (a lane per cluster, 64 clusters per wave),
-//                 4: 256..511 (a lane per cluster, 32 per wave); 5: 512..1024, 6: > 1024 (a wave per cluster)
+// export classes: 7: 8..15, 0: 16..31, 1: 32..63, 2: 64..127 entries (a lane per cluster, 64 clusters per wave);
+//                 5: 128..1024, 6: > 1024 (a wave per cluster); 3 and 4 (lane replay of 128..511) exist but are not fed
 #define LZ2_NCLASS    8u                    // class 7: 8..15 entries (a lane per cluster)
 #define LZ2_BIG_SMALL 1024u                 // boundary between the two wave-replay classes (1 vs 4 bitmap dwords per lane)
 __host__ __device__ __forceinline__ uint32_t lz2_class_of(uint32_t cnt)

@@ -68,7 +68,6 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     __shared__ uint32_t s_cnt[LZ2_NWAVES][256];
     __shared__ uint32_t s_bm[LZ2_CAP / 32 + 2];
     __shared__ int32_t  s_i32[18];
-    __shared__ uint32_t s_u32[18];
     __shared__ uint32_t s_zslot, s_zgid, s_nbigl, s_ngroups;
     __shared__ uint16_t s_gstart[LZ2_CAP + 2];          // replay index of the head of every cluster
     __shared__ uint32_t s_big[3 * LZ2_MAXBIG];          // clusters exported by this part: {s, e, global dst}
@@ -159,11 +158,21 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
                 prev_h = h;
             }
         }
-        uint32_t total_heads; int32_t d1, d2;
-        const uint32_t gid_base = block_exclusive_scan<uint32_t>(nheads, OpAddU32(), 0u, s_u32, &total_heads);
+        // one scan for three carries: heads so far (sum), last head index + 1 (max), last home-run start + 1 (max)
+        struct OpHeads {
+            __device__ uint64_t operator()(uint64_t a, uint64_t b) const {
+                const uint64_t s0 = (a & 0xFFFFu) + (b & 0xFFFFu);
+                const uint64_t a1 = (a >> 16) & 0xFFFFu, b1 = (b >> 16) & 0xFFFFu, a2 = (a >> 32) & 0xFFFFu, b2 = (b >> 32) & 0xFFFFu;
+                return s0 | ((a1 > b1 ? a1 : b1) << 16) | ((a2 > b2 ? a2 : b2) << 32);
+            }
+        };
+        __shared__ uint64_t s_u64[18];
+        uint64_t tot3;
+        const uint64_t pre3 = block_exclusive_scan<uint64_t>((uint64_t)nheads | ((uint64_t)(lasthead + 1) << 16) | ((uint64_t)(lastrun + 1) << 32),
+                                                            OpHeads(), 0ull, s_u64, &tot3);
+        const uint32_t gid_base = (uint32_t)(pre3 & 0xFFFFu), total_heads = (uint32_t)(tot3 & 0xFFFFu);
+        const int32_t gs_carry = (int32_t)((pre3 >> 16) & 0xFFFFu) - 1, hs_carry = (int32_t)((pre3 >> 32) & 0xFFFFu) - 1;
         if (tid == 0) s_ngroups = total_heads;
-        const int32_t gs_carry = block_exclusive_scan<int32_t>(lasthead, OpMaxI32(), -1, s_i32, &d1);
-        const int32_t hs_carry = block_exclusive_scan<int32_t>(lastrun, OpMaxI32(), -1, s_i32, &d2);
         int32_t run = premax, prev_h = 0;
         uint32_t cur_gs = 0, cur_gid = gid_base; int32_t cur_base = 0;
         uint32_t cur_hs = 0, hs_word = 0, hs_j = 0;
@@ -558,8 +567,6 @@ template __global__ void k_lz2_mid<16, 64>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_mid<32, 64>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_mid<64, 64>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_mid<128, 64>(LzP, Lz2Scratch, int);
-template __global__ void k_lz2_mid<256, 64>(LzP, Lz2Scratch, int);
-template __global__ void k_lz2_mid<512, 32>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_big<LZ2_BIG_SMALL, 1>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_big<LZ2_CAP, 4>(LzP, Lz2Scratch, int);
 
