@@ -300,28 +300,29 @@ void k_lz_concat(const uint32_t *__restrict__ slots, const uint64_t *__restrict_
 {
     const uint64_t base = *base_bits, total = excl_local[nb];
     const uint64_t wfirst = base >> 5, wlast = (base + total + 31) >> 5;       // [wfirst, wlast)
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + wfirst;
-    if (j >= wlast) return;
-    const uint64_t g0 = j << 5, g1 = g0 + 32;
-    uint64_t pos = g0 > base ? g0 : base;
-    const uint64_t end = g1 < base + total ? g1 : base + total;
-    // largest i with base + excl[i] <= pos
-    uint32_t lo = 0, hi = nb - 1;
-    const uint64_t rel = pos - base;
-    while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (excl_local[mid] <= rel) lo = mid; else hi = mid - 1; }
-    uint32_t i = lo, word = 0;
-    while (pos < end) {
-        const uint64_t bs = base + excl_local[i], be = base + excl_local[i + 1];
-        const uint64_t se = be < end ? be : end;
-        if (se > pos) {
-            const uint32_t k = (uint32_t)(se - pos);
-            word |= extract_bits(slots + (size_t)i * LZ_SLOT_WORDS, pos - bs, k) << (uint32_t)(pos - g0);
-            pos = se;
+    // grid-stride: the grid is sized for a typical stream, the loop covers the worst case
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + wfirst; j < wlast; j += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t g0 = j << 5, g1 = g0 + 32;
+        uint64_t pos = g0 > base ? g0 : base;
+        const uint64_t end = g1 < base + total ? g1 : base + total;
+        // largest i with base + excl[i] <= pos
+        uint32_t lo = 0, hi = nb - 1;
+        const uint64_t rel = pos - base;
+        while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (excl_local[mid] <= rel) lo = mid; else hi = mid - 1; }
+        uint32_t i = lo, word = 0;
+        while (pos < end) {
+            const uint64_t bs = base + excl_local[i], be = base + excl_local[i + 1];
+            const uint64_t se = be < end ? be : end;
+            if (se > pos) {
+                const uint32_t k = (uint32_t)(se - pos);
+                word |= extract_bits(slots + (size_t)i * LZ_SLOT_WORDS, pos - bs, k) << (uint32_t)(pos - g0);
+                pos = se;
+            }
+            if (pos == be) ++i;
         }
-        if (pos == be) ++i;
+        if (j == wfirst && (base & 31u)) atomicOr(&out[j], word);      // shares a dword with the previous batch
+        else out[j] = word;
     }
-    if (j == wfirst && (base & 31u)) atomicOr(&out[j], word);      // shares a dword with the previous batch
-    else out[j] = word;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -447,8 +448,8 @@ extern "C" mi_status mi_lz_encode_dev(mi_ctx *ctx, const mi_lz_params *p, const 
         hipLaunchKernelGGL(k_lz_scan_blocks, dim3(1), dim3(1024), 0, sp, sc[k].block_bits, nb, base_bits, excl_local, d_block_bits + b0);
         {
             mi_prof_scope pr(ctx, "k_lz_concat", sp, (uint64_t)nb * P.block);
-            const uint64_t maxw = (uint64_t)nb * LZ_SLOT_WORDS + 2;   // upper bound on the dwords of this batch
-            hipLaunchKernelGGL(k_lz_concat, dim3((unsigned)((maxw + 255) / 256)), dim3(256), 0, sp, sc[k].slot, excl_local, nb,
+            const uint64_t typw = (uint64_t)nb * (P.block / 4 + 64);   // about one output byte per input byte; the kernel strides
+            hipLaunchKernelGGL(k_lz_concat, dim3((unsigned)((typw + 255) / 256)), dim3(256), 0, sp, sc[k].slot, excl_local, nb,
                                base_bits, reinterpret_cast<uint32_t *>(d_out));
         }
         hipLaunchKernelGGL(k_lz_advance, dim3(1), dim3(1), 0, sp, base_bits, excl_local, nb);
