@@ -17,11 +17,11 @@
 //                 5: 128..1024, 6: > 1024 (a wave per cluster); 3 and 4 (lane replay of 128..511) exist but are not fed
 #define LZ2_NCLASS    8u                    // class 7: 8..15 entries (a lane per cluster)
 #define LZ2_BIG_SMALL 1024u                 // boundary between the two wave-replay classes (1 vs 4 bitmap dwords per lane)
-__host__ __device__ __forceinline__ uint32_t lz2_class_of(uint32_t cnt)
+// wave_min: clusters of at least this many entries are replayed by a whole wave (128, 256 or 512)
+__host__ __device__ __forceinline__ uint32_t lz2_class_of(uint32_t cnt, uint32_t wave_min)
 {
-    // classes 3 and 4 (lane replay of 128..511 entries) are built but not fed: with ~100 KiB of LDS per wave only one
-    // wave fits a CU and nothing hides its latency — measured 4x slower than the wave replay (profiles/r01b notes)
-    return cnt < 16 ? 7u : cnt < 32 ? 0u : cnt < 64 ? 1u : cnt < LZ2_WAVE ? 2u : cnt <= LZ2_BIG_SMALL ? 5u : 6u;
+    if (cnt >= wave_min) return cnt <= LZ2_BIG_SMALL ? 5u : 6u;
+    return cnt < 16 ? 7u : cnt < 32 ? 0u : cnt < 64 ? 1u : cnt < 128 ? 2u : cnt < 256 ? 3u : 4u;
 }
 #define LZ2_PENDING16 0xFFFEu               // cand placeholder of an entry whose cluster went to the wave replay
 
@@ -52,4 +52,5 @@ struct Lz2Scratch {
     Lz2BigDesc   *desc[LZ2_NCLASS];                  // per class: [nb * capacity of the class]
     uint32_t     *big_count;                         // [LZ2_NCLASS]
     uint64_t     *dbg;                               // phase cycle counters (MI_LZ_DEBUG=1), else NULL
+    uint32_t      wave_min;                          // see lz2_class_of
 };

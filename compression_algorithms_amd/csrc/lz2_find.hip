@@ -37,16 +37,25 @@ __device__ void replay_small(const uint16_t *pos, uint16_t *rs, const uint16_t *
             ++ev;
         }
         if (anom_pending && p > W - 1u) { atomicAnd(&bm[anom >> 5], ~(1u << (anom & 31u))); anom_pending = false; }
+        // the bitmap word and the occupant of the home slot are fetched together, then its id and position together
+        uint32_t wi = r >> 5;
+        const uint32_t w0 = bm[wi];
+        const uint32_t o0 = occ[r];
         uint32_t res = LZ_NONE16;
-        for (uint32_t b = r;; ++b) {
-            if (b == limit && r < limit) break;
-            if (!bm2_test(bm, b)) break;
-            const uint32_t o = occ[b];
-            if (pid[o] == id) { res = pos[o]; break; }
+        if ((w0 >> (r & 31u)) & 1u) {
+            const uint32_t id0 = pid[o0], pos0 = pos[o0];
+            if (id0 == id) res = pos0;
+            else {
+                for (uint32_t b = r + 1;; ++b) {                         // rare: the home holds another word
+                    if (b == limit && r < limit) break;
+                    if (!bm2_test(bm, b)) break;
+                    const uint32_t o = occ[b];
+                    if (pid[o] == id) { res = pos[o]; break; }
+                }
+            }
         }
         cand_i[i] = (uint16_t)res;
-        uint32_t wi = r >> 5;                                            // first fit: word scan (inside the cluster by the parking bound)
-        uint32_t wv = bm[wi] | ((1u << (r & 31u)) - 1u);
+        uint32_t wv = w0 | ((1u << (r & 31u)) - 1u);                     // first fit: word scan (inside the cluster by the parking bound)
         while (wv == 0xFFFFFFFFu) wv = bm[++wi];
         const uint32_t b = (wi << 5) + (uint32_t)__builtin_ctz(~wv);
         atomicOr(&bm[b >> 5], 1u << (b & 31u));
@@ -327,7 +336,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
         uint32_t it = 0;
         for (uint32_t q = tid; q < nbig; q += LZ2_THREADS, ++it) {
             const uint32_t cnt = s_big[3 * q + 1] - s_big[3 * q];
-            const uint32_t cls = lz2_class_of(cnt);
+            const uint32_t cls = lz2_class_of(cnt, sc.wave_min);
             my_rank[it] = atomicAdd(&s_cls[cls], 1u);
             my_dst[it] = atomicAdd(&s_ent, cnt);
         }
@@ -340,7 +349,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
         uint32_t it = 0;
         for (uint32_t q = tid; q < nbig; q += LZ2_THREADS, ++it) {
             const uint32_t s = s_big[3 * q], e = s_big[3 * q + 1], cnt = e - s;
-            const uint32_t cls = lz2_class_of(cnt);
+            const uint32_t cls = lz2_class_of(cnt, sc.wave_min);
             const uint32_t dst = s_entbase + my_dst[it];
             s_big[3 * q + 2] = dst;
             Lz2BigDesc d;
@@ -464,13 +473,22 @@ void k_lz2_big(LzP P, Lz2Scratch sc, int large)
                     ++ev;
                 }
                 if (anom_pending && p > W - 1u) { if (bm.test(d_anom)) bm.flip(d_anom, lane); anom_pending = false; }
+                // find: the occupant of the home slot is fetched before the (register) occupancy test says whether
+                // it is needed — one LDS round trip on the common path
+                const uint32_t h_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_opid[r]);
+                const uint32_t h_pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_opos[r]);
                 uint32_t res = LZ_NONE16;
-                for (uint32_t b = r;; ++b) {                            // find
-                    if (b == d_limit && r < d_limit) break;
-                    if (!bm.test(b)) break;
-                    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)s_opid[b]) == id) {
-                        res = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_opos[b]);
-                        break;
+                if (bm.test(r)) {
+                    if (h_id == id) res = h_pos;
+                    else {
+                        for (uint32_t b = r + 1;; ++b) {                // rare: the home holds another word
+                            if (b == d_limit && r < d_limit) break;
+                            if (!bm.test(b)) break;
+                            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)s_opid[b]) == id) {
+                                res = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_opos[b]);
+                                break;
+                            }
+                        }
                     }
                 }
                 const uint32_t b = bm.first_zero_from(r, lane);         // insert: first fit
@@ -490,9 +508,101 @@ void k_lz2_big(LzP P, Lz2Scratch sc, int large)
 // 64 clusters per wave, every lane owns a private LDS region (slot -> word id, slot -> position,
 // entry -> slot, occupancy bits).  All lanes of a wave step through clusters of similar size.
 // =============================================================================================
+template <bool SMALL> struct SlotType { typedef uint8_t type; };
+template <> struct SlotType<false> { typedef uint16_t type; };
+
 template <int CMAX, int LANES>
 __global__ __launch_bounds__(64)
 void k_lz2_mid(LzP P, Lz2Scratch sc, int cls)
+{
+    constexpr int STRIDE = CMAX + 1;                      // odd stride in 16-bit units: spreads the lanes over the banks
+    constexpr int CH = 16;                                // entries per cluster staged per round
+    constexpr int ROW = 66;                               // padded row of the staging tiles (bank spread for the column writes)
+    typedef typename SlotType<(CMAX <= 256)>::type slot_t;     // a slot number fits a byte up to 256 entries
+    __shared__ uint16_t s_opid[LANES * STRIDE], s_opos[LANES * STRIDE], s_epos[LANES * STRIDE];
+    __shared__ slot_t   s_slot[LANES * STRIDE];
+    __shared__ uint32_t s_bits[LANES * (CMAX / 32 + 1)];
+    // every lane walks its own cluster, so direct global accesses would touch 64 cache lines per instruction:
+    // CH entries of all 64 clusters are staged through LDS by coalesced loads (four clusters per instruction)
+    __shared__ uint16_t st_pos[CH * ROW], st_rs[CH * ROW], st_pid[CH * ROW], st_out[CH * ROW];
+    __shared__ uint32_t s_dblk[64], s_dstart[64], s_dcnt[64];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t ncl = sc.big_count[cls];
+    const uint32_t ci = blockIdx.x * (uint32_t)LANES + lane;
+    if (blockIdx.x * (uint32_t)LANES >= ncl) return;
+    const bool active = ci < ncl && lane < (uint32_t)LANES;
+    Lz2BigDesc d;
+    d.block = 0; d.start = 0; d.count = 0; d.anom = ~0u; d.limit = ~0u;
+    if (active) d = sc.desc[cls][ci];
+    const uint32_t n = d.count, W = 1u << P.wbits;
+    s_dblk[lane] = d.block; s_dstart[lane] = d.start; s_dcnt[lane] = n;
+    const uint32_t lr = lane < (uint32_t)LANES ? lane : 0u;  // surplus lanes (LANES < 64) idle on region 0: n = 0
+    uint16_t *opid = s_opid + lr * STRIDE, *opos = s_opos + lr * STRIDE, *epos = s_epos + lr * STRIDE;
+    slot_t *slot = s_slot + lr * STRIDE;
+    uint32_t *bits = s_bits + lr * (CMAX / 32 + 1);
+    if (lane < (uint32_t)LANES) for (int k = 0; k < CMAX / 32 + 1; ++k) bits[k] = 0;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t ev = 0;
+    bool anom_pending = d.anom != ~0u;
+    const uint32_t sub = lane >> 4, eo = lane & 15u;         // staging role: cluster (4 per step) and entry offset
+    for (uint32_t c0 = 0; c0 < (uint32_t)CMAX; c0 += CH) {
+        if (__ballot(c0 < n) == 0ull) break;                // every cluster of this wave is done
+        for (uint32_t g = 0; g < 16; ++g) {                 // 64 clusters, 4 per step, 16 consecutive entries each
+            const uint32_t cl = g * 4u + sub, e = c0 + eo;
+            if (e < s_dcnt[cl]) {
+                const size_t at = (size_t)s_dblk[cl] * LZ_MAX_BLOCK + s_dstart[cl] + e;
+                st_pos[eo * ROW + cl] = sc.bigpos[at]; st_rs[eo * ROW + cl] = sc.bigrs[at]; st_pid[eo * ROW + cl] = sc.bigpid[at];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t t = 0; t < (uint32_t)CH; ++t) {
+            const uint32_t i = c0 + t;
+            if (i >= n) continue;                           // lanes with shorter clusters idle (same size class: < 2x)
+            const uint32_t p = st_pos[t * ROW + lane], r = st_rs[t * ROW + lane], id = st_pid[t * ROW + lane];
+            epos[i] = (uint16_t)p;
+            while (ev < i && (uint32_t)epos[ev] + W < p) {  // FIFO retirement
+                const uint32_t b = slot[ev];
+                bits[b >> 5] &= ~(1u << (b & 31u));
+                ++ev;
+            }
+            if (anom_pending && p > W - 1u) { bits[d.anom >> 5] &= ~(1u << (d.anom & 31u)); anom_pending = false; }
+            // everything the common case needs depends on the home slot alone: three loads in flight at once
+            const uint32_t w0 = bits[r >> 5];
+            const uint32_t h_id = opid[r], h_pos = opos[r];
+            uint32_t res = LZ_NONE16;
+            if ((w0 >> (r & 31u)) & 1u) {
+                if (h_id == id) res = h_pos;
+                else {
+                    for (uint32_t b = r + 1;; ++b) {       // rare: the home holds another word
+                        if (b == d.limit && r < d.limit) break;
+                        if (!((bits[b >> 5] >> (b & 31u)) & 1u)) break;
+                        if (opid[b] == id) { res = opos[b]; break; }
+                    }
+                }
+            }
+            st_out[t * ROW + lane] = (uint16_t)res;
+            uint32_t wi = r >> 5;
+            uint32_t wv = w0 | ((1u << (r & 31u)) - 1u);
+            while (wv == 0xFFFFFFFFu) wv = bits[++wi];
+            const uint32_t b = (wi << 5) + (uint32_t)__builtin_ctz(~wv);
+            bits[b >> 5] |= 1u << (b & 31u);
+            opid[b] = (uint16_t)id; opos[b] = (uint16_t)p; slot[i] = (slot_t)b;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t g = 0; g < 16; ++g) {
+            const uint32_t cl = g * 4u + sub, e = c0 + eo;
+            if (e < s_dcnt[cl]) sc.bigcand[(size_t)s_dblk[cl] * LZ_MAX_BLOCK + s_dstart[cl] + e] = st_out[eo * ROW + cl];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// the same replay with direct (uncoalesced) global accesses and 3x less LDS.  DEFAULT: alone it is slower than the
+// staged variant (8.35 vs 7.16 ms / 400 MB) but beside k_lz2_find of the next batch its smaller LDS footprint wins
+// (10.88 vs 10.46 GB/s whole pipeline, same box); MI_LZ_MID_STAGED=1 selects the staged kernel
+template <int CMAX, int LANES>
+__global__ __launch_bounds__(64)
+void k_lz2_mid_direct(LzP P, Lz2Scratch sc, int cls)
 {
     constexpr int STRIDE = CMAX + 1;                      // odd stride in 16-bit units: spreads the lanes over the banks
     __shared__ uint16_t s_opid[LANES * STRIDE], s_opos[LANES * STRIDE], s_slot[LANES * STRIDE];
@@ -563,10 +673,16 @@ void k_lz2_scatter(Lz2Scratch sc, uint16_t *__restrict__ cand_by_pos /* [nb][655
     for (uint32_t j = threadIdx.x; j < nb; j += 1024) out[bp[j]] = bc[j];
 }
 
+template __global__ void k_lz2_mid_direct<16, 64>(LzP, Lz2Scratch, int);
+template __global__ void k_lz2_mid_direct<32, 64>(LzP, Lz2Scratch, int);
+template __global__ void k_lz2_mid_direct<64, 64>(LzP, Lz2Scratch, int);
+template __global__ void k_lz2_mid_direct<128, 64>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_mid<16, 64>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_mid<32, 64>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_mid<64, 64>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_mid<128, 64>(LzP, Lz2Scratch, int);
+template __global__ void k_lz2_mid<256, 64>(LzP, Lz2Scratch, int);
+template __global__ void k_lz2_mid<512, 32>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_big<LZ2_BIG_SMALL, 1>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_big<LZ2_CAP, 4>(LzP, Lz2Scratch, int);
 
@@ -600,6 +716,8 @@ void lz2_carve(mi_carver &cv, uint32_t nb, Lz2Scratch *sc)
     for (uint32_t c = 0; c < LZ2_NCLASS; ++c) sc->desc[c] = cv.take<Lz2BigDesc>((size_t)nb * lz2_class_cap(c));
     sc->big_count = sc->fallback_count + 16;
     sc->dbg = getenv("MI_LZ_DEBUG") ? cv.take<uint64_t>(32) : nullptr;
+    sc->wave_min = LZ2_WAVE;
+    if (const char *e = getenv("MI_LZ_WAVE_MIN")) { const int v = atoi(e); if (v == 128 || v == 256 || v == 512) sc->wave_min = (uint32_t)v; }
 }
 
 static uint64_t *g_dbg_ptr = nullptr;
@@ -641,12 +759,22 @@ mi_status lz2_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &
     {
         mi_prof_scope p(ctx, "k_lz2_mid", s, (uint64_t)nb * P.block);
         // grids cover the worst case; surplus workgroups read the class count and leave
-        hipLaunchKernelGGL((k_lz2_mid<16, 64>), dim3(nb * lz2_class_cap(7) / 64 + 1), dim3(64), 0, s, P, sc, 7);
-        hipLaunchKernelGGL((k_lz2_mid<32, 64>), dim3(nb * lz2_class_cap(0) / 64 + 1), dim3(64), 0, s, P, sc, 0);
-        hipLaunchKernelGGL((k_lz2_mid<64, 64>), dim3(nb * lz2_class_cap(1) / 64 + 1), dim3(64), 0, s, P, sc, 1);
-        hipLaunchKernelGGL((k_lz2_mid<128, 64>), dim3(nb * lz2_class_cap(2) / 64 + 1), dim3(64), 0, s, P, sc, 2);
-        // classes 3 and 4 are never fed (lz2_class_of) and an empty launch that asks for 100 KiB of LDS per workgroup
-        // still queues behind k_lz2_find for that LDS: not launched
+        static const bool direct = getenv("MI_LZ_MID_STAGED") == nullptr;   // same-box A/B (round 1): direct 10.88 GB/s, staged 10.46
+        if (direct) {
+            hipLaunchKernelGGL((k_lz2_mid_direct<16, 64>), dim3(nb * lz2_class_cap(7) / 64 + 1), dim3(64), 0, s, P, sc, 7);
+            hipLaunchKernelGGL((k_lz2_mid_direct<32, 64>), dim3(nb * lz2_class_cap(0) / 64 + 1), dim3(64), 0, s, P, sc, 0);
+            hipLaunchKernelGGL((k_lz2_mid_direct<64, 64>), dim3(nb * lz2_class_cap(1) / 64 + 1), dim3(64), 0, s, P, sc, 1);
+            hipLaunchKernelGGL((k_lz2_mid_direct<128, 64>), dim3(nb * lz2_class_cap(2) / 64 + 1), dim3(64), 0, s, P, sc, 2);
+        } else {
+            hipLaunchKernelGGL((k_lz2_mid<16, 64>), dim3(nb * lz2_class_cap(7) / 64 + 1), dim3(64), 0, s, P, sc, 7);
+            hipLaunchKernelGGL((k_lz2_mid<32, 64>), dim3(nb * lz2_class_cap(0) / 64 + 1), dim3(64), 0, s, P, sc, 0);
+            hipLaunchKernelGGL((k_lz2_mid<64, 64>), dim3(nb * lz2_class_cap(1) / 64 + 1), dim3(64), 0, s, P, sc, 1);
+            hipLaunchKernelGGL((k_lz2_mid<128, 64>), dim3(nb * lz2_class_cap(2) / 64 + 1), dim3(64), 0, s, P, sc, 2);
+        }
+        // classes 3 / 4 only exist when the wave replay starts at 256 / 512 entries (an empty launch that asks for
+        // ~90 KiB of LDS per workgroup would still queue behind k_lz2_find for that LDS)
+        if (sc.wave_min > 128) hipLaunchKernelGGL((k_lz2_mid<256, 64>), dim3(nb * lz2_class_cap(3) / 64 + 1), dim3(64), 0, s, P, sc, 3);
+        if (sc.wave_min > 256) hipLaunchKernelGGL((k_lz2_mid<512, 32>), dim3(nb * lz2_class_cap(4) / 32 + 1), dim3(64), 0, s, P, sc, 4);
     }
     {
         mi_prof_scope p(ctx, "k_lz2_big", s, (uint64_t)nb * P.block);

@@ -19,7 +19,7 @@ COVERED32 = 0xFFFFFFFE
 
 def build(force=False):
     so = os.path.join(_HERE, "liborc.so")
-    srcs = [os.path.join(_HERE, f) for f in ("orc_lz.c", "orc_huff.c", "orc_fse.c", "orc_table.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("orc_lz.c", "orc_huff.c", "orc_fse.c", "orc_defh.c", "orc_table.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "liborc.so"])
     return so
@@ -73,6 +73,12 @@ def lib():
         L.orc_fse_decode_block.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_uint64]
         L.orc_fse_ideal_bits.restype = C.c_double
         L.orc_fse_ideal_bits.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32]
+        L.orc_defh_encode_block.restype = C.c_uint64
+        L.orc_defh_encode_block.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+        L.orc_defh_decode_block.restype = C.c_uint64
+        L.orc_defh_decode_block.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+        L.orc_defh_lengths.restype = None
+        L.orc_defh_lengths.argtypes = [C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -270,3 +276,28 @@ def fse_decode_block(rec, n, L=8, S=64, spread=1):
 def fse_ideal_bits(data, L=8):
     src = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8)) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data)
     return float(lib().orc_fse_ideal_bits(_p(src), len(src), L))
+
+
+# ---------------------------------------------------------------- mode H (tokens + per-block dynamic Huffman)
+def defh_encode_block(tokens):
+    """reference byte tokens of one block -> mode-H record (oracle/orc_defh.c)"""
+    t = np.ascontiguousarray(tokens, dtype=np.uint8)
+    out = np.zeros(4 + 288 + 4 * len(t) + 16, dtype=np.uint8)
+    m = lib().orc_defh_encode_block(_p(t), len(t), _p(out))
+    return out[:m].copy()
+
+
+def defh_decode_block(rec, cap):
+    r = np.ascontiguousarray(rec, dtype=np.uint8)
+    out = np.zeros(cap, dtype=np.uint8)
+    m = lib().orc_defh_decode_block(_p(r), len(r), _p(out), cap)
+    if m == 0xFFFFFFFFFFFFFFFF:
+        raise ValueError("malformed mode-H record")
+    return out[:m].copy()
+
+
+def defh_lengths(freq):
+    f = np.ascontiguousarray(freq, dtype=np.uint32)
+    ln = np.zeros(286, dtype=np.uint8)
+    lib().orc_defh_lengths(_p(f), _p(ln))
+    return ln
