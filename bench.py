@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — encode throughput of the MI355X-native block-parallel compressor.
 
-    python bench.py --gpus N --steps K --warmup W [--workload deflate|lz77w16|lz77w14|huffman|fse]
+    python bench.py --gpus N --steps K --warmup W [--workload deflate|deflate-h|lz77w16|lz77w14|huffman|fse]
 
 N > 1 is launched by the driver as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -34,7 +34,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="deflate", choices=["deflate", "lz77w16", "lz77w14", "huffman", "fse"])
+    ap.add_argument("--workload", default="deflate", choices=["deflate", "deflate-h", "lz77w16", "lz77w14", "huffman", "fse"])
     ap.add_argument("--bytes", type=int, default=1_000_000_000, help="input bytes per GPU")
     ap.add_argument("--gather", action="store_true", help="N>1: gather the compressed streams to rank 0 (timed)")
     ap.add_argument("--cpu-sample-mb", type=float, default=None)
@@ -57,6 +57,15 @@ def make_step(workload, x, ctx):
                 "lz77w16": "lz77 (W=64 KiB, len<=15, bit-packed), independent 64 KiB blocks",
                 "lz77w14": "lz77 (W=16 KiB, len<=15, bit-packed), independent 64 KiB blocks"}[workload]
         return step, (lambda: holder["st"].nbytes), (lambda: holder["st"]), "u8", desc
+    if workload == "deflate-h":
+        holder = {}
+        p = lz.params("deflate")
+
+        def step():
+            holder["st"] = lz.compress_h(x, p, ctx)
+
+        return step, (lambda: holder["st"].nbytes), (lambda: holder["st"]), "u8", \
+            "deflate tokeniser + per-block dynamic Huffman over the 286-symbol alphabet (mode H), independent 64 KiB blocks"
     if workload == "huffman":
         holder = {}
 
@@ -93,6 +102,13 @@ def cpu_baseline(workload, sample, sample_desc):
         else:
             t0 = time.perf_counter()
             orc.deflate_stream(sample, 65536, True)
+    elif workload == "deflate-h":
+        # the reference has no entropy stage for this path: the oracle's tokeniser + its mode-H coder
+        d = orc.Deflate(65536)
+        t0 = time.perf_counter()
+        for at in range(0, n, 65536):
+            d.fresh()
+            orc.defh_encode_block(d.block_encode(sample[at:at + 65536]))
     elif workload in ("lz77w16", "lz77w14"):
         wb = 16 if workload == "lz77w16" else 14
         t0 = time.perf_counter()
@@ -209,7 +225,7 @@ def main():
                     "all_kernels_ms_per_step": {k["name"]: round(k["ms"] * k["launches"] / args.steps, 3) for k in ktimes}}
         cpu = None
         if not args.no_cpu_baseline:
-            rate = {"deflate": 0.016, "lz77w16": 0.012, "lz77w14": 0.014, "huffman": 0.23, "fse": 0.15}[args.workload]
+            rate = {"deflate": 0.016, "deflate-h": 0.012, "lz77w16": 0.012, "lz77w14": 0.014, "huffman": 0.23, "fse": 0.15}[args.workload]
             mb = args.cpu_sample_mb if args.cpu_sample_mb else min(n / 1e6, max(4.0, 15.0 * rate * 1e3))
             nsamp = int(mb * 1e6) // 65536 * 65536 or min(n, 65536)
             sample = x[:nsamp].cpu().numpy()

@@ -53,6 +53,7 @@ EXPORTS = [
     "mi_ctx_create", "mi_ctx_destroy", "mi_status_str", "mi_last_hip_error", "mi_version", "mi_sync",
     "mi_huffman_encode_dev", "mi_huffman_encode", "mi_huffman_encode2", "mi_huffman_decode_dev", "mi_huffman_decode",
     "mi_lz_encode_dev", "mi_lz_encode", "mi_lz_decode_dev", "mi_lz_decode", "mi_lz_find_all_dev",
+    "mi_deflate_h_bound_bytes", "mi_deflate_h_encode_dev", "mi_deflate_h_decode_dev", "mi_deflate_h_encode", "mi_deflate_h_decode",
     "mi_fse_block_bound", "mi_fse_encode_dev", "mi_fse_decode_dev", "mi_fse_encode", "mi_fse_decode", "mi_fse_normalise_dev",
     "mi_set_profiling", "mi_get_kernel_times",
 ]
@@ -96,6 +97,13 @@ def lib():
             L.mi_lz_encode.argtypes = [vp, C.POINTER(LzParams), vp, u64, vp, u64, vp]
             L.mi_lz_decode_dev.argtypes = [vp, C.POINTER(LzParams), vp, vp, vp, u64, vp]
             L.mi_lz_find_all_dev.argtypes = [vp, C.POINTER(LzParams), vp, u64, vp, vp]
+        if hasattr(L, "mi_deflate_h_encode_dev"):
+            L.mi_deflate_h_bound_bytes.restype = u64
+            L.mi_deflate_h_bound_bytes.argtypes = [u64]
+            L.mi_deflate_h_encode_dev.argtypes = [vp, C.POINTER(LzParams), vp, u64, vp, u64, vp, vp]
+            L.mi_deflate_h_decode_dev.argtypes = [vp, C.POINTER(LzParams), vp, vp, vp, u64, vp]
+            L.mi_deflate_h_encode.argtypes = [vp, C.POINTER(LzParams), vp, u64, vp, u64, vp]
+            L.mi_deflate_h_decode.argtypes = [vp, C.POINTER(LzParams), vp, u64, vp, vp, u64]
         if hasattr(L, "mi_fse_encode_dev"):
             L.mi_fse_block_bound.restype = u64
             L.mi_fse_block_bound.argtypes = [C.POINTER(FseParams)]

@@ -1,0 +1,336 @@
+// defh.hip — "mode H": the entropy stage the reference's deflate leaves as a TODO
+// (algorithms/deflate/lz77.c:279 "// TODO: Build huffman tree and encode compressed buffer").
+//
+// Taken from the reference: the token sequence (algorithms/deflate/lz77.c:199-280, produced by the
+// same finder / parse kernels as the byte-token stream), the 286-symbol alphabet
+// (deflate/huffman.h:6 NUM_CODES; huffman.c:49-62: literal b -> b, match with offset d ->
+// 256 + clz16(d)), the per-block tally (lz77.c:206,231,273), MSB-first u32 packing
+// (deflate/huffman.c:16-46) and the heap merge procedure with its tie-breaking
+// (algorithms/huffman/huffman.c:100-163,189-211).  Defined by this project (the bit
+// stream is PARITY UNPINNED — the reference has no such encoder; the oracle restatement is
+// oracle/orc_defh.c): lengths from that heap, canonical codes by (length, symbol), a match symbol is
+// followed by the offset bits below its leading one and the 5-bit length.
+//
+// Block record, 4-byte aligned:   u32 n_tokens | u8 len[286] + 2 pad | u32 words[] (MSB-first)
+//
+//   k_defh_encode   one workgroup per block over the token records k_lz_parse_emit left (mode H)
+//   k_defh_decode   one wave per block: record -> tokens -> bytes (LZ copy in LDS), no token stream in HBM
+#include "lz_common.h"
+
+#define DEFH_NSYM     286
+#define DEFH_HDR      292u          // bytes before the packed words
+#define DEFH_THREADS  512
+#define DEFH_PER      4             // tokens per thread per round
+#define DEFH_MAXBITS  44u           // code <= 24 (65536 tokens: Fibonacci bound) + 15 offset bits + 5 length bits
+#define DEFH_LUT_BITS 11
+
+struct DefhHeap {
+    uint32_t freq[2 * DEFH_NSYM];
+    int16_t  parent[2 * DEFH_NSYM];
+    int16_t  heap[DEFH_NSYM];
+    int16_t  leaf_of[DEFH_NSYM];
+    int      nheap, nnodes, root;
+};
+
+__device__ inline void dh_up(DefhHeap &h, int i)
+{
+    while (i > 0) {
+        const int par = (i - 1) >> 1;
+        if (!(h.freq[h.heap[i]] < h.freq[h.heap[par]])) break;
+        const int16_t t = h.heap[i]; h.heap[i] = h.heap[par]; h.heap[par] = t;
+        i = par;
+    }
+}
+__device__ inline void dh_down(DefhHeap &h, int i)
+{
+    for (;;) {
+        const int l = 2 * i + 1, r = l + 1;
+        int best = i;
+        if (l < h.nheap && h.freq[h.heap[l]] < h.freq[h.heap[best]]) best = l;
+        if (r < h.nheap && h.freq[h.heap[r]] < h.freq[h.heap[best]]) best = r;
+        if (best == i) return;
+        const int16_t t = h.heap[i]; h.heap[i] = h.heap[best]; h.heap[best] = t;
+        i = best;
+    }
+}
+__device__ inline int dh_pop(DefhHeap &h)
+{
+    const int id = h.heap[0];
+    h.heap[0] = h.heap[--h.nheap];
+    dh_down(h, 0);
+    return id;
+}
+
+__device__ __forceinline__ uint32_t clz16(uint32_t d) { return (uint32_t)__builtin_clz(d & 0xFFFFu) - 16u; }   // d in 1..65535
+
+// canonical codes from lengths: code[s] = first code of its length + rank among equal lengths (symbol order)
+__device__ __forceinline__ void defh_canonical(const uint8_t *s_len, uint32_t *s_code, uint32_t *s_count /*[34]*/, uint32_t *s_next /*[34]*/)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < 34; i += nt) s_count[i] = 0;
+    __syncthreads();
+    for (int s = tid; s < DEFH_NSYM; s += nt) if (s_len[s]) atomicAdd(&s_count[s_len[s] > 33 ? 33 : s_len[s]], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t c = 0;
+        s_next[0] = 0;
+        for (int l = 1; l <= 32; ++l) { c = (c + s_count[l - 1]) << 1; s_next[l] = c; }
+        s_next[33] = 0;
+    }
+    __syncthreads();
+    for (int s = tid; s < DEFH_NSYM; s += nt) {
+        const uint32_t l = s_len[s];
+        uint32_t rank = 0;
+        for (int k = 0; k < s; ++k) rank += (s_len[k] == l);
+        s_code[s] = (l && l <= 32) ? s_next[l] + rank : 0u;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(DEFH_THREADS)
+void k_defh_encode(const uint32_t *__restrict__ trec_all, uint32_t *__restrict__ slots, uint64_t *__restrict__ block_bits)
+{
+    __shared__ DefhHeap h;
+    __shared__ uint32_t s_hist[DEFH_NSYM + 2], s_code[DEFH_NSYM + 2];
+    __shared__ uint8_t  s_len[DEFH_NSYM + 2];
+    __shared__ uint32_t s_count[34], s_next[34];
+    __shared__ uint32_t s_scan[DEFH_THREADS / 64 + 2];
+    __shared__ uint32_t s_stage[DEFH_THREADS * DEFH_PER * DEFH_MAXBITS / 32 + 8];
+
+    const int tid = threadIdx.x;
+    const uint32_t lb = blockIdx.x;
+    const uint32_t ntok = (uint32_t)block_bits[lb];                   // k_lz_parse_emit (mode H) left the token count here
+    const uint32_t *trec = trec_all + (size_t)lb * LZ_MAX_BLOCK;
+    uint32_t *out = slots + (size_t)lb * LZ_SLOT_WORDS;
+    auto symbol_of = [](uint32_t r) -> uint32_t { return (r >> 31) ? 256u + clz16(r) : (r & 0xFFu); };
+
+    // ---- tally (lz77.c:206,231,273)
+    for (int i = tid; i < DEFH_NSYM + 2; i += DEFH_THREADS) { s_hist[i] = 0; s_len[i] = 0; }
+    __syncthreads();
+    for (uint32_t t = tid; t < ntok; t += DEFH_THREADS) atomicAdd(&s_hist[symbol_of(trec[t])], 1u);
+    __syncthreads();
+
+    // ---- code lengths: the reference heap, leaves enqueued in symbol order (one lane; <= 285 merges)
+    if (tid == 0) {
+        h.nheap = 0; h.nnodes = 0; h.root = -1;
+        for (int s = 0; s < DEFH_NSYM; ++s) {
+            h.leaf_of[s] = -1;
+            const uint32_t f = s_hist[s];
+            if (!f) continue;
+            const int id = h.nnodes++;
+            h.freq[id] = f; h.parent[id] = -1; h.leaf_of[s] = (int16_t)id;
+            h.heap[h.nheap++] = (int16_t)id;
+            dh_up(h, h.nheap - 1);
+        }
+        if (h.nnodes > 1) {
+            while (h.nheap > 1) {
+                const int l = dh_pop(h), r = dh_pop(h), id = h.nnodes++;
+                h.freq[id] = h.freq[l] + h.freq[r]; h.parent[id] = -1;
+                h.parent[l] = (int16_t)id; h.parent[r] = (int16_t)id;
+                h.heap[h.nheap++] = (int16_t)id;
+                dh_up(h, h.nheap - 1);
+            }
+            h.root = dh_pop(h);
+        }
+    }
+    __syncthreads();
+    if (tid < DEFH_NSYM && s_hist[tid]) {
+        uint32_t len = 0;
+        if (h.nnodes == 1) len = 1;
+        else for (int node = h.leaf_of[tid]; node != h.root; node = h.parent[node]) ++len;
+        s_len[tid] = (uint8_t)len;
+    }
+    __syncthreads();
+    defh_canonical(s_len, s_code, s_count, s_next);
+
+    // ---- header
+    if (tid == 0) out[0] = ntok;
+    for (int i = tid; i < (DEFH_NSYM + 2) / 4; i += DEFH_THREADS) out[1 + i] = reinterpret_cast<const uint32_t *>(s_len)[i];
+    uint32_t *words = out + DEFH_HDR / 4;
+
+    // ---- pack, DEFH_THREADS * DEFH_PER tokens per round; a thread owns DEFH_PER consecutive tokens
+    uint64_t qbase = 0;
+    uint32_t carry = 0;
+    for (uint32_t t0 = 0; t0 < ntok; t0 += DEFH_THREADS * DEFH_PER) {
+        const uint32_t t = t0 + (uint32_t)tid * DEFH_PER;
+        const uint4 rv = *reinterpret_cast<const uint4 *>(trec + t);       // the token array is 65536 words: in bounds
+        const uint32_t r[4] = {rv.x, rv.y, rv.z, rv.w};
+        uint32_t c_v[4], c_k[4], x_v[4], x_k[4], mine = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            c_k[k] = 0; x_k[k] = 0; c_v[k] = 0; x_v[k] = 0;
+            if (t + k < ntok) {
+                const uint32_t sym = symbol_of(r[k]);
+                c_v[k] = s_code[sym]; c_k[k] = s_len[sym];
+                if (r[k] >> 31) {
+                    const uint32_t d = r[k] & 0xFFFFu, nx = 15u - clz16(d);
+                    x_v[k] = ((d - (1u << nx)) << 5) | ((r[k] >> 16) & 31u);
+                    x_k[k] = nx + 5u;
+                }
+                mine += c_k[k] + x_k[k];
+            }
+        }
+        uint32_t total;
+        uint32_t rel = block_exclusive_scan<uint32_t>(mine, OpAddU32(), 0u, s_scan, &total);
+        const uint64_t w0 = qbase >> 5;
+        const uint32_t sh0 = (uint32_t)(qbase & 31u);
+        const uint32_t nwords = (sh0 + total + 31u) >> 5;
+        for (uint32_t i = tid; i < nwords + 1; i += DEFH_THREADS) s_stage[i] = (i == 0) ? carry : 0u;
+        __syncthreads();
+        rel += sh0;
+        auto put = [&](uint32_t v, uint32_t k) {                        // MSB first: k <= 32 bits at stage bit `rel`
+            if (!k) return;
+            const uint32_t wi = rel >> 5, sh = rel & 31u;
+            const uint64_t x = (uint64_t)v << (64u - k - sh);
+            atomicOr(&s_stage[wi], (uint32_t)(x >> 32));
+            if ((uint32_t)x) atomicOr(&s_stage[wi + 1], (uint32_t)x);
+            rel += k;
+        };
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { put(c_v[k], c_k[k]); put(x_v[k], x_k[k]); }
+        __syncthreads();
+        const uint32_t ncomplete = (sh0 + total) >> 5;
+        for (uint32_t i = tid; i < ncomplete; i += DEFH_THREADS) words[w0 + i] = s_stage[i];
+        carry = s_stage[ncomplete];
+        qbase += total;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (qbase & 31u) words[qbase >> 5] = carry;
+        block_bits[lb] = ((uint64_t)DEFH_HDR + ((qbase + 31) >> 5) * 4) * 8;
+    }
+}
+
+void defh_launch_encode(const uint32_t *trec, uint32_t *slots, uint64_t *block_bits, uint32_t nb, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_defh_encode, dim3(nb), dim3(DEFH_THREADS), 0, s, trec, slots, block_bits);
+}
+
+// ---------------------------------------------------------------------------------------------
+// decode: one wave per block.  Every lane reads the same bits (uniform control flow); the LZ copy of a
+// match is spread over the lanes, the output block is staged in LDS like k_lz_decode.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64)
+void k_defh_decode(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ block_bits, LzP P,
+                   uint8_t *__restrict__ out, uint64_t n_total, uint32_t *__restrict__ err)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[LZ_MAX_BLOCK + 256];
+    __shared__ uint16_t s_lut[1 << DEFH_LUT_BITS];                     // symbol | length << 9; 0xFFFF = longer than the table
+    __shared__ uint8_t  s_len[DEFH_NSYM + 2];
+    __shared__ uint32_t s_code[DEFH_NSYM + 2], s_count[34], s_next[34];
+    __shared__ uint16_t s_sorted[DEFH_NSYM];                           // symbols by (length, symbol)
+    __shared__ uint32_t s_first[34];                                   // index into s_sorted of the first symbol of a length
+    const uint32_t lane = threadIdx.x;
+    const uint64_t b = blockIdx.x;
+    const uint64_t off = b * (uint64_t)P.block;
+    const uint32_t n = (uint32_t)((n_total - off) < P.block ? (n_total - off) : P.block);
+    const uint64_t rb = block_bits[b], re = block_bits[b + 1];
+    bool bad = (rb & 31u) || re < rb + DEFH_HDR * 8ull;
+    if (bad) { if (lane == 0) atomicOr(err, 1u); return; }
+    const uint32_t *rec = reinterpret_cast<const uint32_t *>(stream + (rb >> 3));
+    const uint32_t ntok = rec[0];
+    const uint32_t nwords = (uint32_t)(((re - rb) >> 5) - DEFH_HDR / 4);
+    const uint32_t *w = rec + DEFH_HDR / 4;
+    for (uint32_t i = lane; i < (DEFH_NSYM + 2) / 4; i += 64) reinterpret_cast<uint32_t *>(s_len)[i] = rec[1 + i];
+    __syncthreads();
+    defh_canonical(s_len, s_code, s_count, s_next);
+    // tables: first-code / sorted symbols for the general walk, a direct LUT for codes <= DEFH_LUT_BITS
+    for (uint32_t i = lane; i < (1u << DEFH_LUT_BITS); i += 64) s_lut[i] = 0xFFFFu;
+    if (lane == 0) { uint32_t run = 0; for (int l = 0; l < 34; ++l) { s_first[l] = run; run += (l >= 1 && l <= 32) ? s_count[l] : 0u; } }
+    __syncthreads();
+    for (uint32_t s = lane; s < DEFH_NSYM; s += 64) {
+        const uint32_t l = s_len[s];
+        if (l > 32) bad = true;
+        if (l && l <= 32) {
+            const uint32_t c = s_code[s];
+            s_sorted[s_first[l] + (c - s_next[l])] = (uint16_t)s;
+            if (l <= DEFH_LUT_BITS) {
+                const uint32_t lo = c << (DEFH_LUT_BITS - l);
+                if (lo + (1u << (DEFH_LUT_BITS - l)) > (1u << DEFH_LUT_BITS)) bad = true;       // over-subscribed lengths
+                else for (uint32_t k = 0; k < (1u << (DEFH_LUT_BITS - l)); ++k) s_lut[lo + k] = (uint16_t)(s | (l << 9));
+            }
+        }
+    }
+    if (__ballot(bad) != 0ull) { if (lane == 0) atomicOr(err, 1u); return; }
+    __syncthreads();
+
+    const uint64_t nbits = (uint64_t)nwords * 32u;
+    uint64_t pos = 0;
+    uint32_t o = 0;
+    auto peek32 = [&](uint64_t q) -> uint32_t {                        // 32 stream bits from bit q, MSB first; zero past the end
+        const uint64_t wi = q >> 5; const uint32_t sh = (uint32_t)(q & 31u);
+        const uint32_t a = wi < nwords ? w[wi] : 0u, c = wi + 1 < nwords ? w[wi + 1] : 0u;
+        return sh ? (a << sh) | (c >> (32u - sh)) : a;
+    };
+    for (uint32_t t = 0; t < ntok && o < n; ++t) {
+        const uint32_t v = peek32(pos);
+        uint32_t sym, l;
+        const uint32_t e = s_lut[v >> (32 - DEFH_LUT_BITS)];
+        if (e != 0xFFFFu) { sym = e & 511u; l = e >> 9; }
+        else {
+            sym = DEFH_NSYM; l = DEFH_LUT_BITS + 1;
+            for (; l <= 32; ++l) {
+                const uint32_t c = v >> (32u - l), rel = c - s_next[l];
+                if (c >= s_next[l] && rel < s_count[l]) { sym = s_sorted[s_first[l] + rel]; break; }
+            }
+            if (sym == DEFH_NSYM) { bad = true; break; }
+        }
+        pos += l;
+        if (sym < 256u) {
+            if (lane == 0) s_out[o] = (uint8_t)sym;
+            o += 1;
+        } else {
+            const uint32_t cz = sym - 256u;
+            if (cz < 1u || cz > 15u) { bad = true; break; }
+            const uint32_t nx = 15u - cz, x = peek32(pos);
+            const uint32_t d = (1u << nx) + (nx ? x >> (32u - nx) : 0u);
+            const uint32_t len = (x << nx) >> 27;
+            pos += nx + 5u;
+            if (d > o) { bad = true; break; }
+            const uint32_t take = (o + len <= n) ? len : n - o;
+            for (uint32_t j = lane; j < take; j += 64) s_out[o + j] = s_out[o - d + (j % d)];
+            o += take;
+        }
+        if (pos > nbits) { bad = true; break; }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (o != n) bad = true;
+    if (bad && lane == 0) atomicOr(err, 1u);
+    __syncthreads();
+    for (uint32_t i = lane; i < n; i += 64) out[off + i] = s_out[i];
+}
+
+mi_status lz_check_params(const mi_lz_params *p);
+
+extern "C" uint64_t mi_deflate_h_bound_bytes(uint64_t n)
+{
+    // a block's Huffman code cannot be longer than a fixed 9-bit code over 286 symbols; tokens <= 65536 - 3 * matches,
+    // a match adds <= 19 extra bits: 9 * tokens + 19 * matches <= 9 * 65536 bits.  Plus header and the last partial word.
+    const uint64_t nblocks = (n + LZ_MAX_BLOCK - 1) / LZ_MAX_BLOCK;
+    return nblocks * (DEFH_HDR + (uint64_t)LZ_MAX_BLOCK * 9 / 8 + 8) + 64;
+}
+
+extern "C" mi_status mi_deflate_h_decode_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_stream,
+                                             const uint64_t *d_block_bits, uint8_t *d_out, uint64_t n, void *stream)
+{
+    if (!ctx || !d_stream || !d_block_bits || (n && !d_out)) return MI_ERR_ARG;
+    mi_status st = lz_check_params(p);
+    if (st) return st;
+    if (!p->deflate || p->lbits > 5 || p->wbits > 16 || ((uintptr_t)d_stream & 3u)) return MI_ERR_ARG;
+    if (n == 0) return MI_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block};
+    const uint64_t nblocks = (n + P.block - 1) / P.block;
+    st = mi_ws_reserve(ctx, 4096);
+    if (st) return st;
+    uint32_t *err = reinterpret_cast<uint32_t *>(ctx->ws);
+    MI_HIP(ctx, hipMemsetAsync(err, 0, 4, s));
+    {
+        mi_prof_scope pr(ctx, "k_defh_decode", s, n);
+        hipLaunchKernelGGL(k_defh_decode, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, d_block_bits, P, d_out, n, err);
+    }
+    uint32_t h_err = 0;
+    MI_HIP(ctx, hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, s));
+    MI_HIP(ctx, hipStreamSynchronize(s));
+    return h_err ? MI_ERR_CORRUPT : MI_OK;
+}

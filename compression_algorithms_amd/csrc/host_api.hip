@@ -75,6 +75,44 @@ extern "C" mi_status mi_lz_decode(mi_ctx *ctx, const mi_lz_params *p, const uint
     return MI_OK;
 }
 
+extern "C" mi_status mi_deflate_h_encode(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *h_in, uint64_t n,
+                                         uint8_t *h_out, uint64_t cap_bytes, uint64_t *h_block_bits)
+{
+    if (!ctx || !p || !h_out || !h_block_bits || (n && !h_in) || !p->block) return MI_ERR_ARG;
+    hipStream_t s = ctx->stream;
+    const uint64_t nblocks = (n + p->block - 1) / p->block, bound = mi_deflate_h_bound_bytes(n);
+    DevBuf in, out, bits;
+    if (!in.alloc(n + 64) || !out.alloc(bound + 64) || !bits.alloc((nblocks + 1) * 8)) return MI_ERR_NOMEM;
+    if (n) MI_HIP(ctx, hipMemcpyAsync(in.p, h_in, n, hipMemcpyHostToDevice, s));
+    mi_status st = mi_deflate_h_encode_dev(ctx, p, in.as<uint8_t>(), n, out.as<uint8_t>(), bound + 64, bits.as<uint64_t>(), s);
+    if (st) return st;
+    MI_HIP(ctx, hipMemcpyAsync(h_block_bits, bits.p, (nblocks + 1) * 8, hipMemcpyDeviceToHost, s));
+    MI_HIP(ctx, hipStreamSynchronize(s));
+    const uint64_t bytes = h_block_bits[nblocks] / 8;
+    if (bytes > cap_bytes) return MI_ERR_CAPACITY;
+    if (bytes) MI_HIP(ctx, hipMemcpy(h_out, out.p, bytes, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+extern "C" mi_status mi_deflate_h_decode(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *h_stream, uint64_t stream_bytes,
+                                         const uint64_t *h_block_bits, uint8_t *h_out, uint64_t n)
+{
+    if (!ctx || !p || !h_stream || !h_block_bits || (n && !h_out) || !p->block) return MI_ERR_ARG;
+    if (n == 0) return MI_OK;
+    hipStream_t s = ctx->stream;
+    const uint64_t nblocks = (n + p->block - 1) / p->block;
+    if (h_block_bits[nblocks] / 8 > stream_bytes) return MI_ERR_CORRUPT;
+    DevBuf st_, bits, out;
+    if (!st_.alloc(stream_bytes + 64) || !bits.alloc((nblocks + 1) * 8) || !out.alloc(n + 16)) return MI_ERR_NOMEM;
+    MI_HIP(ctx, hipMemsetAsync(st_.as<uint8_t>() + stream_bytes, 0, 64, s));
+    MI_HIP(ctx, hipMemcpyAsync(st_.p, h_stream, stream_bytes, hipMemcpyHostToDevice, s));
+    MI_HIP(ctx, hipMemcpyAsync(bits.p, h_block_bits, (nblocks + 1) * 8, hipMemcpyHostToDevice, s));
+    mi_status st = mi_deflate_h_decode_dev(ctx, p, st_.as<uint8_t>(), bits.as<uint64_t>(), out.as<uint8_t>(), n, s);
+    if (st) return st;
+    MI_HIP(ctx, hipMemcpy(h_out, out.p, n, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
 extern "C" mi_status mi_fse_encode(mi_ctx *ctx, const mi_fse_params *p, const uint8_t *h_in, uint64_t n, uint8_t *h_packed,
                                    uint64_t cap_bytes, uint64_t *h_offsets)
 {

@@ -24,7 +24,7 @@ __device__ __forceinline__ uint32_t select_bit(uint64_t m, uint32_t r)   // inde
 
 __global__ __launch_bounds__(1024)
 void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, LzScratch sc, Lz2Scratch s2, int use_v2,
-                     uint64_t block0)
+                     uint64_t block0, uint32_t *__restrict__ trec_all)
 {
     // region0: input bytes -> exit tables [64][1024] -> {token base, match base, staging window}
     __shared__ __attribute__((aligned(16))) uint8_t s_r0[LZ_MAX_BLOCK + LZ_TAIL + 16];
@@ -202,6 +202,25 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     const uint32_t LB = P.deflate ? 16u : 9u, MB = P.deflate ? 32u : (1u + P.wbits + P.lbits);
     uint32_t *slot = sc.slot + (size_t)lb * LZ_SLOT_WORDS;
     uint32_t carry = 0;
+    if (trec_all) {
+        // mode H (defh.hip): no packed tokens; one 32-bit record per token, in token order, for the entropy stage:
+        //   literal  byte                       match  1<<31 | length << 16 | distance
+        uint32_t *trec = trec_all + (size_t)lb * LZ_MAX_BLOCK;
+        for (uint32_t t = tid; t < ntok; t += 1024u) {
+            uint32_t lo = 0, hi = 1023;
+            while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (tb[mid] <= t) lo = mid; else hi = mid - 1; }
+            const uint32_t c = lo, o = select_bit(s_tok[c], t - tb[c]), p = c * 64u + o;
+            uint32_t rec;
+            if ((s_mat[c] >> o) & 1ull) {
+                const uint32_t mbefore = mb[c] + (uint32_t)__popcll(s_mat[c] & ((1ull << o) - 1ull));
+                const uint32_t d = lists ? (uint32_t)md[mbefore] : p - cand[p];
+                rec = 0x80000000u | ((uint32_t)s_L[p] << 16) | d;
+            } else rec = src[p];
+            trec[t] = rec;
+        }
+        if (tid == 0) sc.block_bits[lb] = ntok;
+        return;
+    }
     for (uint32_t t0 = 0; t0 < ntok; t0 += 2048u) {
         uint64_t q[2] = {0, 0}; uint32_t v[2] = {0, 0}, nbits[2] = {0, 0};
         bool valid[2];
@@ -397,14 +416,20 @@ mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t
                         const LzScratch &sc, hipStream_t s);
 uint32_t lz_batch_blocks(uint64_t nblocks);
 
-extern "C" mi_status mi_lz_encode_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_in, uint64_t n,
-                                      uint8_t *d_out, uint64_t cap_bytes, uint64_t *d_block_bits, void *stream)
+void defh_launch_encode(const uint32_t *trec, uint32_t *slots, uint64_t *block_bits, uint32_t nb, hipStream_t s);
+extern "C" uint64_t mi_deflate_h_bound_bytes(uint64_t n);
+
+// mode_h = 0: the reference's token stream.  mode_h = 1: the same tokens, entropy coded per block (defh.hip); the
+// per-block records are word aligned, so the same scan / concatenate kernels place them.
+static mi_status lz_encode_impl(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_in, uint64_t n,
+                                uint8_t *d_out, uint64_t cap_bytes, uint64_t *d_block_bits, void *stream, int mode_h)
 {
     if (!ctx || !d_out || !d_block_bits || (n && !d_in)) return MI_ERR_ARG;
     mi_status st = lz_check_params(p);
     if (st) return st;
     if (((uintptr_t)d_out & 3u) != 0) return MI_ERR_ARG;
-    if (cap_bytes < mi_lz_bound_bytes(n, p)) return MI_ERR_CAPACITY;
+    if (mode_h && (!p->deflate || p->lbits > 5 || p->wbits > 16)) return MI_ERR_ARG;
+    if (cap_bytes < (mode_h ? mi_deflate_h_bound_bytes(n) : mi_lz_bound_bytes(n, p))) return MI_ERR_CAPACITY;
     hipStream_t s = (hipStream_t)stream;
     const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block};
     const uint64_t nblocks = (n + P.block - 1) / P.block;
@@ -417,11 +442,13 @@ extern "C" mi_status mi_lz_encode_dev(mi_ctx *ctx, const mi_lz_params *p, const 
     const bool overlap = nblocks > nbmax && !getenv("MI_LZ_NO_OVERLAP");
     const int nsets = overlap ? MI_SETS : 1;
     const size_t set_bytes = mi_align_up(lz_scratch_bytes(nbmax), 4096);
-    st = mi_ws_reserve(ctx, set_bytes * nsets + 8192);
+    const size_t trec_bytes = mode_h ? (size_t)nbmax * LZ_MAX_BLOCK * 4 : 0;       // token records, one array per set
+    st = mi_ws_reserve(ctx, set_bytes * nsets + 8192 + trec_bytes * nsets);
     if (st) return st;
     LzScratch sc[MI_SETS]; Lz2Scratch sc2[MI_SETS];
     for (int k = 0; k < nsets; ++k) lz_carve(ctx, nbmax, &sc[k], &sc2[k], k);
     uint64_t *base_bits = reinterpret_cast<uint64_t *>((uint8_t *)ctx->ws + set_bytes * nsets);
+    uint32_t *trec_base = reinterpret_cast<uint32_t *>((uint8_t *)ctx->ws + set_bytes * nsets + 8192);
     MI_HIP(ctx, hipMemsetAsync(base_bits, 0, 8, s));
     if (nblocks == 0) { MI_HIP(ctx, hipMemsetAsync(d_block_bits, 0, 8, s)); return MI_OK; }
     hipStream_t sb = overlap ? ctx->side : s, sp = overlap ? ctx->parse : s;
@@ -441,9 +468,14 @@ extern "C" mi_status mi_lz_encode_dev(mi_ctx *ctx, const mi_lz_params *p, const 
             if (lz_use_v2()) MI_HIP(ctx, hipStreamWaitEvent(sp, ctx->ev_fb[k], 0));      // the fallback blocks' candidates
         }
         uint64_t *excl_local = sc[k].block_bits;                   // reused in place by the scan
+        uint32_t *trec = mode_h ? trec_base + (size_t)k * nbmax * LZ_MAX_BLOCK : nullptr;
         {
             mi_prof_scope pr(ctx, "k_lz_parse_emit", sp, (uint64_t)nb * P.block);
-            hipLaunchKernelGGL(k_lz_parse_emit, dim3(nb), dim3(1024), 0, sp, d_in, n, P, sc[k], sc2[k], lz_use_v2() ? 1 : 0, b0);
+            hipLaunchKernelGGL(k_lz_parse_emit, dim3(nb), dim3(1024), 0, sp, d_in, n, P, sc[k], sc2[k], lz_use_v2() ? 1 : 0, b0, trec);
+        }
+        if (mode_h) {
+            mi_prof_scope ph(ctx, "k_defh_encode", sp, (uint64_t)nb * P.block);
+            defh_launch_encode(trec, sc[k].slot, sc[k].block_bits, nb, sp);
         }
         hipLaunchKernelGGL(k_lz_scan_blocks, dim3(1), dim3(1024), 0, sp, sc[k].block_bits, nb, base_bits, excl_local, d_block_bits + b0);
         {
@@ -461,6 +493,18 @@ extern "C" mi_status mi_lz_encode_dev(mi_ctx *ctx, const mi_lz_params *p, const 
     }
     MI_HIP(ctx, hipGetLastError());
     return MI_OK;
+}
+
+extern "C" mi_status mi_lz_encode_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_in, uint64_t n,
+                                      uint8_t *d_out, uint64_t cap_bytes, uint64_t *d_block_bits, void *stream)
+{
+    return lz_encode_impl(ctx, p, d_in, n, d_out, cap_bytes, d_block_bits, stream, 0);
+}
+
+extern "C" mi_status mi_deflate_h_encode_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_in, uint64_t n,
+                                             uint8_t *d_out, uint64_t cap_bytes, uint64_t *d_block_bits, void *stream)
+{
+    return lz_encode_impl(ctx, p, d_in, n, d_out, cap_bytes, d_block_bits, stream, 1);
 }
 
 extern "C" mi_status mi_lz_encode(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *h_in, uint64_t n,

@@ -84,3 +84,32 @@ def decompress(stream, ctx=None):
                                 C.c_void_p(stream.block_bits.data_ptr()), C.c_void_p(out.data_ptr()), stream.n, ctx.stream_ptr())
     _lib.check(st, "mi_lz_decode_dev")
     return out[: stream.n]
+
+
+# ---- mode H: the reference's deflate token sequence, entropy coded per block (include/mi_codec.h) ----------------
+def compress_h(data, p=None, ctx=None):
+    """Deflate tokens (algorithms/deflate/lz77.c:199-280) + per-block dynamic Huffman over the 286-symbol
+    alphabet the reference sketches (deflate/huffman.c:49-62).  Returns an LzStream whose `data` holds the
+    concatenated block records and whose block_bits are record offsets in bits."""
+    ctx = ctx or default_context()
+    p = p or params("deflate")
+    d_in = as_device_bytes(data, ctx.device)
+    n = d_in.numel()
+    nblocks = (n + p.block - 1) // p.block
+    cap = int(ctx.L.mi_deflate_h_bound_bytes(n)) + 64
+    out = torch.empty(cap, dtype=torch.uint8, device=ctx.device)
+    bits = torch.zeros(nblocks + 1, dtype=torch.int64, device=ctx.device)
+    st = ctx.L.mi_deflate_h_encode_dev(ctx.h, C.byref(p), C.c_void_p(d_in.data_ptr() if n else 0), n, C.c_void_p(out.data_ptr()),
+                                       cap, C.c_void_p(bits.data_ptr()), ctx.stream_ptr())
+    _lib.check(st, "mi_deflate_h_encode_dev")
+    return LzStream(out, bits, n, p)
+
+
+def decompress_h(stream, ctx=None):
+    ctx = ctx or default_context()
+    out = torch.empty(max(stream.n, 1), dtype=torch.uint8, device=ctx.device)
+    st = ctx.L.mi_deflate_h_decode_dev(ctx.h, C.byref(stream.p), C.c_void_p(stream.data.data_ptr()),
+                                       C.c_void_p(stream.block_bits.data_ptr()), C.c_void_p(out.data_ptr()), stream.n,
+                                       ctx.stream_ptr())
+    _lib.check(st, "mi_deflate_h_decode_dev")
+    return out[: stream.n]

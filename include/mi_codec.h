@@ -165,6 +165,32 @@ mi_status mi_lz_find_all_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *
                              uint16_t *d_cand, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Deflate "mode H": the entropy stage algorithms/deflate/lz77.c:279 leaves as a TODO
+ * ("Build huffman tree and encode compressed buffer").  The token sequence is the
+ * reference's (same finder and parse as mi_lz_encode_dev with deflate = 1); each block's
+ * tokens are then coded with a dynamic Huffman code over the reference's 286-symbol
+ * alphabet (deflate/huffman.h:6, huffman.c:49-62), lengths from the reference's heap
+ * procedure (algorithms/huffman/huffman.c:100-163), canonical code assignment, MSB-first
+ * u32 packing (deflate/huffman.c:16-46).  The reference has no such encoder: the bit
+ * stream is defined by this build (oracle/orc_defh.c restates it).
+ *
+ * Block record (4-byte aligned): u32 n_tokens | u8 len[286] + 2 pad | u32 words[]
+ *   literal b -> code[b];  match (d, l) -> code[256 + clz16(d)], the 15 - clz16(d) offset
+ *   bits below d's leading one, the 5-bit length.
+ * d_block_bits u64[nblocks+1]: exclusive prefix of record lengths in BITS (multiples of 32).
+ * p must be a deflate-flavour parameter set with lbits <= 5 and wbits <= 16.
+ * ------------------------------------------------------------------------------------ */
+uint64_t  mi_deflate_h_bound_bytes(uint64_t n);
+mi_status mi_deflate_h_encode_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_in, uint64_t n,
+                                  uint8_t *d_out, uint64_t cap_bytes, uint64_t *d_block_bits, void *stream);
+mi_status mi_deflate_h_decode_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_stream,
+                                  const uint64_t *d_block_bits, uint8_t *d_out, uint64_t n, void *stream);
+mi_status mi_deflate_h_encode(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *h_in, uint64_t n,
+                              uint8_t *h_out, uint64_t cap_bytes, uint64_t *h_block_bits);
+mi_status mi_deflate_h_decode(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *h_stream, uint64_t stream_bytes,
+                              const uint64_t *h_block_bits, uint8_t *h_out, uint64_t n);
+
+/* ------------------------------------------------------------------------------------
  * FSE / tANS, block-parallel (fse/src/main.zig — an unfinished sketch; the stream format is
  * defined by this build).  Record layout in include/mi_fse.h.
  * ------------------------------------------------------------------------------------ */
