@@ -23,7 +23,9 @@ __host__ __device__ __forceinline__ uint32_t lz2_class_of(uint32_t cnt, uint32_t
     if (cnt >= wave_min) return cnt <= LZ2_BIG_SMALL ? 5u : 6u;
     return cnt < 16 ? 7u : cnt < 32 ? 0u : cnt < 64 ? 1u : cnt < 128 ? 2u : cnt < 256 ? 3u : 4u;
 }
-#define LZ2_PENDING16 0xFFFEu               // cand placeholder of an entry whose cluster went to the wave replay
+// cand placeholder of an entry whose cluster was exported: the entry's OWN position (a candidate is always smaller
+// than its position, so no real result collides).  Position 0xFFFF pending == LZ_NONE16: consumers preset that one
+// position to "none" and let the exported list overwrite it.
 
 struct Lz2BlockMeta {
     uint32_t n, nparts, base, fallback;
@@ -45,7 +47,7 @@ struct Lz2BigDesc {
 
 struct Lz2Scratch {
     uint16_t     *plist;        // [nb][65536] positions, grouped by part, time order inside a part
-    uint16_t     *cand;         // [nb][65536] find() result aligned with plist (LZ2_PENDING16: see bigcand)
+    uint16_t     *cand;         // [nb][65536] find() result aligned with plist (own position = pending: see bigcand)
     Lz2BlockMeta *meta;         // [nb]
     uint32_t     *fallback_count, *fallback_list;    // blocks the first pipeline has to do
     uint16_t     *bigpos, *bigrs, *bigpid, *bigcand; // [nb][65536] entries of exported clusters, (cluster, time) order

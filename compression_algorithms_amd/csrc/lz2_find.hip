@@ -29,6 +29,7 @@ __device__ void replay_small(const uint16_t *pos, uint16_t *rs, const uint16_t *
 {
     uint32_t ev = s;
     bool anom_pending = anom != ~0u;
+    const bool plain = (anom == ~0u) && (limit == ~0u);                 // not the cluster that covers bucket 0 / T
     for (uint32_t i = s; i < e; ++i) {
         const uint32_t p = pos[i], rsv = rs[i], r = rsv & RS_MASK, id = pid[i];
         while (ev < i && (uint32_t)pos[ev] + W < p) {                   // FIFO retirement, lz77.c:70-76
@@ -42,7 +43,9 @@ __device__ void replay_small(const uint16_t *pos, uint16_t *rs, const uint16_t *
         const uint32_t w0 = bm[wi];
         const uint32_t o0 = occ[r];
         uint32_t res = LZ_NONE16;
-        if ((w0 >> (r & 31u)) & 1u) {
+        if (plain && ev == s) {                                         // nothing evicted yet: the first occurrence (see the sweep)
+            if (id != p) res = id;
+        } else if ((w0 >> (r & 31u)) & 1u) {
             const uint32_t id0 = pid[o0], pos0 = pos[o0];
             if (id0 == id) res = pos0;
             else {
@@ -208,7 +211,10 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
             prev_h = h;
             s_g[j] = (uint16_t)cur_gid;
             s_r[j] = (uint16_t)(cur_gs + (uint32_t)(h - cur_base));
-            s_pid[j] = (uint16_t)id;
+            // the word's identity is the POSITION of its first occurrence in the block (the home order is stable in
+            // time).  While nothing of a cluster has been evicted that position is also what find() returns: the first
+            // copy sits at the lowest slot of the word and every slot between the home and it stays occupied.
+            s_pid[j] = s_pos[id];
         }
     }
     __syncthreads();
@@ -236,10 +242,12 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
 
     LZ2_TICK(2);
     // ---- sort time indices by cluster number (they start in time order): identity -> j0 -> j1
-    radix_pass<LZ2_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return i; },
-        [&](uint32_t e) { return (uint32_t)s_g[e] & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; });
-    radix_pass<LZ2_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return (uint32_t)s_j0[i]; },
-        [&](uint32_t e) { return (uint32_t)s_g[e] >> 8; }, [&](uint32_t d, uint32_t e) { s_j1[d] = (uint16_t)e; });
+    //      (cluster numbers are < LZ2_CAP <= 4096: two 6-bit passes, fewer ballots and a shorter offset scan than 8 + 8)
+    static_assert(LZ2_CAP <= 4096, "cluster numbers must fit 12 bits");
+    radix_pass<LZ2_NWAVES, 6, uint32_t>(m, s_cnt, [&](uint32_t i) { return i; },
+        [&](uint32_t e) { return (uint32_t)s_g[e] & 63u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; });
+    radix_pass<LZ2_NWAVES, 6, uint32_t>(m, s_cnt, [&](uint32_t i) { return (uint32_t)s_j0[i]; },
+        [&](uint32_t e) { return (uint32_t)s_g[e] >> 6; }, [&](uint32_t d, uint32_t e) { s_j1[d] = (uint16_t)e; });
 
     LZ2_TICK(3);
     // ---- permute into replay order (cluster, time).  e_pos / e_rs overlay the dead word array.
@@ -280,8 +288,9 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     //      64 lanes of a wave run the same number of steps.  Larger clusters are exported by size class.
     {
         // cluster heads -> compact list (order irrelevant), sizes from the next head
-        __shared__ uint32_t s_ncl, s_bin[LZ2_BIG + 1];
-        if (tid == 0) s_ncl = 0;
+        __shared__ uint32_t s_ncl, s_bin[LZ2_BIG + 1], s_nquiet;
+        __shared__ uint16_t s_quiet[2 * (LZ2_CAP / 64)];     // quiet clusters of >= 64 entries: filled by a wave each, below
+        if (tid == 0) { s_ncl = 0; s_nquiet = 0; }
         if (tid <= (int)LZ2_BIG) s_bin[tid] = 0;
         __syncthreads();
         uint16_t *c_start = s_j1 + 0;                        // (s_j1 is still needed: cand back to time order) -> use s_pos, dead now
@@ -294,8 +303,15 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
                 const uint32_t e = s_gstart[(regs[c][2] >> 16) + 1];      // clusters are contiguous and in cluster-number order
                 const uint32_t size = e - i;
                 my_n[c] = size;
+                // a cluster whose entries all lie within one window never evicts: no replay, find() = first occurrence
+                const bool quiet = (uint32_t)e_pos[e - 1] <= (uint32_t)e_pos[i] + W && i != s_zhead;
                 if (size == 1) cand_i[i] = LZ_NONE16;
+                else if (quiet && size < 64u) {
+                    for (uint32_t k = i; k < e; ++k) { const uint32_t id = e_pid[k]; cand_i[k] = (id != e_pos[k]) ? (uint16_t)id : (uint16_t)LZ_NONE16; }
+                    my_n[c] = 0;
+                }
                 else if (size < LZ2_BIG) atomicAdd(&s_bin[size], 1u);
+                else if (quiet) { const uint32_t q = atomicAdd(&s_nquiet, 1u); s_quiet[2 * q] = (uint16_t)i; s_quiet[2 * q + 1] = (uint16_t)e; }
                 else {
                     const uint32_t q = atomicAdd(&s_nbigl, 1u);
                     if (q < LZ2_MAXBIG) { s_big[3 * q] = i; s_big[3 * q + 1] = e; }
@@ -312,6 +328,11 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
         for (uint32_t c = 0; c < CH; ++c)
             if (my_n[c] >= 2 && my_n[c] < LZ2_BIG) c_start[atomicAdd(&s_bin[my_n[c]], 1u)] = (uint16_t)my_s[c];
         __syncthreads();
+        for (uint32_t q = tid >> 6; q < s_nquiet; q += LZ2_NWAVES)
+            for (uint32_t k = (uint32_t)s_quiet[2 * q] + (tid & 63u); k < s_quiet[2 * q + 1]; k += 64) {
+                const uint32_t id = e_pid[k];
+                cand_i[k] = (id != e_pos[k]) ? (uint16_t)id : (uint16_t)LZ_NONE16;
+            }
         const uint32_t ncl = s_ncl;
         for (uint32_t q = tid; q < ncl; q += LZ2_THREADS) {
             const uint32_t s = c_start[q];
@@ -368,7 +389,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
         uint16_t *br = sc.bigrs + (size_t)lb * LZ_MAX_BLOCK + dst;
         uint16_t *bi = sc.bigpid + (size_t)lb * LZ_MAX_BLOCK + dst;
         for (uint32_t i = s + (tid & 63); i < e; i += 64) {
-            cand_i[i] = LZ2_PENDING16;
+            cand_i[i] = e_pos[i];                                // pending (lz2.h)
             bp[i - s] = e_pos[i];
             br[i - s] = (uint16_t)((e_rs[i] & RS_MASK) - s);    // home slot relative to the cluster
             bi[i - s] = e_pid[i];
@@ -408,6 +429,12 @@ struct WaveBitmap {
         return r;
     }
     __device__ __forceinline__ bool test(uint32_t slot) const { return (word(slot >> 5) >> (slot & 31u)) & 1u; }
+    __device__ __forceinline__ void clear_bit(uint32_t slot, uint32_t lane) {      // whoever sits there, or nobody
+        const uint32_t wi = slot >> 5, wq = wi >> 6;
+        const uint32_t keep = (lane == (wi & 63u)) ? ~(1u << (slot & 31u)) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) w[q] &= ((uint32_t)q == wq) ? keep : 0xFFFFFFFFu;
+    }
     __device__ __forceinline__ void flip(uint32_t slot, uint32_t lane) {
         const uint32_t wi = slot >> 5, wq = wi >> 6;
         const uint32_t bit = (lane == (wi & 63u)) ? (1u << (slot & 31u)) : 0u;
@@ -439,7 +466,8 @@ template <int LDS_ENTRIES, int NW>
 __global__ __launch_bounds__(64)
 void k_lz2_big(LzP P, Lz2Scratch sc, int large)
 {
-    __shared__ uint16_t s_opid[LDS_ENTRIES], s_opos[LDS_ENTRIES], s_slot[LDS_ENTRIES];
+    __shared__ uint32_t s_occ[LDS_ENTRIES];               // slot -> word id | position << 16 of its occupant
+    __shared__ uint16_t s_slot[LDS_ENTRIES];              // entry -> slot (for its eviction)
     const uint32_t lane = threadIdx.x;
     const uint32_t ncl = sc.big_count[large ? 6 : 5];
     const Lz2BigDesc *list = sc.desc[large ? 6 : 5];
@@ -455,6 +483,7 @@ void k_lz2_big(LzP P, Lz2Scratch sc, int large)
         bm.clear();
         uint32_t ev = 0;
         bool anom_pending = d_anom != ~0u;
+        const bool plain = d_anom == ~0u && d_limit == ~0u;               // not the cluster that covers bucket 0 / T
         uint32_t c_pos = 0, c_rs = 0, c_pid = 0, ev_pos = 0, ev_base = ~0u, out_acc = 0;
         for (uint32_t i0 = 0; i0 < n; i0 += 64) {
             const uint32_t ii = i0 + lane;
@@ -463,37 +492,41 @@ void k_lz2_big(LzP P, Lz2Scratch sc, int large)
             for (uint32_t t = 0; t < lim; ++t) {
                 const uint32_t i = i0 + t;
                 const uint32_t p = RLANE(c_pos, t), r = RLANE(c_rs, t), id = RLANE(c_pid, t);
-                for (;;) {                                              // FIFO retirement (lz77.c:70-76)
-                    if (ev >= i) break;
-                    if ((ev & ~63u) != ev_base) { ev_base = ev & ~63u; const uint32_t q = ev_base + lane; ev_pos = q < n ? bp[q] : 0u; }
-                    const uint32_t pe = RLANE(ev_pos, ev & 63u);
-                    if (pe + W >= p) break;
-                    const uint32_t sl = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_slot[ev]);
-                    if (bm.test(sl)) bm.flip(sl, lane);                 // clears the bucket, whoever sits there
-                    ++ev;
-                }
-                if (anom_pending && p > W - 1u) { if (bm.test(d_anom)) bm.flip(d_anom, lane); anom_pending = false; }
-                // find: the occupant of the home slot is fetched before the (register) occupancy test says whether
-                // it is needed — one LDS round trip on the common path
-                const uint32_t h_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_opid[r]);
-                const uint32_t h_pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_opos[r]);
+                // This loop is bound by the CU's one scalar unit (every wave-uniform step is an SALU instruction and all
+                // resident waves share it), so the common case is kept short: positions <= W cannot evict anything.
+                if (p > W) {
+                    for (;;) {                                          // FIFO retirement (lz77.c:70-76)
+                        if (ev >= i) break;
+                        if ((ev & ~63u) != ev_base) { ev_base = ev & ~63u; const uint32_t q = ev_base + lane; ev_pos = q < n ? bp[q] : 0u; }
+                        const uint32_t pe = RLANE(ev_pos, ev & 63u);
+                        if (pe + W >= p) break;
+                        const uint32_t sl = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_slot[ev]);
+                        bm.clear_bit(sl, lane);                         // clears the bucket, whoever sits there
+                        ++ev;
+                    }
+                    if (anom_pending) { bm.clear_bit(d_anom, lane); anom_pending = false; }     // p > W - 1, SURVEY.md A.1.2
+                } else if (anom_pending && p > W - 1u) { bm.clear_bit(d_anom, lane); anom_pending = false; }
                 uint32_t res = LZ_NONE16;
-                if (bm.test(r)) {
-                    if (h_id == id) res = h_pos;
-                    else {
-                        for (uint32_t b = r + 1;; ++b) {                // rare: the home holds another word
-                            if (b == d_limit && r < d_limit) break;
-                            if (!bm.test(b)) break;
-                            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)s_opid[b]) == id) {
-                                res = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_opos[b]);
-                                break;
+                if (plain && ev == 0) {
+                    // nothing evicted yet: find() = the word's first occurrence = the word id (k_lz2_find, the sweep)
+                    if (id != p) res = id;
+                } else {
+                    const uint32_t h = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_occ[r]);
+                    if (bm.test(r)) {
+                        if ((h & 0xFFFFu) == id) res = h >> 16;
+                        else {
+                            for (uint32_t b = r + 1;; ++b) {            // rare: the home holds another word
+                                if (b == d_limit && r < d_limit) break;
+                                if (!bm.test(b)) break;
+                                const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_occ[b]);
+                                if ((o & 0xFFFFu) == id) { res = o >> 16; break; }
                             }
                         }
                     }
                 }
                 const uint32_t b = bm.first_zero_from(r, lane);         // insert: first fit
                 bm.flip(b, lane);
-                if (lane == 0) { s_opid[b] = (uint16_t)id; s_opos[b] = (uint16_t)p; s_slot[i] = (uint16_t)b; }
+                if (lane == 0) { s_occ[b] = id | (p << 16); s_slot[i] = (uint16_t)b; }
                 if (lane == t) out_acc = res;
                 __builtin_amdgcn_wave_barrier();
             }
@@ -604,8 +637,10 @@ template <int CMAX, int LANES>
 __global__ __launch_bounds__(64)
 void k_lz2_mid_direct(LzP P, Lz2Scratch sc, int cls)
 {
-    constexpr int STRIDE = CMAX + 1;                      // odd stride in 16-bit units: spreads the lanes over the banks
-    __shared__ uint16_t s_opid[LANES * STRIDE], s_opos[LANES * STRIDE], s_slot[LANES * STRIDE];
+    constexpr int STRIDE = CMAX + 1;                      // odd stride: spreads the lanes over the banks
+    typedef typename SlotType<(CMAX <= 128)>::type slot_t;     // a slot number fits a byte up to 255
+    __shared__ uint32_t s_occ[LANES * STRIDE];            // slot -> word id | position << 16 of its occupant
+    __shared__ slot_t   s_slot[LANES * STRIDE];           // entry -> slot (for its eviction)
     __shared__ uint32_t s_bits[LANES * (CMAX / 32 + 1)];
     const uint32_t lane = threadIdx.x;
     const uint32_t ncl = sc.big_count[cls];
@@ -621,11 +656,13 @@ void k_lz2_mid_direct(LzP P, Lz2Scratch sc, int cls)
     const uint16_t *bi = sc.bigpid + (size_t)d.block * LZ_MAX_BLOCK + d.start;
     uint16_t *bc = sc.bigcand + (size_t)d.block * LZ_MAX_BLOCK + d.start;
     const uint32_t lr = lane < (uint32_t)LANES ? lane : 0u;  // surplus lanes (LANES < 64) idle on region 0: n = 0
-    uint16_t *opid = s_opid + lr * STRIDE, *opos = s_opos + lr * STRIDE, *slot = s_slot + lr * STRIDE;
+    uint32_t *occ = s_occ + lr * STRIDE;
+    slot_t *slot = s_slot + lr * STRIDE;
     uint32_t *bits = s_bits + lr * (CMAX / 32 + 1);
     if (lane < (uint32_t)LANES) for (int k = 0; k < CMAX / 32 + 1; ++k) bits[k] = 0;
     uint32_t ev = 0, ev_p = active && n ? bp[0] : 0u;
     bool anom_pending = d.anom != ~0u;
+    const bool plain = d.anom == ~0u && d.limit == ~0u;    // not the cluster that covers bucket 0 / T
     // entry fields are fetched one step ahead: each lane walks its own cluster, so these loads do not coalesce
     // and their latency would otherwise sit on every step
     uint32_t nx_p = 0, nx_r = 0, nx_id = 0;
@@ -641,19 +678,27 @@ void k_lz2_mid_direct(LzP P, Lz2Scratch sc, int cls)
             ++ev; ev_p = bp[ev];
         }
         if (anom_pending && p > W - 1u) { bits[d.anom >> 5] &= ~(1u << (d.anom & 31u)); anom_pending = false; }
+        uint32_t wi = r >> 5;
+        const uint32_t w0 = bits[wi];
         uint32_t res = LZ_NONE16;
-        for (uint32_t b = r;; ++b) {
-            if (b == d.limit && r < d.limit) break;
-            if (!((bits[b >> 5] >> (b & 31u)) & 1u)) break;
-            if (opid[b] == id) { res = opos[b]; break; }
+        if (plain && ev == 0) {                            // nothing evicted yet: find() = the word's first occurrence,
+            if (id != p) res = id;                         // which is what the word id is (k_lz2_find, the sweep)
+        } else if ((w0 >> (r & 31u)) & 1u) {
+            for (uint32_t b = r;; ++b) {
+                if (b != r) {
+                    if (b == d.limit && r < d.limit) break;
+                    if (!((bits[b >> 5] >> (b & 31u)) & 1u)) break;
+                }
+                const uint32_t o = occ[b];
+                if ((o & 0xFFFFu) == id) { res = o >> 16; break; }
+            }
         }
         bc[i] = (uint16_t)res;
-        uint32_t wi = r >> 5;
-        uint32_t wv = bits[wi] | ((1u << (r & 31u)) - 1u);
+        uint32_t wv = w0 | ((1u << (r & 31u)) - 1u);
         while (wv == 0xFFFFFFFFu) wv = bits[++wi];
         const uint32_t b = (wi << 5) + (uint32_t)__builtin_ctz(~wv);
         bits[b >> 5] |= 1u << (b & 31u);
-        opid[b] = (uint16_t)id; opos[b] = (uint16_t)p; slot[i] = (uint16_t)b;
+        occ[b] = id | (p << 16); slot[i] = (slot_t)b;
     }
 }
 
@@ -667,7 +712,8 @@ void k_lz2_scatter(Lz2Scratch sc, uint16_t *__restrict__ cand_by_pos /* [nb][655
     const uint32_t n = mt->n;
     const uint16_t *pl = sc.plist + (size_t)lb * LZ_MAX_BLOCK, *cd = sc.cand + (size_t)lb * LZ_MAX_BLOCK;
     uint16_t *out = cand_by_pos + (size_t)lb * LZ_MAX_BLOCK;
-    for (uint32_t j = threadIdx.x; j < n; j += 1024) { const uint32_t c = cd[j]; if (c != LZ2_PENDING16) out[pl[j]] = (uint16_t)c; }
+    for (uint32_t j = threadIdx.x; j < n; j += 1024) { const uint32_t c = cd[j], p = pl[j]; if (c != p || p == LZ_NONE16) out[p] = (uint16_t)c; }
+    __syncthreads();                                                     // position 0xFFFF: "none" first, the exported result over it
     const uint32_t nb = mt->nbig_entries;
     const uint16_t *bp = sc.bigpos + (size_t)lb * LZ_MAX_BLOCK, *bc = sc.bigcand + (size_t)lb * LZ_MAX_BLOCK;
     for (uint32_t j = threadIdx.x; j < nb; j += 1024) out[bp[j]] = bc[j];

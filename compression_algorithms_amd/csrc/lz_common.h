@@ -134,7 +134,7 @@ __device__ __forceinline__ void radix_pass(uint32_t n, uint32_t (*s_cnt)[256], L
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t seg = ((n + (uint32_t)NT - 1u) / (uint32_t)NT) * 64u;
     const uint32_t a = wave * seg, b = (a + seg < n) ? a + seg : n;
-    for (int i = tid; i < NWAVES * 256; i += NT) (&s_cnt[0][0])[i] = 0;
+    for (int i = tid; i < NWAVES * ND; i += NT) s_cnt[i >> NBITS][i & (ND - 1)] = 0;
     __syncthreads();
     for (uint32_t i = a + lane; i < b; i += 64) atomicAdd(&s_cnt[wave][digit(load(i))], 1u);
     __syncthreads();

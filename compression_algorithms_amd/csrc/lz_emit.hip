@@ -56,6 +56,7 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
             for (uint32_t k = 0; k < 16; ++k) s_r0[i + k] = (i + k < n) ? src[i + k] : (uint8_t)0;
         }
     }
+    if (tid == 0) s_L[LZ_MAX_BLOCK - 1] = 0;     // position 0xFFFF: its "pending" marker equals "none" (lz2.h); none unless a list says otherwise
     __syncthreads();
 
     PE_TICK(0);
@@ -97,7 +98,7 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
         }
     };
     if (lists) {
-        for_each_pair(l_pos, l_cand, n, [&](uint32_t p, uint32_t c) { if (c != LZ2_PENDING16) s_L[p] = (uint8_t)token_len(p, c); });
+        for_each_pair(l_pos, l_cand, n, [&](uint32_t p, uint32_t c) { if (c != p) s_L[p] = (uint8_t)token_len(p, c); });
         for_each_pair(b_pos, b_cand, nbig, [&](uint32_t p, uint32_t c) { s_L[p] = (uint8_t)token_len(p, c); });
     } else {
         for (uint32_t p = tid; p < n; p += 1024u) s_L[p] = (uint8_t)token_len(p, cand[p]);
@@ -192,7 +193,7 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
             const uint32_t ch = p >> 6, o = p & 63u;
             if ((s_mat[ch] >> o) & 1ull) md[mb[ch] + (uint32_t)__popcll(s_mat[ch] & ((1ull << o) - 1ull))] = (uint16_t)(p - c);
         };
-        for_each_pair(l_pos, l_cand, n, [&](uint32_t p, uint32_t c) { if (c != LZ2_PENDING16 && c != LZ_NONE16) put(p, c); });
+        for_each_pair(l_pos, l_cand, n, [&](uint32_t p, uint32_t c) { if (c != p && c != LZ_NONE16) put(p, c); });
         for_each_pair(b_pos, b_cand, nbig, [&](uint32_t p, uint32_t c) { if (c != LZ_NONE16) put(p, c); });
         __syncthreads();
     }
