@@ -153,21 +153,37 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     constexpr uint32_t CH = LZ2_CAP / LZ2_THREADS;
     const uint32_t k0 = tid * CH, k1 = (k0 + CH < m) ? k0 + CH : m;
     {
+        // the thread's CH entries live in registers for the three passes below (time index, mixed word, home')
+        uint32_t rj[CH], rw[CH]; int32_t rh[CH];
         int32_t mx = INT32_MIN;
-        for (uint32_t k = k0; k < k1; ++k) { const int32_t g = (int32_t)homep(s_j0[k]) - (int32_t)k; mx = g > mx ? g : mx; }
+#pragma unroll
+        for (uint32_t c = 0; c < CH; ++c) {
+            const uint32_t k = k0 + c;
+            rj[c] = 0; rw[c] = 0; rh[c] = 0;
+            if (k < k1) {
+                rj[c] = s_j0[k]; rw[c] = s_word[rj[c]]; rh[c] = (int32_t)(((rw[c] & Tmask) - base) & Tmask);
+                const int32_t g = rh[c] - (int32_t)k;
+                mx = g > mx ? g : mx;
+            }
+        }
         int32_t gmax_total;
         const int32_t premax = block_exclusive_scan<int32_t>(mx, OpMaxI32(), INT32_MIN, s_i32, &gmax_total);
+        int32_t prev_h0 = 0;
+        if (k0 > 0 && k0 < m) prev_h0 = (int32_t)homep(s_j0[k0 - 1]);
         uint32_t nheads = 0; int32_t lasthead = -1, lastrun = -1;
         {
-            int32_t run = premax, prev_h = 0;
-            if (k0 > 0 && k0 < m) prev_h = (int32_t)homep(s_j0[k0 - 1]);
-            for (uint32_t k = k0; k < k1; ++k) {
-                const int32_t h = (int32_t)homep(s_j0[k]), g = h - (int32_t)k;
-                const bool head = (k == 0) || (g >= run);
-                run = g > run ? g : run;
-                if (head) { ++nheads; lasthead = (int32_t)k; }
-                if (k == 0 || h != prev_h) lastrun = (int32_t)k;
-                prev_h = h;
+            int32_t run = premax, prev_h = prev_h0;
+#pragma unroll
+            for (uint32_t c = 0; c < CH; ++c) {
+                const uint32_t k = k0 + c;
+                if (k < k1) {
+                    const int32_t h = rh[c], g = h - (int32_t)k;
+                    const bool head = (k == 0) || (g >= run);
+                    run = g > run ? g : run;
+                    if (head) { ++nheads; lasthead = (int32_t)k; }
+                    if (k == 0 || h != prev_h) lastrun = (int32_t)k;
+                    prev_h = h;
+                }
             }
         }
         // one scan for three carries: heads so far (sum), last head index + 1 (max), last home-run start + 1 (max)
@@ -185,36 +201,39 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
         const uint32_t gid_base = (uint32_t)(pre3 & 0xFFFFu), total_heads = (uint32_t)(tot3 & 0xFFFFu);
         const int32_t gs_carry = (int32_t)((pre3 >> 16) & 0xFFFFu) - 1, hs_carry = (int32_t)((pre3 >> 32) & 0xFFFFu) - 1;
         if (tid == 0) s_ngroups = total_heads;
-        int32_t run = premax, prev_h = 0;
+        int32_t run = premax, prev_h = prev_h0;
         uint32_t cur_gs = 0, cur_gid = gid_base; int32_t cur_base = 0;
         uint32_t cur_hs = 0, hs_word = 0, hs_j = 0;
         if (k0 < m) {
-            if (k0 > 0) prev_h = (int32_t)homep(s_j0[k0 - 1]);
             if (gs_carry >= 0) { cur_gs = (uint32_t)gs_carry; cur_base = (int32_t)homep(s_j0[cur_gs]); cur_gid = gid_base - 1u; }
             if (hs_carry >= 0) { cur_hs = (uint32_t)hs_carry; hs_j = s_j0[cur_hs]; hs_word = s_word[hs_j]; }
         }
         uint32_t seen = 0;
-        for (uint32_t k = k0; k < k1; ++k) {
-            const uint32_t j = s_j0[k];
-            const int32_t h = (int32_t)homep(j), g = h - (int32_t)k;
-            const bool head = (k == 0) || (g >= run);
-            run = g > run ? g : run;
-            const uint32_t w = s_word[j];
-            if (head) { cur_gs = k; cur_base = h; cur_gid = gid_base + seen; ++seen; }
-            uint32_t id;
-            if (k == 0 || h != prev_h) { cur_hs = k; hs_word = w; hs_j = j; id = j; }
-            else if (w == hs_word) id = hs_j;
-            else {                                      // two different words share a home bucket: rare
-                id = j;
-                for (uint32_t kk = cur_hs + 1; kk < k; ++kk) { const uint32_t j2 = s_j0[kk]; if (s_word[j2] == w) { id = j2; break; } }
+#pragma unroll
+        for (uint32_t c = 0; c < CH; ++c) {
+            const uint32_t k = k0 + c;
+            if (k < k1) {
+                const uint32_t j = rj[c];
+                const int32_t h = rh[c], g = h - (int32_t)k;
+                const bool head = (k == 0) || (g >= run);
+                run = g > run ? g : run;
+                const uint32_t w = rw[c];
+                if (head) { cur_gs = k; cur_base = h; cur_gid = gid_base + seen; ++seen; }
+                uint32_t id;
+                if (k == 0 || h != prev_h) { cur_hs = k; hs_word = w; hs_j = j; id = j; }
+                else if (w == hs_word) id = hs_j;
+                else {                                      // two different words share a home bucket: rare
+                    id = j;
+                    for (uint32_t kk = cur_hs + 1; kk < k; ++kk) { const uint32_t j2 = s_j0[kk]; if (s_word[j2] == w) { id = j2; break; } }
+                }
+                prev_h = h;
+                s_g[j] = (uint16_t)cur_gid;
+                s_r[j] = (uint16_t)(cur_gs + (uint32_t)(h - cur_base));
+                // the word's identity is the POSITION of its first occurrence in the block (the home order is stable in
+                // time).  While nothing of a cluster has been evicted that position is also what find() returns: the first
+                // copy sits at the lowest slot of the word and every slot between the home and it stays occupied.
+                s_pid[j] = s_pos[id];
             }
-            prev_h = h;
-            s_g[j] = (uint16_t)cur_gid;
-            s_r[j] = (uint16_t)(cur_gs + (uint32_t)(h - cur_base));
-            // the word's identity is the POSITION of its first occurrence in the block (the home order is stable in
-            // time).  While nothing of a cluster has been evicted that position is also what find() returns: the first
-            // copy sits at the lowest slot of the word and every slot between the home and it stays occupied.
-            s_pid[j] = s_pos[id];
         }
     }
     __syncthreads();
@@ -357,7 +376,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
         uint32_t it = 0;
         for (uint32_t q = tid; q < nbig; q += LZ2_THREADS, ++it) {
             const uint32_t cnt = s_big[3 * q + 1] - s_big[3 * q];
-            const uint32_t cls = lz2_class_of(cnt, sc.wave_min);
+            const uint32_t cls = lz2_class_of(cnt, sc.wave_min, sc.row_mode);
             my_rank[it] = atomicAdd(&s_cls[cls], 1u);
             my_dst[it] = atomicAdd(&s_ent, cnt);
         }
@@ -370,7 +389,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
         uint32_t it = 0;
         for (uint32_t q = tid; q < nbig; q += LZ2_THREADS, ++it) {
             const uint32_t s = s_big[3 * q], e = s_big[3 * q + 1], cnt = e - s;
-            const uint32_t cls = lz2_class_of(cnt, sc.wave_min);
+            const uint32_t cls = lz2_class_of(cnt, sc.wave_min, sc.row_mode);
             const uint32_t dst = s_entbase + my_dst[it];
             s_big[3 * q + 2] = dst;
             Lz2BigDesc d;
@@ -533,6 +552,143 @@ void k_lz2_big(LzP P, Lz2Scratch sc, int large)
             if (ii < n) bc[ii] = (uint16_t)out_acc;
         }
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// =============================================================================================
+// quarter-wave-per-cluster replay (128 .. 1024 entries), opt-in with MI_LZ_ROW=1 (see lz2_carve for the numbers).
+// k_lz2_big spends a whole wave on one cluster and nearly all of its instructions are wave-uniform, i.e. SALU work —
+// and a CU issues ONE scalar instruction per cycle for all resident waves: ~90 CU-cycles per replayed entry.  Here a 16-lane DPP row owns a cluster: the
+// occupancy bitmap is spread over the row's registers (word q*16+l in register q of lane l), first-fit is a row
+// minimum by four row-rotate DPP steps, the current entry is broadcast inside the row by ds_bpermute.  Everything
+// is VALU / LDS work issued per SIMD, four clusters per wave advance in lockstep, and the scalar loop control is
+// shared by the four.
+// =============================================================================================
+__device__ __forceinline__ uint32_t row_min_u32(uint32_t v)
+{
+    // dpp_ctrl 0x120 + n = row_ror:n (rotate right inside each 16-lane row); after 8,4,2,1 every lane holds the row minimum
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xF, 0xF, false); v = t < v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xF, 0xF, false); v = t < v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x122, 0xF, 0xF, false); v = t < v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x121, 0xF, 0xF, false); v = t < v ? t : v;
+    return v;
+}
+
+#define LZ2_ROW_ENTRIES 1024
+__global__ __launch_bounds__(64)
+void k_lz2_row(LzP P, Lz2Scratch sc)
+{
+    constexpr int LDS_ENTRIES = LZ2_ROW_ENTRIES;
+    constexpr int NWR = (LDS_ENTRIES + 511) / 512;        // bitmap registers per lane (16 lanes x 32 bits each)
+    __shared__ uint32_t s_occ[4][LDS_ENTRIES];            // slot -> word id | position << 16 of its occupant
+    __shared__ uint16_t s_slot[4][LDS_ENTRIES];           // entry -> slot (for its eviction)
+    const uint32_t lane = threadIdx.x, row = lane >> 4, lr = lane & 15u;
+    // ONE launch for the three size classes, longest chains first: a launch lasts as long as its longest cluster, and
+    // three launches in a row would add those tails up.  Workgroup -> (class, four clusters of that class).
+    const uint32_t n5 = sc.big_count[5], n4 = sc.big_count[4], n3 = sc.big_count[3];
+    const uint32_t g5 = (n5 + 3u) >> 2, g4 = (n4 + 3u) >> 2, g3 = (n3 + 3u) >> 2;
+    uint32_t wg = blockIdx.x, cls, ncl;
+    if (wg < g5) { cls = 5; ncl = n5; }
+    else if (wg < g5 + g4) { cls = 4; ncl = n4; wg -= g5; }
+    else if (wg < g5 + g4 + g3) { cls = 3; ncl = n3; wg -= g5 + g4; }
+    else return;
+    const uint32_t ci = wg * 4u + row;
+    Lz2BigDesc d;
+    d.block = 0; d.start = 0; d.count = 0; d.anom = ~0u; d.limit = ~0u;
+    if (ci < ncl) d = sc.desc[cls][ci];
+    const uint32_t n = d.count <= (uint32_t)LDS_ENTRIES ? d.count : 0u, W = 1u << P.wbits;
+    const uint16_t *bp = sc.bigpos + (size_t)d.block * LZ_MAX_BLOCK + d.start;
+    const uint16_t *br = sc.bigrs + (size_t)d.block * LZ_MAX_BLOCK + d.start;
+    const uint16_t *bi = sc.bigpid + (size_t)d.block * LZ_MAX_BLOCK + d.start;
+    uint16_t *bc = sc.bigcand + (size_t)d.block * LZ_MAX_BLOCK + d.start;
+    uint32_t *occ = s_occ[row];
+    uint16_t *slot = s_slot[row];
+    uint32_t w[NWR];
+#pragma unroll
+    for (int q = 0; q < NWR; ++q) w[q] = 0;
+    auto bitword = [&](uint32_t wi) -> uint32_t {         // bitmap word wi of this row (wi is row-uniform)
+        uint32_t sel = w[0];
+#pragma unroll
+        for (int q = 1; q < NWR; ++q) sel = ((wi >> 4) == (uint32_t)q) ? w[q] : sel;
+        return (uint32_t)__shfl((int)sel, (int)(wi & 15u), 16);
+    };
+    auto clear_slot = [&](uint32_t sl) {
+        const uint32_t wi = sl >> 5;
+        const uint32_t keep = ((wi & 15u) == lr) ? ~(1u << (sl & 31u)) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int q = 0; q < NWR; ++q) w[q] &= ((wi >> 4) == (uint32_t)q) ? keep : 0xFFFFFFFFu;
+    };
+    // the oldest entry still in the table: its position is kept at hand so that the common "nothing to evict" test
+    // costs a compare, not an LDS round trip
+    uint32_t ev = 0, ev_pos = 0, ev_base = 0, out_acc = 0;
+    { const uint32_t q = lr; ev_pos = q < n ? bp[q] : 0u; }
+    uint32_t pe = (uint32_t)__shfl((int)ev_pos, 0, 16);
+    bool anom_pending = d.anom != ~0u;
+    const bool plain = d.anom == ~0u && d.limit == ~0u;     // not the cluster that covers bucket 0 / T
+    for (uint32_t i0 = 0; i0 < (uint32_t)LDS_ENTRIES; i0 += 16) {
+        if (__ballot(i0 < n) == 0ull) break;                // every cluster of this wave is done
+        const uint32_t ii = i0 + lr;
+        uint32_t c_a = 0, c_id = 0;
+        if (ii < n) { c_a = (uint32_t)bp[ii] | ((uint32_t)br[ii] << 16); c_id = bi[ii]; }
+        // the entry of step t + 1 is broadcast inside the row while step t runs (ds_bpermute latency off the chain)
+        uint32_t a_nx = (uint32_t)__shfl((int)c_a, 0, 16), id_nx = (uint32_t)__shfl((int)c_id, 0, 16);
+        for (uint32_t t = 0; t < 16; ++t) {
+            const uint32_t i = i0 + t;
+            if (__ballot(i < n) == 0ull) break;
+            const uint32_t a = a_nx, id = id_nx;
+            a_nx = (uint32_t)__shfl((int)c_a, (int)((t + 1u) & 15u), 16); id_nx = (uint32_t)__shfl((int)c_id, (int)((t + 1u) & 15u), 16);
+            if (i < n) {                                    // row-uniform from here on
+                const uint32_t p = a & 0xFFFFu, r = a >> 16;
+                while (ev < i && pe + W < p) {              // FIFO retirement (lz77.c:70-76)
+                    clear_slot(slot[ev]);                   // clears the bucket, whoever sits there
+                    ++ev;
+                    if ((ev & ~15u) != ev_base) { ev_base = ev & ~15u; const uint32_t q = ev_base + lr; ev_pos = q < n ? bp[q] : 0u; }
+                    pe = (uint32_t)__shfl((int)ev_pos, (int)(ev & 15u), 16);
+                }
+                if (anom_pending && p > W - 1u) { clear_slot(d.anom); anom_pending = false; }
+                uint32_t res = LZ_NONE16;
+                if (plain && ev == 0) {
+                    // nothing evicted yet: find() = the word's first occurrence = the word id (k_lz2_find, the sweep)
+                    if (id != p) res = id;
+                } else {
+                    const uint32_t h = occ[r];
+                    if ((bitword(r >> 5) >> (r & 31u)) & 1u) {
+                        if ((h & 0xFFFFu) == id) res = h >> 16;
+                        else {
+                            for (uint32_t b = r + 1;; ++b) {    // rare: the home holds another word
+                                if (b == d.limit && r < d.limit) break;
+                                if (!((bitword(b >> 5) >> (b & 31u)) & 1u)) break;
+                                const uint32_t o = occ[b];
+                                if ((o & 0xFFFFu) == id) { res = o >> 16; break; }
+                            }
+                        }
+                    }
+                }
+                // insert: first fit = row minimum over every lane's first zero at or after r (inside the cluster by the parking bound)
+                const uint32_t rw = r >> 5, lowmask = (1u << (r & 31u)) - 1u;
+                uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+                for (int q = 0; q < NWR; ++q) {
+                    const uint32_t wi = (uint32_t)q * 16u + lr;
+                    uint32_t v = w[q];
+                    if (wi < rw) v = 0xFFFFFFFFu; else if (wi == rw) v |= lowmask;
+                    const uint32_t c = (v != 0xFFFFFFFFu) ? (wi << 5) + (uint32_t)__builtin_ctz(~v) : 0xFFFFFFFFu;
+                    best = c < best ? c : best;
+                }
+                const uint32_t b = row_min_u32(best);
+                {
+                    const uint32_t wi = b >> 5;
+                    const uint32_t bit = ((wi & 15u) == lr) ? (1u << (b & 31u)) : 0u;
+#pragma unroll
+                    for (int q = 0; q < NWR; ++q) w[q] |= ((wi >> 4) == (uint32_t)q) ? bit : 0u;
+                }
+                if (lr == 0 && b < (uint32_t)LDS_ENTRIES) { occ[b] = id | (p << 16); slot[i] = (uint16_t)b; }
+                if (lr == t) out_acc = res;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (ii < n) bc[ii] = (uint16_t)out_acc;
     }
 }
 
@@ -763,6 +919,11 @@ void lz2_carve(mi_carver &cv, uint32_t nb, Lz2Scratch *sc)
     sc->big_count = sc->fallback_count + 16;
     sc->dbg = getenv("MI_LZ_DEBUG") ? cv.take<uint64_t>(32) : nullptr;
     sc->wave_min = LZ2_WAVE;
+    // quarter-wave replay of 128..1024-entry clusters (k_lz2_row) is OPT-IN: alone it is no faster than k_lz2_big
+    // (19.6 vs 16.7 ms / GB: 24 KiB of LDS per wave leaves 6 waves per CU and every instruction of a wave costs >= 4
+    // cycles of latency), and beside k_lz2_find — which needs all of a CU's LDS for its two workgroups — that LDS
+    // footprint costs the pipeline 4 % (10.74 vs 11.24 GB/s, same box).  Kept for the measurement.
+    sc->row_mode = getenv("MI_LZ_ROW") ? 1u : 0u;
     if (const char *e = getenv("MI_LZ_WAVE_MIN")) { const int v = atoi(e); if (v == 128 || v == 256 || v == 512) sc->wave_min = (uint32_t)v; }
 }
 
@@ -819,10 +980,14 @@ mi_status lz2_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &
         }
         // classes 3 / 4 only exist when the wave replay starts at 256 / 512 entries (an empty launch that asks for
         // ~90 KiB of LDS per workgroup would still queue behind k_lz2_find for that LDS)
-        if (sc.wave_min > 128) hipLaunchKernelGGL((k_lz2_mid<256, 64>), dim3(nb * lz2_class_cap(3) / 64 + 1), dim3(64), 0, s, P, sc, 3);
-        if (sc.wave_min > 256) hipLaunchKernelGGL((k_lz2_mid<512, 32>), dim3(nb * lz2_class_cap(4) / 32 + 1), dim3(64), 0, s, P, sc, 4);
+        if (!sc.row_mode && sc.wave_min > 128) hipLaunchKernelGGL((k_lz2_mid<256, 64>), dim3(nb * lz2_class_cap(3) / 64 + 1), dim3(64), 0, s, P, sc, 3);
+        if (!sc.row_mode && sc.wave_min > 256) hipLaunchKernelGGL((k_lz2_mid<512, 32>), dim3(nb * lz2_class_cap(4) / 32 + 1), dim3(64), 0, s, P, sc, 4);
     }
-    {
+    if (sc.row_mode) {
+        mi_prof_scope p(ctx, "k_lz2_row", s, (uint64_t)nb * P.block);
+        hipLaunchKernelGGL(k_lz2_row, dim3(nb * (lz2_class_cap(5) + lz2_class_cap(4) + lz2_class_cap(3)) / 4 + 3), dim3(64), 0, s, P, sc);
+        hipLaunchKernelGGL((k_lz2_big<LZ2_CAP, 4>), dim3(nb * lz2_class_cap(6) < 4096 ? nb * lz2_class_cap(6) : 4096), dim3(64), 0, s, P, sc, 1);
+    } else {
         mi_prof_scope p(ctx, "k_lz2_big", s, (uint64_t)nb * P.block);
         hipLaunchKernelGGL((k_lz2_big<LZ2_BIG_SMALL, 1>), dim3(nb * lz2_class_cap(5)), dim3(64), 0, s, P, sc, 0);
         hipLaunchKernelGGL((k_lz2_big<LZ2_CAP, 4>), dim3(nb * lz2_class_cap(6) < 4096 ? nb * lz2_class_cap(6) : 4096), dim3(64), 0, s, P, sc, 1);
