@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 CSRC_DIR = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(LIB_DIR, "libmi_codec.so")
+LIB_PATH = os.environ.get("MI_CODEC_LIB") or os.path.join(LIB_DIR, "libmi_codec.so")   # override: A/B builds of the same ABI
 
 MI_OK = 0
 STATUS = {0: "MI_OK", 1: "MI_ERR_ARG", 2: "MI_ERR_HIP", 3: "MI_ERR_NOMEM", 4: "MI_ERR_CAPACITY",

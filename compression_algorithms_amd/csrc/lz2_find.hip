@@ -700,95 +700,12 @@ void k_lz2_row(LzP P, Lz2Scratch sc)
 template <bool SMALL> struct SlotType { typedef uint8_t type; };
 template <> struct SlotType<false> { typedef uint16_t type; };
 
-template <int CMAX, int LANES>
-__global__ __launch_bounds__(64)
-void k_lz2_mid(LzP P, Lz2Scratch sc, int cls)
-{
-    constexpr int STRIDE = CMAX + 1;                      // odd stride in 16-bit units: spreads the lanes over the banks
-    constexpr int CH = 16;                                // entries per cluster staged per round
-    constexpr int ROW = 66;                               // padded row of the staging tiles (bank spread for the column writes)
-    typedef typename SlotType<(CMAX <= 256)>::type slot_t;     // a slot number fits a byte up to 256 entries
-    __shared__ uint16_t s_opid[LANES * STRIDE], s_opos[LANES * STRIDE], s_epos[LANES * STRIDE];
-    __shared__ slot_t   s_slot[LANES * STRIDE];
-    __shared__ uint32_t s_bits[LANES * (CMAX / 32 + 1)];
-    // every lane walks its own cluster, so direct global accesses would touch 64 cache lines per instruction:
-    // CH entries of all 64 clusters are staged through LDS by coalesced loads (four clusters per instruction)
-    __shared__ uint16_t st_pos[CH * ROW], st_rs[CH * ROW], st_pid[CH * ROW], st_out[CH * ROW];
-    __shared__ uint32_t s_dblk[64], s_dstart[64], s_dcnt[64];
-    const uint32_t lane = threadIdx.x;
-    const uint32_t ncl = sc.big_count[cls];
-    const uint32_t ci = blockIdx.x * (uint32_t)LANES + lane;
-    if (blockIdx.x * (uint32_t)LANES >= ncl) return;
-    const bool active = ci < ncl && lane < (uint32_t)LANES;
-    Lz2BigDesc d;
-    d.block = 0; d.start = 0; d.count = 0; d.anom = ~0u; d.limit = ~0u;
-    if (active) d = sc.desc[cls][ci];
-    const uint32_t n = d.count, W = 1u << P.wbits;
-    s_dblk[lane] = d.block; s_dstart[lane] = d.start; s_dcnt[lane] = n;
-    const uint32_t lr = lane < (uint32_t)LANES ? lane : 0u;  // surplus lanes (LANES < 64) idle on region 0: n = 0
-    uint16_t *opid = s_opid + lr * STRIDE, *opos = s_opos + lr * STRIDE, *epos = s_epos + lr * STRIDE;
-    slot_t *slot = s_slot + lr * STRIDE;
-    uint32_t *bits = s_bits + lr * (CMAX / 32 + 1);
-    if (lane < (uint32_t)LANES) for (int k = 0; k < CMAX / 32 + 1; ++k) bits[k] = 0;
-    __builtin_amdgcn_wave_barrier();
-    uint32_t ev = 0;
-    bool anom_pending = d.anom != ~0u;
-    const uint32_t sub = lane >> 4, eo = lane & 15u;         // staging role: cluster (4 per step) and entry offset
-    for (uint32_t c0 = 0; c0 < (uint32_t)CMAX; c0 += CH) {
-        if (__ballot(c0 < n) == 0ull) break;                // every cluster of this wave is done
-        for (uint32_t g = 0; g < 16; ++g) {                 // 64 clusters, 4 per step, 16 consecutive entries each
-            const uint32_t cl = g * 4u + sub, e = c0 + eo;
-            if (e < s_dcnt[cl]) {
-                const size_t at = (size_t)s_dblk[cl] * LZ_MAX_BLOCK + s_dstart[cl] + e;
-                st_pos[eo * ROW + cl] = sc.bigpos[at]; st_rs[eo * ROW + cl] = sc.bigrs[at]; st_pid[eo * ROW + cl] = sc.bigpid[at];
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t t = 0; t < (uint32_t)CH; ++t) {
-            const uint32_t i = c0 + t;
-            if (i >= n) continue;                           // lanes with shorter clusters idle (same size class: < 2x)
-            const uint32_t p = st_pos[t * ROW + lane], r = st_rs[t * ROW + lane], id = st_pid[t * ROW + lane];
-            epos[i] = (uint16_t)p;
-            while (ev < i && (uint32_t)epos[ev] + W < p) {  // FIFO retirement
-                const uint32_t b = slot[ev];
-                bits[b >> 5] &= ~(1u << (b & 31u));
-                ++ev;
-            }
-            if (anom_pending && p > W - 1u) { bits[d.anom >> 5] &= ~(1u << (d.anom & 31u)); anom_pending = false; }
-            // everything the common case needs depends on the home slot alone: three loads in flight at once
-            const uint32_t w0 = bits[r >> 5];
-            const uint32_t h_id = opid[r], h_pos = opos[r];
-            uint32_t res = LZ_NONE16;
-            if ((w0 >> (r & 31u)) & 1u) {
-                if (h_id == id) res = h_pos;
-                else {
-                    for (uint32_t b = r + 1;; ++b) {       // rare: the home holds another word
-                        if (b == d.limit && r < d.limit) break;
-                        if (!((bits[b >> 5] >> (b & 31u)) & 1u)) break;
-                        if (opid[b] == id) { res = opos[b]; break; }
-                    }
-                }
-            }
-            st_out[t * ROW + lane] = (uint16_t)res;
-            uint32_t wi = r >> 5;
-            uint32_t wv = w0 | ((1u << (r & 31u)) - 1u);
-            while (wv == 0xFFFFFFFFu) wv = bits[++wi];
-            const uint32_t b = (wi << 5) + (uint32_t)__builtin_ctz(~wv);
-            bits[b >> 5] |= 1u << (b & 31u);
-            opid[b] = (uint16_t)id; opos[b] = (uint16_t)p; slot[i] = (slot_t)b;
-        }
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t g = 0; g < 16; ++g) {
-            const uint32_t cl = g * 4u + sub, e = c0 + eo;
-            if (e < s_dcnt[cl]) sc.bigcand[(size_t)s_dblk[cl] * LZ_MAX_BLOCK + s_dstart[cl] + e] = st_out[eo * ROW + cl];
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// the same replay with direct (uncoalesced) global accesses and 3x less LDS.  DEFAULT: alone it is slower than the
-// staged variant (8.35 vs 7.16 ms / 400 MB) but beside k_lz2_find of the next batch its smaller LDS footprint wins
-// (10.88 vs 10.46 GB/s whole pipeline, same box); MI_LZ_MID_STAGED=1 selects the staged kernel
+// Measured alternatives (round 1, same box): staging 16 entries of all 64 clusters through LDS by coalesced loads ran
+// 14 % faster alone (7.16 vs 8.35 ms / 400 MB) but its 3x LDS footprint cost the overlapped pipeline 4 % (10.46 vs 10.88
+// GB/s) — k_lz2_find needs the whole LDS of a CU for its two workgroups; packing an entry into one 8-byte record
+// fetched four steps ahead ran 19 % faster alone (6.76 ms) and cost the pipeline 2 % (11.24 vs 11.46: the export in
+// k_lz2_find writes twice the bytes); lane replay of 128..511-entry clusters was 4x slower than the wave replay (one
+// wave per CU).  All three were removed.
 template <int CMAX, int LANES>
 __global__ __launch_bounds__(64)
 void k_lz2_mid_direct(LzP P, Lz2Scratch sc, int cls)
@@ -879,12 +796,6 @@ template __global__ void k_lz2_mid_direct<16, 64>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_mid_direct<32, 64>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_mid_direct<64, 64>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_mid_direct<128, 64>(LzP, Lz2Scratch, int);
-template __global__ void k_lz2_mid<16, 64>(LzP, Lz2Scratch, int);
-template __global__ void k_lz2_mid<32, 64>(LzP, Lz2Scratch, int);
-template __global__ void k_lz2_mid<64, 64>(LzP, Lz2Scratch, int);
-template __global__ void k_lz2_mid<128, 64>(LzP, Lz2Scratch, int);
-template __global__ void k_lz2_mid<256, 64>(LzP, Lz2Scratch, int);
-template __global__ void k_lz2_mid<512, 32>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_big<LZ2_BIG_SMALL, 1>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_big<LZ2_CAP, 4>(LzP, Lz2Scratch, int);
 
@@ -924,7 +835,6 @@ void lz2_carve(mi_carver &cv, uint32_t nb, Lz2Scratch *sc)
     // cycles of latency), and beside k_lz2_find — which needs all of a CU's LDS for its two workgroups — that LDS
     // footprint costs the pipeline 4 % (10.74 vs 11.24 GB/s, same box).  Kept for the measurement.
     sc->row_mode = getenv("MI_LZ_ROW") ? 1u : 0u;
-    if (const char *e = getenv("MI_LZ_WAVE_MIN")) { const int v = atoi(e); if (v == 128 || v == 256 || v == 512) sc->wave_min = (uint32_t)v; }
 }
 
 static uint64_t *g_dbg_ptr = nullptr;
@@ -963,26 +873,15 @@ mi_status lz2_stage_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_
 // stage B: replay of the exported clusters (almost no LDS: runs beside the next batch's stage A)
 mi_status lz2_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &sc, hipStream_t s)
 {
-    {
-        mi_prof_scope p(ctx, "k_lz2_mid", s, (uint64_t)nb * P.block);
-        // grids cover the worst case; surplus workgroups read the class count and leave
-        static const bool direct = getenv("MI_LZ_MID_STAGED") == nullptr;   // same-box A/B (round 1): direct 10.88 GB/s, staged 10.46
-        if (direct) {
-            hipLaunchKernelGGL((k_lz2_mid_direct<16, 64>), dim3(nb * lz2_class_cap(7) / 64 + 1), dim3(64), 0, s, P, sc, 7);
-            hipLaunchKernelGGL((k_lz2_mid_direct<32, 64>), dim3(nb * lz2_class_cap(0) / 64 + 1), dim3(64), 0, s, P, sc, 0);
-            hipLaunchKernelGGL((k_lz2_mid_direct<64, 64>), dim3(nb * lz2_class_cap(1) / 64 + 1), dim3(64), 0, s, P, sc, 1);
-            hipLaunchKernelGGL((k_lz2_mid_direct<128, 64>), dim3(nb * lz2_class_cap(2) / 64 + 1), dim3(64), 0, s, P, sc, 2);
-        } else {
-            hipLaunchKernelGGL((k_lz2_mid<16, 64>), dim3(nb * lz2_class_cap(7) / 64 + 1), dim3(64), 0, s, P, sc, 7);
-            hipLaunchKernelGGL((k_lz2_mid<32, 64>), dim3(nb * lz2_class_cap(0) / 64 + 1), dim3(64), 0, s, P, sc, 0);
-            hipLaunchKernelGGL((k_lz2_mid<64, 64>), dim3(nb * lz2_class_cap(1) / 64 + 1), dim3(64), 0, s, P, sc, 1);
-            hipLaunchKernelGGL((k_lz2_mid<128, 64>), dim3(nb * lz2_class_cap(2) / 64 + 1), dim3(64), 0, s, P, sc, 2);
-        }
-        // classes 3 / 4 only exist when the wave replay starts at 256 / 512 entries (an empty launch that asks for
-        // ~90 KiB of LDS per workgroup would still queue behind k_lz2_find for that LDS)
-        if (!sc.row_mode && sc.wave_min > 128) hipLaunchKernelGGL((k_lz2_mid<256, 64>), dim3(nb * lz2_class_cap(3) / 64 + 1), dim3(64), 0, s, P, sc, 3);
-        if (!sc.row_mode && sc.wave_min > 256) hipLaunchKernelGGL((k_lz2_mid<512, 32>), dim3(nb * lz2_class_cap(4) / 32 + 1), dim3(64), 0, s, P, sc, 4);
-    }
+    // lane-per-cluster classes; grids cover the worst case, surplus workgroups read the class count and leave
+    { mi_prof_scope p(ctx, "k_lz2_mid<16>", s, (uint64_t)nb * P.block);
+      hipLaunchKernelGGL((k_lz2_mid_direct<16, 64>), dim3(nb * lz2_class_cap(7) / 64 + 1), dim3(64), 0, s, P, sc, 7); }
+    { mi_prof_scope p(ctx, "k_lz2_mid<32>", s, (uint64_t)nb * P.block);
+      hipLaunchKernelGGL((k_lz2_mid_direct<32, 64>), dim3(nb * lz2_class_cap(0) / 64 + 1), dim3(64), 0, s, P, sc, 0); }
+    { mi_prof_scope p(ctx, "k_lz2_mid<64>", s, (uint64_t)nb * P.block);
+      hipLaunchKernelGGL((k_lz2_mid_direct<64, 64>), dim3(nb * lz2_class_cap(1) / 64 + 1), dim3(64), 0, s, P, sc, 1); }
+    { mi_prof_scope p(ctx, "k_lz2_mid<128>", s, (uint64_t)nb * P.block);
+      hipLaunchKernelGGL((k_lz2_mid_direct<128, 64>), dim3(nb * lz2_class_cap(2) / 64 + 1), dim3(64), 0, s, P, sc, 2); }
     if (sc.row_mode) {
         mi_prof_scope p(ctx, "k_lz2_row", s, (uint64_t)nb * P.block);
         hipLaunchKernelGGL(k_lz2_row, dim3(nb * (lz2_class_cap(5) + lz2_class_cap(4) + lz2_class_cap(3)) / 4 + 3), dim3(64), 0, s, P, sc);

@@ -183,10 +183,13 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
         while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (s_thr[mid] <= h) lo = mid; else hi = mid - 1; }
         return lo;
     };
+    uint8_t  *part_in = reinterpret_cast<uint8_t *>(s_grp) + 24576;    // [8192] part of every position of the slab (hashed once)
     for (uint32_t e0 = 0; e0 < n; e0 += 8192u) {
         const uint32_t en = (n - e0) < 8192u ? (n - e0) : 8192u;
+        for (uint32_t i = tid; i < en; i += 1024) part_in[i] = (uint8_t)part_of(e0 + i);
+        __syncthreads();
         radix_pass_1024<5, uint32_t>(en, s_cnt,
-            [&](uint32_t i) { const uint32_t p = e0 + i; return p | (part_of(p) << 16); },
+            [&](uint32_t i) { return (e0 + i) | ((uint32_t)part_in[i] << 16); },
             [&](uint32_t e) { return e >> 16; },
             [&](uint32_t j, uint32_t e) { stage[j] = (uint16_t)e; stage_part[j] = (uint8_t)(e >> 16); });
         // segment starts of this slab: first index of each part in the staged order

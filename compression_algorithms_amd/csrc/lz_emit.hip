@@ -185,9 +185,14 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     uint32_t *mb = tb + 1026;                                      // [1025]
     uint32_t *stage = mb + 1026;                                   // [2048 + 8]
     uint16_t *md = reinterpret_cast<uint16_t *>(stage + 2064);   // [<= 16384] distance of the k-th match token
+    uint16_t *tch = md + 16384;                                    // [<= 1024] chunk that holds token 64 * k
     tb[tid] = tbase; mb[tid] = mbase;
     if (tid == 0) { tb[1024] = ntok; mb[1024] = nmat; }
+    // token -> chunk without a binary search: every 64th token's chunk is tabulated (a chunk holds <= 64 tokens, so it
+    // covers at most one multiple of 64), the rest is a walk of a few chunks from there
+    for (uint32_t mlt = (tbase + 63u) & ~63u; mlt < tbase + (uint32_t)__popcll(my_tok); mlt += 64u) tch[mlt >> 6] = (uint16_t)tid;
     __syncthreads();
+    auto chunk_of = [&](uint32_t t) -> uint32_t { uint32_t c = tch[t >> 6]; while (tb[c + 1] <= t) ++c; return c; };
     if (lists) {
         auto put = [&](uint32_t p, uint32_t c) {
             const uint32_t ch = p >> 6, o = p & 63u;
@@ -208,9 +213,7 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
         //   literal  byte                       match  1<<31 | length << 16 | distance
         uint32_t *trec = trec_all + (size_t)lb * LZ_MAX_BLOCK;
         for (uint32_t t = tid; t < ntok; t += 1024u) {
-            uint32_t lo = 0, hi = 1023;
-            while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (tb[mid] <= t) lo = mid; else hi = mid - 1; }
-            const uint32_t c = lo, o = select_bit(s_tok[c], t - tb[c]), p = c * 64u + o;
+            const uint32_t c = chunk_of(t), o = select_bit(s_tok[c], t - tb[c]), p = c * 64u + o;
             uint32_t rec;
             if ((s_mat[c] >> o) & 1ull) {
                 const uint32_t mbefore = mb[c] + (uint32_t)__popcll(s_mat[c] & ((1ull << o) - 1ull));
@@ -230,9 +233,7 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
             const uint32_t t = t0 + (uint32_t)u * 1024u + tid;
             valid[u] = t < ntok;
             if (valid[u]) {
-                uint32_t lo = 0, hi = 1023;                           // last chunk with tb[c] <= t
-                while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (tb[mid] <= t) lo = mid; else hi = mid - 1; }
-                const uint32_t c = lo, o = select_bit(s_tok[c], t - tb[c]);
+                const uint32_t c = chunk_of(t), o = select_bit(s_tok[c], t - tb[c]);   // last chunk with tb[c] <= t
                 const uint32_t p = c * 64u + o;
                 const uint64_t below = (1ull << o) - 1ull;
                 const uint32_t mbefore = mb[c] + (uint32_t)__popcll(s_mat[c] & below);
