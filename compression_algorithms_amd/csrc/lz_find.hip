@@ -21,9 +21,13 @@
 // =============================================================================================
 // k_lz_sort_home
 // =============================================================================================
-__global__ __launch_bounds__(1024)
-void k_lz_sort_home(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, LzScratch sc, uint64_t block0,
-                    const uint32_t *__restrict__ blist, const uint32_t *__restrict__ bcount)
+// As the fallback of the LDS-resident finder these kernels normally have nothing to do, but every workgroup of a launch
+// must still be given its 82..155 KiB of LDS before it can find that out, and it takes that LDS from k_lz2_find
+// (rocprofv3, round 1: 1024-workgroup empty launches spent 4.8 ms each queueing).  So the bodies loop over the listed
+// blocks and the fallback launches use a small grid (LZ_FB_GRID workgroups).
+#define LZ_FB_GRID 128u
+__device__ __forceinline__ void lz_sort_home_block(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, LzScratch sc, uint64_t block0,
+                                                   uint32_t lb)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_in[LZ_MAX_BLOCK + LZ_TAIL + 16];
     __shared__ uint32_t s_cnt[16][256];
@@ -32,8 +36,6 @@ void k_lz_sort_home(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, LzS
     __shared__ uint32_t s_rot;
 
     const int tid = threadIdx.x;
-    if (bcount && blockIdx.x >= *bcount) return;          // only the listed blocks (fallback of the LDS-resident finder)
-    const uint32_t lb = blist ? blist[blockIdx.x] : blockIdx.x;
     const uint64_t off = (block0 + lb) * (uint64_t)P.block;
     const uint32_t n = (uint32_t)((n_total - off) < P.block ? (n_total - off) : P.block);
     const uint8_t *src = in + off;
@@ -170,16 +172,28 @@ void k_lz_sort_home(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, LzS
     }
 }
 
+__global__ __launch_bounds__(1024)
+void k_lz_sort_home(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, LzScratch sc, uint64_t block0, uint32_t nb,
+                    const uint32_t *__restrict__ blist, const uint32_t *__restrict__ bcount)
+{
+    const uint32_t count = bcount ? *bcount : nb;          // only the listed blocks when there is a list
+    for (uint32_t bi = blockIdx.x; bi < count; bi += gridDim.x) {
+        lz_sort_home_block(in, n_total, P, sc, block0, blist ? blist[bi] : bi);
+        __syncthreads();
+    }
+}
+
 // =============================================================================================
 // k_lz_sort_cluster: (cluster, time) order.  Input records sit at index = position, i.e. in
 // time order, so two stable passes over the 16-bit cluster number are enough.
 // =============================================================================================
 __global__ __launch_bounds__(1024)
-void k_lz_sort_cluster(LzScratch sc, const uint32_t *__restrict__ blist, const uint32_t *__restrict__ bcount)
+void k_lz_sort_cluster(LzScratch sc, uint32_t nb, const uint32_t *__restrict__ blist, const uint32_t *__restrict__ bcount)
 {
     __shared__ uint32_t s_cnt[16][256];
-    if (bcount && blockIdx.x >= *bcount) return;
-    const uint32_t lb = blist ? blist[blockIdx.x] : blockIdx.x;
+    const uint32_t count = bcount ? *bcount : nb;
+    for (uint32_t bi = blockIdx.x; bi < count; bi += gridDim.x) {
+    const uint32_t lb = blist ? blist[bi] : bi;
     const uint32_t n = sc.meta[lb].n;
     uint64_t *A = sc.eA + (size_t)lb * LZ_MAX_BLOCK;
     uint64_t *B = sc.eB + (size_t)lb * LZ_MAX_BLOCK;
@@ -191,6 +205,7 @@ void k_lz_sort_cluster(LzScratch sc, const uint32_t *__restrict__ blist, const u
         [&](uint32_t i) { return B[i]; },
         [&](uint64_t e) { return ((uint32_t)e >> 8) & 255u; },
         [&](uint32_t j, uint64_t e) { A[j] = e; });
+    }
 }
 
 // =============================================================================================
@@ -288,8 +303,7 @@ __device__ void replay_cluster(const TileView &v, uint32_t s, uint32_t e, uint32
     }
 }
 
-__global__ __launch_bounds__(512)
-void k_lz_emulate(LzP P, LzScratch sc, const uint32_t *__restrict__ blist, const uint32_t *__restrict__ bcount)
+__device__ __forceinline__ void lz_emulate_tile(LzP P, LzScratch sc, uint32_t lb, uint32_t t)
 {
     __shared__ uint16_t s_pos[LZ_TILE_CAP], s_rs[LZ_TILE_CAP], s_pid[LZ_TILE_CAP], s_occ[LZ_TILE_CAP];
     __shared__ uint32_t s_bm[LZ_TILE_CAP / 32 + 2];
@@ -297,8 +311,6 @@ void k_lz_emulate(LzP P, LzScratch sc, const uint32_t *__restrict__ blist, const
     __shared__ uint32_t s_a, s_b, s_lasthead;
 
     const int tid = threadIdx.x;
-    if (bcount && blockIdx.y >= *bcount) return;
-    const uint32_t lb = blist ? blist[blockIdx.y] : blockIdx.y, t = blockIdx.x;
     const LzBlockMeta mt = sc.meta[lb];
     const uint32_t n = mt.n;
     const uint32_t lo = t * LZ_TILE_NOM, hi = (lo + LZ_TILE_NOM < n) ? lo + LZ_TILE_NOM : n;
@@ -354,6 +366,16 @@ void k_lz_emulate(LzP P, LzScratch sc, const uint32_t *__restrict__ blist, const
         if (e - s < 2) continue;                 // a lone entry finds nothing and blocks nobody
         const bool first = (a + s) == 0;
         replay_cluster(v, s, e, W, first ? mt.anom_idx : ~0u, first ? mt.limit_idx : ~0u, cand);
+    }
+}
+
+__global__ __launch_bounds__(512)
+void k_lz_emulate(LzP P, LzScratch sc, uint32_t nb, const uint32_t *__restrict__ blist, const uint32_t *__restrict__ bcount)
+{
+    const uint32_t count = bcount ? *bcount : nb;
+    for (uint32_t bi = blockIdx.y; bi < count; bi += gridDim.y) {
+        lz_emulate_tile(P, sc, blist ? blist[bi] : bi, blockIdx.x);
+        __syncthreads();
     }
 }
 
@@ -534,22 +556,23 @@ mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t
     const int saved_prof = ctx->profiling;
     if (blist) ctx->profiling = 0;
     MI_HIP(ctx, hipMemsetAsync(sc.giant_count, 0, 4, s));
+    const uint32_t fgrid = (blist && nb > LZ_FB_GRID) ? LZ_FB_GRID : nb;     // fallback: few looping workgroups (see LZ_FB_GRID)
     {
         mi_prof_scope p(ctx, "k_lz_sort_home", s, (uint64_t)nb * P.block);
-        hipLaunchKernelGGL(k_lz_sort_home, dim3(nb), dim3(1024), 0, s, d_in, n, P, sc, block0, blist, bcount);
+        hipLaunchKernelGGL(k_lz_sort_home, dim3(fgrid), dim3(1024), 0, s, d_in, n, P, sc, block0, nb, blist, bcount);
     }
     {
         mi_prof_scope p(ctx, "k_lz_sort_cluster", s, (uint64_t)nb * P.block);
-        hipLaunchKernelGGL(k_lz_sort_cluster, dim3(nb), dim3(1024), 0, s, sc, blist, bcount);
+        hipLaunchKernelGGL(k_lz_sort_cluster, dim3(fgrid), dim3(1024), 0, s, sc, nb, blist, bcount);
     }
     {
         mi_prof_scope p(ctx, "k_lz_emulate", s, (uint64_t)nb * P.block);
         const uint32_t tiles = (P.block + LZ_TILE_NOM - 1) / LZ_TILE_NOM;
-        hipLaunchKernelGGL(k_lz_emulate, dim3(tiles, nb), dim3(512), 0, s, P, sc, blist, bcount);
+        hipLaunchKernelGGL(k_lz_emulate, dim3(tiles, fgrid), dim3(512), 0, s, P, sc, nb, blist, bcount);
     }
     {
         mi_prof_scope p(ctx, "k_lz_emulate_giant", s, (uint64_t)nb * P.block);
-        const uint32_t grid = nb < 1024 ? nb : 1024;
+        const uint32_t grid = blist ? (nb < LZ_FB_GRID ? nb : LZ_FB_GRID) : (nb < 1024 ? nb : 1024);
         hipLaunchKernelGGL(k_lz_emulate_giant, dim3(grid), dim3(256), 0, s, P, sc);
     }
     ctx->profiling = saved_prof;
