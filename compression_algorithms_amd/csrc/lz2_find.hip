@@ -30,6 +30,11 @@ __device__ void replay_small(const uint16_t *pos, uint16_t *rs, const uint16_t *
     uint32_t ev = s;
     bool anom_pending = anom != ~0u;
     const bool plain = (anom == ~0u) && (limit == ~0u);                 // not the cluster that covers bucket 0 / T
+    if (plain && (uint32_t)pos[e - 1] <= (uint32_t)pos[s] + W) {
+        // a cluster whose entries all lie within one window never evicts: no replay at all, find() = first occurrence
+        for (uint32_t i = s; i < e; ++i) { const uint32_t id = pid[i]; cand_i[i] = (id != pos[i]) ? (uint16_t)id : (uint16_t)LZ_NONE16; }
+        return;
+    }
     for (uint32_t i = s; i < e; ++i) {
         const uint32_t p = pos[i], rsv = rs[i], r = rsv & RS_MASK, id = pid[i];
         while (ev < i && (uint32_t)pos[ev] + W < p) {                   // FIFO retirement, lz77.c:70-76
@@ -308,7 +313,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     {
         // cluster heads -> compact list (order irrelevant), sizes from the next head
         __shared__ uint32_t s_ncl, s_bin[LZ2_BIG + 1], s_nquiet;
-        __shared__ uint16_t s_quiet[2 * (LZ2_CAP / 64)];     // quiet clusters of >= 64 entries: filled by a wave each, below
+        __shared__ uint16_t s_quiet[2 * LZ2_MAXBIG];         // quiet clusters of >= LZ2_BIG entries: filled by a wave each, below
         if (tid == 0) { s_ncl = 0; s_nquiet = 0; }
         if (tid <= (int)LZ2_BIG) s_bin[tid] = 0;
         __syncthreads();
@@ -323,14 +328,9 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
                 const uint32_t size = e - i;
                 my_n[c] = size;
                 // a cluster whose entries all lie within one window never evicts: no replay, find() = first occurrence
-                const bool quiet = (uint32_t)e_pos[e - 1] <= (uint32_t)e_pos[i] + W && i != s_zhead;
                 if (size == 1) cand_i[i] = LZ_NONE16;
-                else if (quiet && size < 64u) {
-                    for (uint32_t k = i; k < e; ++k) { const uint32_t id = e_pid[k]; cand_i[k] = (id != e_pos[k]) ? (uint16_t)id : (uint16_t)LZ_NONE16; }
-                    my_n[c] = 0;
-                }
-                else if (size < LZ2_BIG) atomicAdd(&s_bin[size], 1u);
-                else if (quiet) { const uint32_t q = atomicAdd(&s_nquiet, 1u); s_quiet[2 * q] = (uint16_t)i; s_quiet[2 * q + 1] = (uint16_t)e; }
+                else if (size < LZ2_BIG) atomicAdd(&s_bin[size], 1u);          // (replay_small notices a quiet cluster itself)
+                else if ((uint32_t)e_pos[e - 1] <= (uint32_t)e_pos[i] + W && i != s_zhead) { const uint32_t q = atomicAdd(&s_nquiet, 1u); s_quiet[2 * q] = (uint16_t)i; s_quiet[2 * q + 1] = (uint16_t)e; }
                 else {
                     const uint32_t q = atomicAdd(&s_nbigl, 1u);
                     if (q < LZ2_MAXBIG) { s_big[3 * q] = i; s_big[3 * q + 1] = e; }
