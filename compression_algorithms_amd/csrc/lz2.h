@@ -33,7 +33,8 @@ static_assert(LZ2_CAP % LZ2_THREADS == 0, "entries per thread must be whole");
 __host__ __device__ __forceinline__ uint32_t lz2_class_of(uint32_t cnt, uint32_t wave_min, uint32_t row_mode)
 {
     if (row_mode && cnt >= 128u) return cnt < 256u ? 3u : cnt < 512u ? 4u : cnt <= LZ2_BIG_SMALL ? 5u : 6u;
-    if (cnt >= wave_min) return cnt <= LZ2_BIG_SMALL ? 5u : 6u;
+    // wave replay: 4 = 512..1024 entries and 5 = wave_min..511 share one launch that starts the long chains first
+    if (cnt >= wave_min) return cnt > LZ2_BIG_SMALL ? 6u : cnt >= 512u ? 4u : 5u;
     return cnt < 16 ? 7u : cnt < 32 ? 0u : cnt < 64 ? 1u : cnt < 128 ? 2u : cnt < 256 ? 3u : 4u;
 }
 // cand placeholder of an entry whose cluster was exported: the entry's OWN position (a candidate is always smaller

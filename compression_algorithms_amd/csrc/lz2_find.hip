@@ -488,12 +488,13 @@ void k_lz2_big(LzP P, Lz2Scratch sc, int large)
     __shared__ uint32_t s_occ[LDS_ENTRIES];               // slot -> word id | position << 16 of its occupant
     __shared__ uint16_t s_slot[LDS_ENTRIES];              // entry -> slot (for its eviction)
     const uint32_t lane = threadIdx.x;
-    const uint32_t ncl = sc.big_count[large ? 6 : 5];
-    const Lz2BigDesc *list = sc.desc[large ? 6 : 5];
+    // a launch lasts as long as its longest cluster: the 512..1024-entry class is dispatched before the 128..511 one
+    const uint32_t nhi = large ? sc.big_count[6] : sc.big_count[4], ncl = nhi + (large ? 0u : sc.big_count[5]);
     const uint32_t W = 1u << P.wbits;
     for (uint32_t ci = blockIdx.x; ci < ncl; ci += gridDim.x) {
-        const uint32_t d_block = list[ci].block, d_start = list[ci].start, n = list[ci].count;
-        const uint32_t d_anom = list[ci].anom, d_limit = list[ci].limit;
+        const Lz2BigDesc *dp = large ? &sc.desc[6][ci] : (ci < nhi ? &sc.desc[4][ci] : &sc.desc[5][ci - nhi]);
+        const uint32_t d_block = dp->block, d_start = dp->start, n = dp->count;
+        const uint32_t d_anom = dp->anom, d_limit = dp->limit;
         const uint16_t *bp = sc.bigpos + (size_t)d_block * LZ_MAX_BLOCK + d_start;
         const uint16_t *br = sc.bigrs + (size_t)d_block * LZ_MAX_BLOCK + d_start;
         const uint16_t *bi = sc.bigpid + (size_t)d_block * LZ_MAX_BLOCK + d_start;
@@ -806,7 +807,7 @@ template __global__ void k_lz2_big<LZ2_CAP, 4>(LzP, Lz2Scratch, int);
 // clusters of class c per block, at most (a block has 65536 entries)
 static uint32_t lz2_class_cap(uint32_t c)
 {
-    static const uint32_t lo[LZ2_NCLASS] = {16, 32, 64, 128, 256, 512, 1025, 8};
+    static const uint32_t lo[LZ2_NCLASS] = {16, 32, 64, 128, 256, 128, 1025, 8};    // smallest cluster a class can hold (either mode)
     return LZ_MAX_BLOCK / lo[c] + 8;
 }
 
@@ -888,7 +889,7 @@ mi_status lz2_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &
         hipLaunchKernelGGL((k_lz2_big<LZ2_CAP, 4>), dim3(nb * lz2_class_cap(6) < 4096 ? nb * lz2_class_cap(6) : 4096), dim3(64), 0, s, P, sc, 1);
     } else {
         mi_prof_scope p(ctx, "k_lz2_big", s, (uint64_t)nb * P.block);
-        hipLaunchKernelGGL((k_lz2_big<LZ2_BIG_SMALL, 1>), dim3(nb * lz2_class_cap(5)), dim3(64), 0, s, P, sc, 0);
+        hipLaunchKernelGGL((k_lz2_big<LZ2_BIG_SMALL, 1>), dim3(nb * (lz2_class_cap(4) + lz2_class_cap(5))), dim3(64), 0, s, P, sc, 0);
         hipLaunchKernelGGL((k_lz2_big<LZ2_CAP, 4>), dim3(nb * lz2_class_cap(6) < 4096 ? nb * lz2_class_cap(6) : 4096), dim3(64), 0, s, P, sc, 1);
     }
     MI_HIP(ctx, hipGetLastError());
