@@ -24,7 +24,7 @@ struct mi_prof_entry {
 
 struct mi_ctx {
     int         device = 0;
-    hipStream_t stream = nullptr;       // the context's own stream
+    hipStream_t stream = nullptr;       // the context's own stream (host-buffer entry points; created on first use: mi_host_stream)
     hipStream_t side = nullptr;         // second stream: overlaps the replay/parse of batch i with the find of batch i+1
     hipStream_t fb = nullptr;           // low priority: the (normally empty) fallback chain must not hold LDS-hungry launches in front of real work
     hipStream_t parse = nullptr;        // third stage: parse / emit / concatenate
@@ -55,6 +55,8 @@ struct mi_ctx {
 
 // grow the context workspace to at least `bytes` (256-byte aligned carve-outs are the caller's job)
 mi_status mi_ws_reserve(mi_ctx *ctx, size_t bytes);
+// the context's own stream for the host-buffer entry points, created on first use
+hipStream_t mi_host_stream(mi_ctx *ctx);
 
 // profiling: bracket a launch with events on the launch stream
 struct mi_prof_scope {

@@ -16,7 +16,7 @@ extern "C" mi_status mi_huffman_encode2(mi_ctx *ctx, const uint8_t *h_in, uint64
                                         mi_huffman_info *h_info, mi_huffman_tree *h_tree, uint64_t *h_tile_off)
 {
     if (!ctx || !h_words || !h_info || (n && !h_in)) return MI_ERR_ARG;
-    hipStream_t s = ctx->stream;
+    hipStream_t s = mi_host_stream(ctx);
     const uint64_t ntiles = (n + MI_HUFFMAN_TILE - 1) / MI_HUFFMAN_TILE;
     DevBuf in, words, info, tree, toff;
     if (!in.alloc(n + 16) || !words.alloc(cap_words * 4) || !info.alloc(sizeof(mi_huffman_info)) ||
@@ -41,7 +41,7 @@ extern "C" mi_status mi_huffman_decode(mi_ctx *ctx, const uint32_t *h_words, uin
 {
     if (!ctx || !h_words || !h_tree || (n && !h_out)) return MI_ERR_ARG;
     if (n == 0) return MI_OK;
-    hipStream_t s = ctx->stream;
+    hipStream_t s = mi_host_stream(ctx);
     const uint64_t nw = (total_bits + 31) >> 5, ntiles = (n + MI_HUFFMAN_TILE - 1) / MI_HUFFMAN_TILE;
     DevBuf words, tree, toff, out;
     if (!words.alloc((nw + 2) * 4) || !tree.alloc(sizeof(mi_huffman_tree)) || !toff.alloc((ntiles + 1) * 8) || !out.alloc(n + 16))
@@ -62,7 +62,7 @@ extern "C" mi_status mi_lz_decode(mi_ctx *ctx, const mi_lz_params *p, const uint
 {
     if (!ctx || !p || !h_stream || !h_block_bits || (n && !h_out) || !p->block) return MI_ERR_ARG;
     if (n == 0) return MI_OK;
-    hipStream_t s = ctx->stream;
+    hipStream_t s = mi_host_stream(ctx);
     const uint64_t nblocks = (n + p->block - 1) / p->block;
     DevBuf st_, bits, out;
     if (!st_.alloc(stream_bytes + 64) || !bits.alloc((nblocks + 1) * 8) || !out.alloc(n + 16)) return MI_ERR_NOMEM;
@@ -79,7 +79,7 @@ extern "C" mi_status mi_deflate_h_encode(mi_ctx *ctx, const mi_lz_params *p, con
                                          uint8_t *h_out, uint64_t cap_bytes, uint64_t *h_block_bits)
 {
     if (!ctx || !p || !h_out || !h_block_bits || (n && !h_in) || !p->block) return MI_ERR_ARG;
-    hipStream_t s = ctx->stream;
+    hipStream_t s = mi_host_stream(ctx);
     const uint64_t nblocks = (n + p->block - 1) / p->block, bound = mi_deflate_h_bound_bytes(n);
     DevBuf in, out, bits;
     if (!in.alloc(n + 64) || !out.alloc(bound + 64) || !bits.alloc((nblocks + 1) * 8)) return MI_ERR_NOMEM;
@@ -99,7 +99,7 @@ extern "C" mi_status mi_deflate_h_decode(mi_ctx *ctx, const mi_lz_params *p, con
 {
     if (!ctx || !p || !h_stream || !h_block_bits || (n && !h_out) || !p->block) return MI_ERR_ARG;
     if (n == 0) return MI_OK;
-    hipStream_t s = ctx->stream;
+    hipStream_t s = mi_host_stream(ctx);
     const uint64_t nblocks = (n + p->block - 1) / p->block;
     if (h_block_bits[nblocks] / 8 > stream_bytes) return MI_ERR_CORRUPT;
     DevBuf st_, bits, out;
@@ -117,7 +117,7 @@ extern "C" mi_status mi_fse_encode(mi_ctx *ctx, const mi_fse_params *p, const ui
                                    uint64_t cap_bytes, uint64_t *h_offsets)
 {
     if (!ctx || !p || !h_packed || !h_offsets || (n && !h_in) || !p->block) return MI_ERR_ARG;
-    hipStream_t s = ctx->stream;
+    hipStream_t s = mi_host_stream(ctx);
     const uint64_t nblocks = (n + p->block - 1) / p->block, need = nblocks * mi_fse_block_bound(p);
     if (cap_bytes < need) return MI_ERR_CAPACITY;
     DevBuf in, out, offs;
@@ -137,7 +137,7 @@ extern "C" mi_status mi_fse_decode(mi_ctx *ctx, const mi_fse_params *p, const ui
 {
     if (!ctx || !p || !h_packed || !h_offsets || (n && !h_out) || !p->block) return MI_ERR_ARG;
     if (n == 0) return MI_OK;
-    hipStream_t s = ctx->stream;
+    hipStream_t s = mi_host_stream(ctx);
     const uint64_t nblocks = (n + p->block - 1) / p->block, bytes = h_offsets[nblocks] / 8;
     DevBuf in, offs, out;
     if (!in.alloc(bytes + 16) || !offs.alloc((nblocks + 1) * 8) || !out.alloc(n + 16)) return MI_ERR_NOMEM;

@@ -384,7 +384,7 @@ extern "C" mi_status mi_huffman_encode(mi_ctx *ctx, const uint8_t *h_in, uint64_
                                        uint64_t cap_words, mi_huffman_info *h_info, mi_huffman_tree *h_tree)
 {
     if (!ctx || !h_words || !h_info || (n && !h_in)) return MI_ERR_ARG;
-    hipStream_t s = ctx->stream;
+    hipStream_t s = mi_host_stream(ctx);
     uint8_t *d_in = nullptr; uint32_t *d_words = nullptr; mi_huffman_info *d_info = nullptr; mi_huffman_tree *d_tree = nullptr;
     mi_status st = MI_OK;
     // reserve the kernels' workspace first: growing it later would synchronise mid-sequence

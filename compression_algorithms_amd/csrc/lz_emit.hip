@@ -518,7 +518,7 @@ extern "C" mi_status mi_lz_encode(mi_ctx *ctx, const mi_lz_params *p, const uint
     if (cap_bytes < bound) return MI_ERR_CAPACITY;
     uint8_t *d_in = nullptr, *d_out = nullptr; uint64_t *d_bits = nullptr;
     mi_status st = MI_OK;
-    hipStream_t s = ctx->stream;
+    hipStream_t s = mi_host_stream(ctx);
     if (hipMalloc(&d_in, n + 64) != hipSuccess || hipMalloc(&d_out, bound + 64) != hipSuccess ||
         hipMalloc(&d_bits, (nblocks + 1) * 8) != hipSuccess) st = MI_ERR_NOMEM;
     if (st == MI_OK && n && hipMemcpyAsync(d_in, h_in, n, hipMemcpyHostToDevice, s) != hipSuccess) st = MI_ERR_HIP;
