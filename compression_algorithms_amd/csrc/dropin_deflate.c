@@ -26,10 +26,16 @@ StateData compress(const char *input_filename)
     uint64_t n; char *in = slurp(input_filename, &n);
     mi_ctx *ctx = dropin_ctx();
     mi_lz_params p = mi_lz_params_deflate();
-    const uint64_t nblocks = mi_lz_num_blocks(n, &p), cap = mi_lz_bound_bytes(n, &p) + 64;
+    /* MI_DEFLATE_MODE=H: finish what lz77.c:279 leaves as a TODO — the same tokens, Huffman coded per block
+     * (include/mi_codec.h "mode H").  Default: the reference's raw token bytes. */
+    const char *mode = getenv("MI_DEFLATE_MODE");
+    const int mode_h = mode && (mode[0] == 'H' || mode[0] == 'h');
+    const uint64_t nblocks = mi_lz_num_blocks(n, &p);
+    const uint64_t cap = (mode_h ? mi_deflate_h_bound_bytes(n) : mi_lz_bound_bytes(n, &p)) + 64;
     uint8_t *out = (uint8_t *)malloc(cap); uint64_t *bits = (uint64_t *)malloc(8 * (nblocks + 1));
     struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
-    mi_status st = mi_lz_encode(ctx, &p, (const uint8_t *)in, n, out, cap, bits);
+    mi_status st = mode_h ? mi_deflate_h_encode(ctx, &p, (const uint8_t *)in, n, out, cap, bits)
+                          : mi_lz_encode(ctx, &p, (const uint8_t *)in, n, out, cap, bits);
     clock_gettime(CLOCK_MONOTONIC, &t1);
     if (st != MI_OK) { fprintf(stderr, "compress: %s\n", mi_status_str(st)); exit(1); }
     FILE *f = fopen(sd.compressed_filename, "wb");
@@ -38,7 +44,8 @@ StateData compress(const char *input_filename)
     char *idx = (char *)malloc(strlen(sd.compressed_filename) + 5);
     strcpy(idx, sd.compressed_filename); strcat(idx, ".idx");
     f = fopen(idx, "wb");
-    if (f) { uint64_t hdr[3] = { n, p.block, nblocks }; fwrite(hdr, 8, 3, f); fwrite(bits, 8, nblocks + 1, f); fclose(f); }
+    /* side-car: original size, block size | mode H flag << 32, block count, then the per-block bit offsets */
+    if (f) { uint64_t hdr[3] = { n, p.block | ((uint64_t)mode_h << 32), nblocks }; fwrite(hdr, 8, 3, f); fwrite(bits, 8, nblocks + 1, f); fclose(f); }
     const double sec = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
     printf("MB/s: %f\n", (double)n / (1024 * 1024) / sec);     /* deflate.c:65 */
     free(idx); free(in); free(out); free(bits);
@@ -54,8 +61,10 @@ void decompress(StateData *sd, const char *input_filename)
     const uint64_t n = h[0], nblocks = h[2];
     uint64_t csz; char *cb = slurp(name, &csz);
     mi_lz_params p = mi_lz_params_deflate(); p.block = (uint32_t)h[1];
+    const int mode_h = (int)((h[1] >> 32) & 1u);
     uint8_t *out = (uint8_t *)malloc(n ? n : 1);
-    mi_status st = mi_lz_decode(dropin_ctx(), &p, (const uint8_t *)cb, csz, h + 3, out, n);
+    mi_status st = mode_h ? mi_deflate_h_decode(dropin_ctx(), &p, (const uint8_t *)cb, csz, h + 3, out, n)
+                          : mi_lz_decode(dropin_ctx(), &p, (const uint8_t *)cb, csz, h + 3, out, n);
     if (st != MI_OK) { fprintf(stderr, "decompress: %s\n", mi_status_str(st)); exit(1); }
     char *on = (char *)malloc(strlen(name) + 6); strcpy(on, name); strcat(on, ".orig");
     FILE *f = fopen(on, "wb");

@@ -11,6 +11,11 @@
  * in the current directory: the token bytes, exactly what the reference's per-block
  * lz77_compress emits.  A side-car "<basename>.deflate.idx" (original size, block size,
  * per-block byte offsets) makes the stream decodable; the reference's decompress() is empty.
+ *
+ * MI_DEFLATE_MODE=H in the environment makes compress() finish the stage the reference leaves as
+ * "// TODO: Build huffman tree and encode compressed buffer" (deflate/lz77.c:279): the same
+ * tokens, Huffman coded per block over the reference's 286-symbol alphabet (mi_codec.h, "mode
+ * H").  The side-car records the mode, so decompress() needs no switch.
  */
 #ifndef MI_DEFLATE_H
 #define MI_DEFLATE_H

@@ -155,3 +155,36 @@ def test_fse_c_entry_points():
     back = np.zeros(len(data), dtype=np.uint8)
     assert L.fse_decompress(out.ctypes.data_as(C.c_void_p), m, back.ctypes.data_as(C.c_void_p), len(back)) == len(data)
     assert np.array_equal(back, data)
+
+
+@pytest.mark.gpu
+def test_deflate_compress_file_mode_h(tmp_path, monkeypatch):
+    """MI_DEFLATE_MODE=H: compress() writes the Huffman-coded records (the stage the reference leaves as a TODO,
+    deflate/lz77.c:279), decompress() restores the file; the records are the oracle's (oracle/orc_defh.c)."""
+    from oracle import orc
+    L = _load("deflate")
+
+    class StateData(C.Structure):
+        _fields_ = [("table", C.c_void_p), ("huffman_root", C.c_void_p), ("compressed_filename", C.c_char_p)]
+
+    L.compress.restype = StateData
+    L.compress.argtypes = [C.c_char_p]
+    L.decompress.argtypes = [C.POINTER(StateData), C.c_char_p]
+    data = synth.enwik_like(200_000, seed=8).numpy()
+    src = tmp_path / "data" / "enwik_h"
+    src.parent.mkdir()
+    data.tofile(src)
+    monkeypatch.setenv("MI_DEFLATE_MODE", "H")
+    monkeypatch.chdir(tmp_path)
+    sd = L.compress(str(src).encode())
+    got = np.fromfile(tmp_path / "enwik_h.deflate", dtype=np.uint8)
+    d = orc.Deflate(65536)
+    recs = []
+    for at in range(0, len(data), 65536):
+        d.fresh()
+        recs.append(orc.defh_encode_block(d.block_encode(data[at:at + 65536])))
+    assert np.array_equal(got, np.concatenate(recs))
+    assert len(got) < 0.6 * len(data)
+    monkeypatch.delenv("MI_DEFLATE_MODE")                 # the side-car says which decoder to use
+    L.decompress(C.byref(sd), None)
+    assert np.array_equal(np.fromfile(tmp_path / "enwik_h.deflate.orig", dtype=np.uint8), data)
