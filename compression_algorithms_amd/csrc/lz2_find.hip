@@ -72,6 +72,44 @@ __device__ void replay_small(const uint16_t *pos, uint16_t *rs, const uint16_t *
     }
 }
 
+// The same replay for a cluster of < 8 entries that does not cover bucket 0 / T, with its whole table in registers:
+// 7 occupancy bits, the occupant of every slot and the slot of every entry as 4-bit fields.  LDS is only read for the
+// entry records (and for an occupant's word id when a probe has to compare) and written for the result.
+__device__ __forceinline__ void replay_small_reg(const uint16_t *pos, const uint16_t *rs, const uint16_t *pid,
+                                                 uint32_t s, uint32_t e, uint32_t W, uint16_t *cand_i)
+{
+    if ((uint32_t)pos[e - 1] <= (uint32_t)pos[s] + W) {
+        // a cluster whose entries all lie within one window never evicts: no replay at all, find() = first occurrence
+        for (uint32_t i = s; i < e; ++i) { const uint32_t id = pid[i]; cand_i[i] = (id != pos[i]) ? (uint16_t)id : (uint16_t)LZ_NONE16; }
+        return;
+    }
+    const uint32_t n = e - s;
+    uint32_t mask = 0, ent = 0, slots = 0;
+    uint32_t ev = 0, ev_pos = pos[s];
+    for (uint32_t li = 0; li < n; ++li) {
+        const uint32_t i = s + li;
+        const uint32_t p = pos[i], rr = ((uint32_t)rs[i] & RS_MASK) - s, id = pid[i];
+        while (ev < li && ev_pos + W < p) {                              // FIFO retirement, lz77.c:70-76
+            mask &= ~(1u << ((slots >> (4u * ev)) & 15u));
+            ++ev; ev_pos = pos[s + ev];
+        }
+        uint32_t res = LZ_NONE16;
+        if (ev == 0) {                                                  // nothing evicted yet: the first occurrence (see the sweep)
+            if (id != p) res = id;
+        } else {
+            for (uint32_t b = rr; (mask >> b) & 1u; ++b) {              // bits >= n are never set: the probe ends inside the cluster
+                const uint32_t o = s + ((ent >> (4u * b)) & 15u);
+                if (pid[o] == id) { res = pos[o]; break; }
+            }
+        }
+        cand_i[i] = (uint16_t)res;
+        const uint32_t b = rr + (uint32_t)__builtin_ctz(~(mask >> rr));  // first fit (inside the cluster by the parking bound)
+        mask |= 1u << b;
+        ent = (ent & ~(15u << (4u * b))) | (li << (4u * b));
+        slots |= b << (4u * li);
+    }
+}
+
 __global__ __launch_bounds__(LZ2_THREADS)
 void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scratch sc, uint64_t block0)
 {
@@ -358,7 +396,8 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
             uint32_t e = s + 1;
             while (e < m && !(e_rs[e] & RS_HEAD)) ++e;
             const bool zc = (s == s_zhead);
-            replay_small(e_pos, e_rs, e_pid, occ, s_bm, s, e, W, zc ? s_zslot : ~0u, (zc && P.deflate) ? s_zslot : ~0u, cand_i);
+            if (zc) replay_small(e_pos, e_rs, e_pid, occ, s_bm, s, e, W, s_zslot, P.deflate ? s_zslot : ~0u, cand_i);
+            else replay_small_reg(e_pos, e_rs, e_pid, s, e, W, cand_i);
         }
     }
     __syncthreads();
