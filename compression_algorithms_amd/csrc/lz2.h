@@ -23,6 +23,11 @@ static_assert(LZ2_CAP % LZ2_THREADS == 0, "entries per thread must be whole");
 #define LZ2_BIG       8u                    // clusters of at least this many entries leave k_lz2_find
 #define LZ2_WAVE      128u                  // ... and from this size on a whole wave replays one cluster
 #define LZ2_MAXBIG    (LZ2_CAP / LZ2_BIG)   // exported clusters per part, at most
+// Exported clusters start on 8-entry boundaries of the block's big arrays (the lane replay loads and stores 16 bytes =
+// 8 entries at a time).  <= 65536 entries in <= 8192 clusters, <= 7 pad entries each: 2 x 65536 slots always suffice.
+// A pad entry carries position 0 and result 0; consumers skip pairs whose result equals their position (lz2.h below).
+#define LZ2_BIG_STRIDE (2u * LZ_MAX_BLOCK)
+#define LZ2_ALIGN8(x)  (((x) + 7u) & ~7u)
 #define LZ2_DESC_SMALL (LZ_MAX_BLOCK / LZ2_BIG + 32u)   // exported clusters per block, at most
 // export classes: 7: 8..15, 0: 16..31, 1: 32..63, 2: 64..127 entries (a lane per cluster, 64 clusters per wave);
 //                 5: 128..1024, 6: > 1024 (a wave per cluster); 3 and 4 (lane replay of 128..511) exist but are not fed
@@ -64,7 +69,7 @@ struct Lz2Scratch {
     uint16_t     *cand;         // [nb][65536] find() result aligned with plist (own position = pending: see bigcand)
     Lz2BlockMeta *meta;         // [nb]
     uint32_t     *fallback_count, *fallback_list;    // blocks the first pipeline has to do
-    uint16_t     *bigpos, *bigrs, *bigpid, *bigcand; // [nb][65536] entries of exported clusters, (cluster, time) order
+    uint16_t     *bigpos, *bigrs, *bigpid, *bigcand; // [nb][LZ2_BIG_STRIDE] entries of exported clusters, (cluster, time) order
     Lz2BigDesc   *desc[LZ2_NCLASS];                  // per class: [nb * capacity of the class]
     uint32_t     *big_count;                         // [LZ2_NCLASS]
     uint64_t     *dbg;                               // phase cycle counters (MI_LZ_DEBUG=1), else NULL

@@ -417,7 +417,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
             const uint32_t cnt = s_big[3 * q + 1] - s_big[3 * q];
             const uint32_t cls = lz2_class_of(cnt, sc.wave_min, sc.row_mode);
             my_rank[it] = atomicAdd(&s_cls[cls], 1u);
-            my_dst[it] = atomicAdd(&s_ent, cnt);
+            my_dst[it] = atomicAdd(&s_ent, LZ2_ALIGN8(cnt));            // every cluster starts on an 8-entry boundary
         }
     }
     __syncthreads();
@@ -443,15 +443,17 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     __syncthreads();
     for (uint32_t b = tid >> 6; b < nbig; b += LZ2_NWAVES) {          // a wave per exported cluster
         const uint32_t s = s_big[3 * b], e = s_big[3 * b + 1], dst = s_big[3 * b + 2];
-        uint16_t *bp = sc.bigpos + (size_t)lb * LZ_MAX_BLOCK + dst;
-        uint16_t *br = sc.bigrs + (size_t)lb * LZ_MAX_BLOCK + dst;
-        uint16_t *bi = sc.bigpid + (size_t)lb * LZ_MAX_BLOCK + dst;
+        uint16_t *bp = sc.bigpos + (size_t)lb * LZ2_BIG_STRIDE + dst;
+        uint16_t *br = sc.bigrs + (size_t)lb * LZ2_BIG_STRIDE + dst;
+        uint16_t *bi = sc.bigpid + (size_t)lb * LZ2_BIG_STRIDE + dst;
         for (uint32_t i = s + (tid & 63); i < e; i += 64) {
             cand_i[i] = e_pos[i];                                // pending (lz2.h)
             bp[i - s] = e_pos[i];
             br[i - s] = (uint16_t)((e_rs[i] & RS_MASK) - s);    // home slot relative to the cluster
             bi[i - s] = e_pid[i];
         }
+        uint16_t *bc = sc.bigcand + (size_t)lb * LZ2_BIG_STRIDE + dst;
+        for (uint32_t k = (e - s) + (tid & 63); k < LZ2_ALIGN8(e - s); k += 64) { bp[k] = 0; bc[k] = 0; }    // pads: skipped by every consumer
     }
     // ---- cand back to time order and out (coalesced)
     uint16_t *cand_j = s_pid;
@@ -534,10 +536,10 @@ void k_lz2_big(LzP P, Lz2Scratch sc, int large)
         const Lz2BigDesc *dp = large ? &sc.desc[6][ci] : (ci < nhi ? &sc.desc[4][ci] : &sc.desc[5][ci - nhi]);
         const uint32_t d_block = dp->block, d_start = dp->start, n = dp->count;
         const uint32_t d_anom = dp->anom, d_limit = dp->limit;
-        const uint16_t *bp = sc.bigpos + (size_t)d_block * LZ_MAX_BLOCK + d_start;
-        const uint16_t *br = sc.bigrs + (size_t)d_block * LZ_MAX_BLOCK + d_start;
-        const uint16_t *bi = sc.bigpid + (size_t)d_block * LZ_MAX_BLOCK + d_start;
-        uint16_t *bc = sc.bigcand + (size_t)d_block * LZ_MAX_BLOCK + d_start;
+        const uint16_t *bp = sc.bigpos + (size_t)d_block * LZ2_BIG_STRIDE + d_start;
+        const uint16_t *br = sc.bigrs + (size_t)d_block * LZ2_BIG_STRIDE + d_start;
+        const uint16_t *bi = sc.bigpid + (size_t)d_block * LZ2_BIG_STRIDE + d_start;
+        uint16_t *bc = sc.bigcand + (size_t)d_block * LZ2_BIG_STRIDE + d_start;
         WaveBitmap<NW> bm;
         bm.clear();
         uint32_t ev = 0;
@@ -638,10 +640,10 @@ void k_lz2_row(LzP P, Lz2Scratch sc)
     d.block = 0; d.start = 0; d.count = 0; d.anom = ~0u; d.limit = ~0u;
     if (ci < ncl) d = sc.desc[cls][ci];
     const uint32_t n = d.count <= (uint32_t)LDS_ENTRIES ? d.count : 0u, W = 1u << P.wbits;
-    const uint16_t *bp = sc.bigpos + (size_t)d.block * LZ_MAX_BLOCK + d.start;
-    const uint16_t *br = sc.bigrs + (size_t)d.block * LZ_MAX_BLOCK + d.start;
-    const uint16_t *bi = sc.bigpid + (size_t)d.block * LZ_MAX_BLOCK + d.start;
-    uint16_t *bc = sc.bigcand + (size_t)d.block * LZ_MAX_BLOCK + d.start;
+    const uint16_t *bp = sc.bigpos + (size_t)d.block * LZ2_BIG_STRIDE + d.start;
+    const uint16_t *br = sc.bigrs + (size_t)d.block * LZ2_BIG_STRIDE + d.start;
+    const uint16_t *bi = sc.bigpid + (size_t)d.block * LZ2_BIG_STRIDE + d.start;
+    uint16_t *bc = sc.bigcand + (size_t)d.block * LZ2_BIG_STRIDE + d.start;
     uint32_t *occ = s_occ[row];
     uint16_t *slot = s_slot[row];
     uint32_t w[NWR];
@@ -746,6 +748,13 @@ template <> struct SlotType<false> { typedef uint16_t type; };
 // fetched four steps ahead ran 19 % faster alone (6.76 ms) and cost the pipeline 2 % (11.24 vs 11.46: the export in
 // k_lz2_find writes twice the bytes); lane replay of 128..511-entry clusters was 4x slower than the wave replay (one
 // wave per CU).  All three were removed.
+__device__ __forceinline__ uint32_t u16_of(const uint4 &v, uint32_t k)      // k-th 16-bit element of a 16-byte vector
+{
+    // two 64-bit halves and a variable shift: a select chain on the four dwords is turned into an indexed scratch access
+    const uint64_t lo = (uint64_t)v.x | ((uint64_t)v.y << 32), hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    return (uint32_t)(((k & 4u) ? hi : lo) >> ((k & 3u) * 16u)) & 0xFFFFu;
+}
+
 template <int CMAX, int LANES>
 __global__ __launch_bounds__(64)
 void k_lz2_mid_direct(LzP P, Lz2Scratch sc, int cls)
@@ -760,58 +769,71 @@ void k_lz2_mid_direct(LzP P, Lz2Scratch sc, int cls)
     const uint32_t ci = blockIdx.x * (uint32_t)LANES + lane;
     if (blockIdx.x * (uint32_t)LANES >= ncl) return;
     const bool active = ci < ncl && lane < (uint32_t)LANES;
-    Lz2BigDesc d;
-    d.block = 0; d.start = 0; d.count = 0; d.anom = ~0u; d.limit = ~0u;
-    if (active) d = sc.desc[cls][ci];
+    struct { uint32_t block, start, count, anom, limit; } d = {0u, 0u, 0u, ~0u, ~0u};
+    if (active) { const Lz2BigDesc *dp = &sc.desc[cls][ci]; d.block = dp->block; d.start = dp->start; d.count = dp->count; d.anom = dp->anom; d.limit = dp->limit; }
     const uint32_t n = d.count, W = 1u << P.wbits;
-    const uint16_t *bp = sc.bigpos + (size_t)d.block * LZ_MAX_BLOCK + d.start;
-    const uint16_t *br = sc.bigrs + (size_t)d.block * LZ_MAX_BLOCK + d.start;
-    const uint16_t *bi = sc.bigpid + (size_t)d.block * LZ_MAX_BLOCK + d.start;
-    uint16_t *bc = sc.bigcand + (size_t)d.block * LZ_MAX_BLOCK + d.start;
+    // Every lane walks its own cluster, so nothing coalesces, and 2-byte loads cost a cache line each: rocprofv3 showed
+    // 1.5 GB of HBM traffic per launch against 60 MB of entries (the lines do not survive in L1 between steps).  Clusters
+    // start on 16-byte boundaries (lz2.h), so a lane fetches EIGHT entries per load and stores eight results at once.
+    const uint4 *vp = reinterpret_cast<const uint4 *>(sc.bigpos + (size_t)d.block * LZ2_BIG_STRIDE + d.start);
+    const uint4 *vr = reinterpret_cast<const uint4 *>(sc.bigrs + (size_t)d.block * LZ2_BIG_STRIDE + d.start);
+    const uint4 *vi = reinterpret_cast<const uint4 *>(sc.bigpid + (size_t)d.block * LZ2_BIG_STRIDE + d.start);
+    uint4 *vc = reinterpret_cast<uint4 *>(sc.bigcand + (size_t)d.block * LZ2_BIG_STRIDE + d.start);
     const uint32_t lr = lane < (uint32_t)LANES ? lane : 0u;  // surplus lanes (LANES < 64) idle on region 0: n = 0
     uint32_t *occ = s_occ + lr * STRIDE;
     slot_t *slot = s_slot + lr * STRIDE;
     uint32_t *bits = s_bits + lr * (CMAX / 32 + 1);
     if (lane < (uint32_t)LANES) for (int k = 0; k < CMAX / 32 + 1; ++k) bits[k] = 0;
-    uint32_t ev = 0, ev_p = active && n ? bp[0] : 0u;
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    uint4 evw = zero4;                                     // positions of entries [ev & ~7, +8): the next to retire
+    if (n) evw = vp[0];
+    uint32_t ev = 0, ev_p = evw.x & 0xFFFFu;
     bool anom_pending = d.anom != ~0u;
     const bool plain = d.anom == ~0u && d.limit == ~0u;    // not the cluster that covers bucket 0 / T
-    // entry fields are fetched one step ahead: each lane walks its own cluster, so these loads do not coalesce
-    // and their latency would otherwise sit on every step
-    uint32_t nx_p = 0, nx_r = 0, nx_id = 0;
-    if (n) { nx_p = bp[0]; nx_r = br[0]; nx_id = bi[0]; }
-    for (uint32_t i = 0; i < (uint32_t)CMAX; ++i) {
-        if (__ballot(i < n) == 0ull) break;                 // every cluster of this wave is done
-        if (i >= n) continue;                              // lanes with shorter clusters idle (same size class: < 2x)
-        const uint32_t p = nx_p, r = nx_r, id = nx_id;
-        if (i + 1 < n) { nx_p = bp[i + 1]; nx_r = br[i + 1]; nx_id = bi[i + 1]; }
-        while (ev < i && ev_p + W < p) {                   // FIFO retirement
-            const uint32_t b = slot[ev];
-            bits[b >> 5] &= ~(1u << (b & 31u));
-            ++ev; ev_p = bp[ev];
-        }
-        if (anom_pending && p > W - 1u) { bits[d.anom >> 5] &= ~(1u << (d.anom & 31u)); anom_pending = false; }
-        uint32_t wi = r >> 5;
-        const uint32_t w0 = bits[wi];
-        uint32_t res = LZ_NONE16;
-        if (plain && ev == 0) {                            // nothing evicted yet: find() = the word's first occurrence,
-            if (id != p) res = id;                         // which is what the word id is (k_lz2_find, the sweep)
-        } else if ((w0 >> (r & 31u)) & 1u) {
-            for (uint32_t b = r;; ++b) {
-                if (b != r) {
-                    if (b == d.limit && r < d.limit) break;
-                    if (!((bits[b >> 5] >> (b & 31u)) & 1u)) break;
+    uint4 np = evw, nr = zero4, ni = zero4;                // the group after the current one is in flight
+    if (n) { nr = vr[0]; ni = vi[0]; }
+    for (uint32_t i0 = 0; i0 < (uint32_t)CMAX; i0 += 8) {
+        if (__ballot(i0 < n) == 0ull) break;                // every cluster of this wave is done
+        const uint4 cp = np, cr = nr, cid = ni;
+        if (i0 + 8 < n) { np = vp[(i0 >> 3) + 1]; nr = vr[(i0 >> 3) + 1]; ni = vi[(i0 >> 3) + 1]; }
+        uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            const uint32_t i = i0 + k;
+            if (i < n) {                                   // lanes with shorter clusters idle (same size class: < 2x)
+                const uint32_t p = u16_of(cp, k), r = u16_of(cr, k), id = u16_of(cid, k);
+                while (ev < i && ev_p + W < p) {           // FIFO retirement
+                    const uint32_t b = slot[ev];
+                    bits[b >> 5] &= ~(1u << (b & 31u));
+                    ++ev;
+                    if ((ev & 7u) == 0) evw = vp[ev >> 3];
+                    ev_p = u16_of(evw, ev & 7u);
                 }
-                const uint32_t o = occ[b];
-                if ((o & 0xFFFFu) == id) { res = o >> 16; break; }
+                if (anom_pending && p > W - 1u) { bits[d.anom >> 5] &= ~(1u << (d.anom & 31u)); anom_pending = false; }
+                uint32_t wi = r >> 5;
+                const uint32_t w0 = bits[wi];
+                uint32_t res = LZ_NONE16;
+                if (plain && ev == 0) {                    // nothing evicted yet: find() = the word's first occurrence,
+                    if (id != p) res = id;                 // which is what the word id is (k_lz2_find, the sweep)
+                } else if ((w0 >> (r & 31u)) & 1u) {
+                    for (uint32_t b = r;; ++b) {
+                        if (b != r) {
+                            if (b == d.limit && r < d.limit) break;
+                            if (!((bits[b >> 5] >> (b & 31u)) & 1u)) break;
+                        }
+                        const uint32_t o = occ[b];
+                        if ((o & 0xFFFFu) == id) { res = o >> 16; break; }
+                    }
+                }
+                { const uint32_t v = res << ((k & 1u) * 16u); if (k < 2) o0 |= v; else if (k < 4) o1 |= v; else if (k < 6) o2 |= v; else o3 |= v; }
+                uint32_t wv = w0 | ((1u << (r & 31u)) - 1u);
+                while (wv == 0xFFFFFFFFu) wv = bits[++wi];
+                const uint32_t b = (wi << 5) + (uint32_t)__builtin_ctz(~wv);
+                bits[b >> 5] |= 1u << (b & 31u);
+                occ[b] = id | (p << 16); slot[i] = (slot_t)b;
             }
         }
-        bc[i] = (uint16_t)res;
-        uint32_t wv = w0 | ((1u << (r & 31u)) - 1u);
-        while (wv == 0xFFFFFFFFu) wv = bits[++wi];
-        const uint32_t b = (wi << 5) + (uint32_t)__builtin_ctz(~wv);
-        bits[b >> 5] |= 1u << (b & 31u);
-        occ[b] = id | (p << 16); slot[i] = (slot_t)b;
+        if (i0 < n) vc[i0 >> 3] = make_uint4(o0, o1, o2, o3);      // pads of the last group: 0 (= skipped, lz2.h)
     }
 }
 
@@ -828,8 +850,8 @@ void k_lz2_scatter(Lz2Scratch sc, uint16_t *__restrict__ cand_by_pos /* [nb][655
     for (uint32_t j = threadIdx.x; j < n; j += 1024) { const uint32_t c = cd[j], p = pl[j]; if (c != p || p == LZ_NONE16) out[p] = (uint16_t)c; }
     __syncthreads();                                                     // position 0xFFFF: "none" first, the exported result over it
     const uint32_t nb = mt->nbig_entries;
-    const uint16_t *bp = sc.bigpos + (size_t)lb * LZ_MAX_BLOCK, *bc = sc.bigcand + (size_t)lb * LZ_MAX_BLOCK;
-    for (uint32_t j = threadIdx.x; j < nb; j += 1024) out[bp[j]] = bc[j];
+    const uint16_t *bp = sc.bigpos + (size_t)lb * LZ2_BIG_STRIDE, *bc = sc.bigcand + (size_t)lb * LZ2_BIG_STRIDE;
+    for (uint32_t j = threadIdx.x; j < nb; j += 1024) { const uint32_t p = bp[j], c = bc[j]; if (c != p) out[p] = (uint16_t)c; }    // c == p: a pad
 }
 
 template __global__ void k_lz2_mid_direct<16, 64>(LzP, Lz2Scratch, int);
@@ -852,7 +874,7 @@ static uint32_t lz2_class_cap(uint32_t c)
 
 size_t lz2_scratch_bytes(uint32_t nb)
 {
-    return (size_t)nb * (LZ_MAX_BLOCK * 2 * 6 + sizeof(Lz2BlockMeta) + 4 + 3 * LZ2_DESC_SMALL * sizeof(Lz2BigDesc)) + 16 * 256 + 4096;
+    return (size_t)nb * (LZ_MAX_BLOCK * 2 * 2 + LZ2_BIG_STRIDE * 2 * 4 + sizeof(Lz2BlockMeta) + 4 + 3 * LZ2_DESC_SMALL * sizeof(Lz2BigDesc)) + 16 * 256 + 4096;
 }
 
 void lz2_carve(mi_carver &cv, uint32_t nb, Lz2Scratch *sc)
@@ -862,10 +884,10 @@ void lz2_carve(mi_carver &cv, uint32_t nb, Lz2Scratch *sc)
     sc->meta = cv.take<Lz2BlockMeta>(nb);
     sc->fallback_count = cv.take<uint32_t>(64);
     sc->fallback_list = cv.take<uint32_t>(nb);
-    sc->bigpos = cv.take<uint16_t>((size_t)nb * LZ_MAX_BLOCK);
-    sc->bigrs = cv.take<uint16_t>((size_t)nb * LZ_MAX_BLOCK);
-    sc->bigpid = cv.take<uint16_t>((size_t)nb * LZ_MAX_BLOCK);
-    sc->bigcand = cv.take<uint16_t>((size_t)nb * LZ_MAX_BLOCK);
+    sc->bigpos = cv.take<uint16_t>((size_t)nb * LZ2_BIG_STRIDE);
+    sc->bigrs = cv.take<uint16_t>((size_t)nb * LZ2_BIG_STRIDE);
+    sc->bigpid = cv.take<uint16_t>((size_t)nb * LZ2_BIG_STRIDE);
+    sc->bigcand = cv.take<uint16_t>((size_t)nb * LZ2_BIG_STRIDE);
     for (uint32_t c = 0; c < LZ2_NCLASS; ++c) sc->desc[c] = cv.take<Lz2BigDesc>((size_t)nb * lz2_class_cap(c));
     sc->big_count = sc->fallback_count + 16;
     sc->dbg = getenv("MI_LZ_DEBUG") ? cv.take<uint64_t>(32) : nullptr;

@@ -82,7 +82,7 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
         return len;
     };
     const uint16_t *l_pos = s2.plist + (size_t)lb * LZ_MAX_BLOCK, *l_cand = s2.cand + (size_t)lb * LZ_MAX_BLOCK;
-    const uint16_t *b_pos = s2.bigpos + (size_t)lb * LZ_MAX_BLOCK, *b_cand = s2.bigcand + (size_t)lb * LZ_MAX_BLOCK;
+    const uint16_t *b_pos = s2.bigpos + (size_t)lb * LZ2_BIG_STRIDE, *b_cand = s2.bigcand + (size_t)lb * LZ2_BIG_STRIDE;
     const uint32_t nbig = lists ? s2.meta[lb].nbig_entries : 0u;
     // (position, candidate) pairs of a list, 8 per lane per step: two 16-byte loads instead of sixteen 2-byte ones
     auto for_each_pair = [&](const uint16_t *lp, const uint16_t *lc, uint32_t cnt, auto &&fn) {
@@ -99,7 +99,7 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     };
     if (lists) {
         for_each_pair(l_pos, l_cand, n, [&](uint32_t p, uint32_t c) { if (c != p) s_L[p] = (uint8_t)token_len(p, c); });
-        for_each_pair(b_pos, b_cand, nbig, [&](uint32_t p, uint32_t c) { s_L[p] = (uint8_t)token_len(p, c); });
+        for_each_pair(b_pos, b_cand, nbig, [&](uint32_t p, uint32_t c) { if (c != p) s_L[p] = (uint8_t)token_len(p, c); });    // c == p: an alignment pad
     } else {
         for (uint32_t p = tid; p < n; p += 1024u) s_L[p] = (uint8_t)token_len(p, cand[p]);
     }
@@ -199,7 +199,7 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
             if ((s_mat[ch] >> o) & 1ull) md[mb[ch] + (uint32_t)__popcll(s_mat[ch] & ((1ull << o) - 1ull))] = (uint16_t)(p - c);
         };
         for_each_pair(l_pos, l_cand, n, [&](uint32_t p, uint32_t c) { if (c != p && c != LZ_NONE16) put(p, c); });
-        for_each_pair(b_pos, b_cand, nbig, [&](uint32_t p, uint32_t c) { if (c != LZ_NONE16) put(p, c); });
+        for_each_pair(b_pos, b_cand, nbig, [&](uint32_t p, uint32_t c) { if (c != LZ_NONE16 && c != p) put(p, c); });
         __syncthreads();
     }
 
