@@ -119,13 +119,21 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     __shared__ uint16_t s_j0[LZ2_CAP], s_j1[LZ2_CAP];   // sort ping-pong; later e_pid / (free)
     __shared__ uint16_t s_g[LZ2_CAP];                   // cluster number by j; later occ
     __shared__ uint16_t s_r[LZ2_CAP];                   // dense home slot by j; later cand by replay index
-    __shared__ uint16_t s_pid[LZ2_CAP];                 // word id by j (j of the first occurrence); later cand by j
+    __shared__ uint16_t s_pid[LZ2_CAP + 2];             // word id by j (position of the first occurrence); then s_gstart; last cand by j
     __shared__ uint32_t s_cnt[LZ2_NWAVES][256];
     __shared__ uint32_t s_bm[LZ2_CAP / 32 + 2];
     __shared__ int32_t  s_i32[18];
     __shared__ uint32_t s_zslot, s_zgid, s_nbigl, s_ngroups;
-    __shared__ uint16_t s_gstart[LZ2_CAP + 2];          // replay index of the head of every cluster
-    __shared__ uint32_t s_big[3 * LZ2_MAXBIG];          // clusters exported by this part: {s, e, global dst}
+    // LDS diet: two of these workgroups share a CU, and whatever they leave (160 KiB - 2 x this kernel) is all that the
+    // replay kernels of the previous batch can use beside them.  Arrays that are dead by then are reused:
+    //   s_gstart (replay index of the head of every cluster) lives in s_pid, dead between the permutation and the final
+    //            reordering of the results;
+    //   s_big    ({s, e, global dst} of the clusters this part exports) and s_quiet (quiet clusters of >= LZ2_BIG
+    //            entries) live in the radix counters, dead after the second sort.
+    uint16_t *const s_gstart = s_pid;
+    uint32_t *const s_big = &s_cnt[0][0];
+    uint16_t *const s_quiet = reinterpret_cast<uint16_t *>(&s_cnt[0][0] + 3 * LZ2_MAXBIG);
+    static_assert(3 * LZ2_MAXBIG * 4 + 2 * LZ2_MAXBIG * 2 <= sizeof(uint32_t) * LZ2_NWAVES * 256, "export lists must fit the radix counters");
 
     const int tid = threadIdx.x;
     const uint32_t lb = blockIdx.y, part = blockIdx.x;
@@ -351,7 +359,6 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     {
         // cluster heads -> compact list (order irrelevant), sizes from the next head
         __shared__ uint32_t s_ncl, s_bin[LZ2_BIG + 1], s_nquiet;
-        __shared__ uint16_t s_quiet[2 * LZ2_MAXBIG];         // quiet clusters of >= LZ2_BIG entries: filled by a wave each, below
         if (tid == 0) { s_ncl = 0; s_nquiet = 0; }
         if (tid <= (int)LZ2_BIG) s_bin[tid] = 0;
         __syncthreads();
