@@ -126,9 +126,11 @@ struct OpMaxI32 { __device__ int32_t operator()(int32_t a, int32_t b) const { re
 //   load(i)  -> element (any trivially copyable type E) at input index i
 //   digit(e) -> 0 .. (1<<NBITS)-1
 //   store(j, e) writes element e to output index j
-template <int NWAVES, int NBITS, typename E, typename Load, typename Digit, typename Store>
-__device__ __forceinline__ void radix_pass(uint32_t n, uint32_t (*s_cnt)[256], Load load, Digit digit, Store store)
+//   s_cnt    [NWAVES][ROW] counters, ROW >= 1 << NBITS (a narrow row saves LDS where a kernel only sorts small digits)
+template <int NWAVES, int NBITS, typename E, typename CntRow, typename Load, typename Digit, typename Store>
+__device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load, Digit digit, Store store)
 {
+    static_assert(sizeof(CntRow) / sizeof(uint32_t) >= (1u << NBITS), "counter row too narrow for the digit");
     constexpr int ND = 1 << NBITS;
     constexpr int NT = NWAVES * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -174,8 +176,8 @@ __device__ __forceinline__ void radix_pass(uint32_t n, uint32_t (*s_cnt)[256], L
     __syncthreads();
 }
 
-template <int NBITS, typename E, typename Load, typename Digit, typename Store>
-__device__ __forceinline__ void radix_pass_1024(uint32_t n, uint32_t (*s_cnt)[256], Load load, Digit digit, Store store)
+template <int NBITS, typename E, typename CntRow, typename Load, typename Digit, typename Store>
+__device__ __forceinline__ void radix_pass_1024(uint32_t n, CntRow *s_cnt, Load load, Digit digit, Store store)
 {
     radix_pass<16, NBITS, E>(n, s_cnt, load, digit, store);
 }
