@@ -492,7 +492,7 @@ struct WaveBitmap {
         const uint32_t wq = wi >> 6, ln = wi & 63u;
         uint32_t r = 0;
 #pragma unroll
-        for (int q = 0; q < NW; ++q) { const uint32_t t = RLANE(w[q], ln); if ((uint32_t)q == wq) r = t; }
+        for (int q = 0; q < NW; ++q) { const uint32_t t = RLANE(w[q], ln); if (NW == 1 || (uint32_t)q == wq) r = t; }
         return r;
     }
     __device__ __forceinline__ bool test(uint32_t slot) const { return (word(slot >> 5) >> (slot & 31u)) & 1u; }
@@ -500,13 +500,13 @@ struct WaveBitmap {
         const uint32_t wi = slot >> 5, wq = wi >> 6;
         const uint32_t keep = (lane == (wi & 63u)) ? ~(1u << (slot & 31u)) : 0xFFFFFFFFu;
 #pragma unroll
-        for (int q = 0; q < NW; ++q) w[q] &= ((uint32_t)q == wq) ? keep : 0xFFFFFFFFu;
+        for (int q = 0; q < NW; ++q) w[q] &= (NW == 1 || (uint32_t)q == wq) ? keep : 0xFFFFFFFFu;
     }
     __device__ __forceinline__ void flip(uint32_t slot, uint32_t lane) {
         const uint32_t wi = slot >> 5, wq = wi >> 6;
         const uint32_t bit = (lane == (wi & 63u)) ? (1u << (slot & 31u)) : 0u;
 #pragma unroll
-        for (int q = 0; q < NW; ++q) w[q] ^= ((uint32_t)q == wq) ? bit : 0u;
+        for (int q = 0; q < NW; ++q) w[q] ^= (NW == 1 || (uint32_t)q == wq) ? bit : 0u;
     }
     __device__ __forceinline__ uint32_t first_zero_from(uint32_t r, uint32_t lane) const {
         const uint32_t rw = r >> 5, lowmask = (1u << (r & 31u)) - 1u;
@@ -529,6 +529,66 @@ struct WaveBitmap {
     }
 };
 
+// one cluster, one wave.  PLAIN: the cluster does not cover bucket 0 / T (all but one per block): the spurious clear and
+// the non-wrapping find() drop out of the loop, which is bound by the number of scalar instructions per step.
+template <int LDS_ENTRIES, int NW, bool PLAIN>
+__device__ __forceinline__ void big_replay(uint32_t *s_occ, uint16_t *s_slot, uint32_t lane, uint32_t W, uint32_t n,
+                                           uint32_t d_anom, uint32_t d_limit, const uint16_t *bp, const uint16_t *br,
+                                           const uint16_t *bi, uint16_t *bc)
+{
+    WaveBitmap<NW> bm;
+    bm.clear();
+    uint32_t ev = 0;
+    bool anom_pending = !PLAIN && d_anom != ~0u;
+    uint32_t c_pos = 0, c_rs = 0, c_pid = 0, ev_pos = 0, ev_base = ~0u, out_acc = 0;
+    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+        const uint32_t ii = i0 + lane;
+        if (ii < n) { c_pos = bp[ii]; c_rs = br[ii]; c_pid = bi[ii]; }
+        const uint32_t lim = (n - i0) < 64u ? (n - i0) : 64u;
+        for (uint32_t t = 0; t < lim; ++t) {
+            const uint32_t i = i0 + t;
+            const uint32_t p = RLANE(c_pos, t), r = RLANE(c_rs, t), id = RLANE(c_pid, t);
+            if (p > W) {                                            // positions <= W cannot evict anything
+                for (;;) {                                          // FIFO retirement (lz77.c:70-76)
+                    if (ev >= i) break;
+                    if ((ev & ~63u) != ev_base) { ev_base = ev & ~63u; const uint32_t q = ev_base + lane; ev_pos = q < n ? bp[q] : 0u; }
+                    const uint32_t pe = RLANE(ev_pos, ev & 63u);
+                    if (pe + W >= p) break;
+                    const uint32_t sl = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_slot[ev]);
+                    bm.clear_bit(sl, lane);                         // clears the bucket, whoever sits there
+                    ++ev;
+                }
+                if (!PLAIN && anom_pending) { bm.clear_bit(d_anom, lane); anom_pending = false; }     // p > W - 1, SURVEY.md A.1.2
+            } else if (!PLAIN && anom_pending && p > W - 1u) { bm.clear_bit(d_anom, lane); anom_pending = false; }
+            uint32_t res = LZ_NONE16;
+            if (PLAIN && ev == 0) {
+                // nothing evicted yet: find() = the word's first occurrence = the word id (k_lz2_find, the sweep)
+                if (id != p) res = id;
+            } else {
+                const uint32_t h = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_occ[r]);
+                if (bm.test(r)) {
+                    if ((h & 0xFFFFu) == id) res = h >> 16;
+                    else {
+                        for (uint32_t b = r + 1;; ++b) {            // rare: the home holds another word
+                            if (!PLAIN && b == d_limit && r < d_limit) break;
+                            if (!bm.test(b)) break;
+                            const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_occ[b]);
+                            if ((o & 0xFFFFu) == id) { res = o >> 16; break; }
+                        }
+                    }
+                }
+            }
+            const uint32_t b = bm.first_zero_from(r, lane);         // insert: first fit
+            bm.flip(b, lane);
+            if (lane == 0) { s_occ[b] = id | (p << 16); s_slot[i] = (uint16_t)b; }
+            if (lane == t) out_acc = res;
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (ii < n) bc[ii] = (uint16_t)out_acc;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <int LDS_ENTRIES, int NW>
 __global__ __launch_bounds__(64)
 void k_lz2_big(LzP P, Lz2Scratch sc, int large)
@@ -547,60 +607,9 @@ void k_lz2_big(LzP P, Lz2Scratch sc, int large)
         const uint16_t *br = sc.bigrs + (size_t)d_block * LZ2_BIG_STRIDE + d_start;
         const uint16_t *bi = sc.bigpid + (size_t)d_block * LZ2_BIG_STRIDE + d_start;
         uint16_t *bc = sc.bigcand + (size_t)d_block * LZ2_BIG_STRIDE + d_start;
-        WaveBitmap<NW> bm;
-        bm.clear();
-        uint32_t ev = 0;
-        bool anom_pending = d_anom != ~0u;
-        const bool plain = d_anom == ~0u && d_limit == ~0u;               // not the cluster that covers bucket 0 / T
-        uint32_t c_pos = 0, c_rs = 0, c_pid = 0, ev_pos = 0, ev_base = ~0u, out_acc = 0;
-        for (uint32_t i0 = 0; i0 < n; i0 += 64) {
-            const uint32_t ii = i0 + lane;
-            if (ii < n) { c_pos = bp[ii]; c_rs = br[ii]; c_pid = bi[ii]; }
-            const uint32_t lim = (n - i0) < 64u ? (n - i0) : 64u;
-            for (uint32_t t = 0; t < lim; ++t) {
-                const uint32_t i = i0 + t;
-                const uint32_t p = RLANE(c_pos, t), r = RLANE(c_rs, t), id = RLANE(c_pid, t);
-                // This loop is bound by the CU's one scalar unit (every wave-uniform step is an SALU instruction and all
-                // resident waves share it), so the common case is kept short: positions <= W cannot evict anything.
-                if (p > W) {
-                    for (;;) {                                          // FIFO retirement (lz77.c:70-76)
-                        if (ev >= i) break;
-                        if ((ev & ~63u) != ev_base) { ev_base = ev & ~63u; const uint32_t q = ev_base + lane; ev_pos = q < n ? bp[q] : 0u; }
-                        const uint32_t pe = RLANE(ev_pos, ev & 63u);
-                        if (pe + W >= p) break;
-                        const uint32_t sl = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_slot[ev]);
-                        bm.clear_bit(sl, lane);                         // clears the bucket, whoever sits there
-                        ++ev;
-                    }
-                    if (anom_pending) { bm.clear_bit(d_anom, lane); anom_pending = false; }     // p > W - 1, SURVEY.md A.1.2
-                } else if (anom_pending && p > W - 1u) { bm.clear_bit(d_anom, lane); anom_pending = false; }
-                uint32_t res = LZ_NONE16;
-                if (plain && ev == 0) {
-                    // nothing evicted yet: find() = the word's first occurrence = the word id (k_lz2_find, the sweep)
-                    if (id != p) res = id;
-                } else {
-                    const uint32_t h = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_occ[r]);
-                    if (bm.test(r)) {
-                        if ((h & 0xFFFFu) == id) res = h >> 16;
-                        else {
-                            for (uint32_t b = r + 1;; ++b) {            // rare: the home holds another word
-                                if (b == d_limit && r < d_limit) break;
-                                if (!bm.test(b)) break;
-                                const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_occ[b]);
-                                if ((o & 0xFFFFu) == id) { res = o >> 16; break; }
-                            }
-                        }
-                    }
-                }
-                const uint32_t b = bm.first_zero_from(r, lane);         // insert: first fit
-                bm.flip(b, lane);
-                if (lane == 0) { s_occ[b] = id | (p << 16); s_slot[i] = (uint16_t)b; }
-                if (lane == t) out_acc = res;
-                __builtin_amdgcn_wave_barrier();
-            }
-            if (ii < n) bc[ii] = (uint16_t)out_acc;
-        }
-        __builtin_amdgcn_wave_barrier();
+        // (in the non-PLAIN version the first-occurrence shortcut is off: that one cluster per block keeps the literal replay)
+        if (d_anom == ~0u && d_limit == ~0u) big_replay<LDS_ENTRIES, NW, true>(s_occ, s_slot, lane, W, n, d_anom, d_limit, bp, br, bi, bc);
+        else big_replay<LDS_ENTRIES, NW, false>(s_occ, s_slot, lane, W, n, d_anom, d_limit, bp, br, bi, bc);
     }
 }
 

@@ -134,8 +134,17 @@ def test_block_sizes(block):
     _check(synth.enwik_like(150_000, seed=9).numpy(), "lz77", 14, block)
 
 
+@pytest.mark.parametrize("flavour,wbits", CONFIGS)
+@pytest.mark.parametrize("batch", [1, 7])
+def test_small_batches_rotate_scratch_sets(flavour, wbits, batch, monkeypatch):
+    """MI_LZ_BATCH forces many batches on a small input: the three-stream pipeline with its rotating scratch sets and
+    the bit-contiguous concatenation across batch boundaries, byte-exact against the oracle"""
+    monkeypatch.setenv("MI_LZ_BATCH", str(batch))
+    _check(synth.enwik_like(46 * 65536 + 1234, seed=33).numpy(), flavour, wbits)
+
+
 def test_many_blocks_batches():
-    # more than one batch of 512 blocks: 40 MB
+    # 40 MB, 611 blocks
     from compression_algorithms_amd import lz
     from oracle import orc
     x = synth.enwik_like(40_000_000, seed=21, device="cuda")
