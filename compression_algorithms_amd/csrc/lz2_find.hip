@@ -540,7 +540,10 @@ __device__ __forceinline__ void big_replay(uint32_t *s_occ, uint16_t *s_slot, ui
     bm.clear();
     uint32_t ev = 0;
     bool anom_pending = !PLAIN && d_anom != ~0u;
-    uint32_t c_pos = 0, c_rs = 0, c_pid = 0, ev_pos = 0, ev_base = ~0u, out_acc = 0;
+    uint32_t c_pos = 0, c_rs = 0, c_pid = 0, out_acc = 0;
+    // position of the oldest entry still in the table, kept in a scalar: "nothing to retire" is one compare per step
+    uint32_t ev_pos = lane < n ? bp[lane] : 0u;
+    uint32_t pe = RLANE(ev_pos, 0);
     for (uint32_t i0 = 0; i0 < n; i0 += 64) {
         const uint32_t ii = i0 + lane;
         if (ii < n) { c_pos = bp[ii]; c_rs = br[ii]; c_pid = bi[ii]; }
@@ -548,18 +551,14 @@ __device__ __forceinline__ void big_replay(uint32_t *s_occ, uint16_t *s_slot, ui
         for (uint32_t t = 0; t < lim; ++t) {
             const uint32_t i = i0 + t;
             const uint32_t p = RLANE(c_pos, t), r = RLANE(c_rs, t), id = RLANE(c_pid, t);
-            if (p > W) {                                            // positions <= W cannot evict anything
-                for (;;) {                                          // FIFO retirement (lz77.c:70-76)
-                    if (ev >= i) break;
-                    if ((ev & ~63u) != ev_base) { ev_base = ev & ~63u; const uint32_t q = ev_base + lane; ev_pos = q < n ? bp[q] : 0u; }
-                    const uint32_t pe = RLANE(ev_pos, ev & 63u);
-                    if (pe + W >= p) break;
-                    const uint32_t sl = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_slot[ev]);
-                    bm.clear_bit(sl, lane);                         // clears the bucket, whoever sits there
-                    ++ev;
-                }
-                if (!PLAIN && anom_pending) { bm.clear_bit(d_anom, lane); anom_pending = false; }     // p > W - 1, SURVEY.md A.1.2
-            } else if (!PLAIN && anom_pending && p > W - 1u) { bm.clear_bit(d_anom, lane); anom_pending = false; }
+            while (ev < i && pe + W < p) {                          // FIFO retirement (lz77.c:70-76)
+                const uint32_t sl = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_slot[ev]);
+                bm.clear_bit(sl, lane);                             // clears the bucket, whoever sits there
+                ++ev;
+                if ((ev & 63u) == 0) { const uint32_t q = ev + lane; ev_pos = q < n ? bp[q] : 0u; }
+                pe = RLANE(ev_pos, ev & 63u);
+            }
+            if (!PLAIN && anom_pending && p > W - 1u) { bm.clear_bit(d_anom, lane); anom_pending = false; }
             uint32_t res = LZ_NONE16;
             if (PLAIN && ev == 0) {
                 // nothing evicted yet: find() = the word's first occurrence = the word id (k_lz2_find, the sweep)
