@@ -120,7 +120,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     __shared__ uint16_t s_g[LZ2_CAP];                   // cluster number by j; later occ
     __shared__ uint16_t s_r[LZ2_CAP];                   // dense home slot by j; later cand by replay index
     __shared__ uint16_t s_pid[LZ2_CAP + 2];             // word id by j (position of the first occurrence); then s_gstart; last cand by j
-    __shared__ uint32_t s_cnt[LZ2_NWAVES][256];
+    __shared__ uint32_t s_cnt[LZ2_NWAVES + 1][256];   // radix counters, [digit][wave + pad] (lz_common.h)
     __shared__ uint32_t s_bm[LZ2_CAP / 32 + 2];
     __shared__ int32_t  s_i32[18];
     __shared__ uint32_t s_zslot, s_zgid, s_nbigl, s_ngroups;

@@ -119,37 +119,47 @@ __device__ __forceinline__ T block_exclusive_scan(T v, Op op, T ident, T *s_tmp,
 struct OpAddU32 { __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a + b; } };
 struct OpMaxI32 { __device__ int32_t operator()(int32_t a, int32_t b) const { return a > b ? a : b; } };
 
-// ---- one stable LSD radix pass over n elements held by a 1024-thread workgroup ----------------
+// ---- one stable LSD radix pass over n elements held by a workgroup of NWAVES waves ----------------
 // Wave w owns the contiguous segment [w*seg, (w+1)*seg): per-wave digit counts -> offsets by a
 // (digit-major, wave-minor) scan -> each wave scatters its segment in order, ranking the 64
 // elements of a step with ballots; no workgroup barrier inside the scatter.
 //   load(i)  -> element (any trivially copyable type E) at input index i
 //   digit(e) -> 0 .. (1<<NBITS)-1
 //   store(j, e) writes element e to output index j
-//   s_cnt    [NWAVES][ROW] counters, ROW >= 1 << NBITS (a narrow row saves LDS where a kernel only sorts small digits)
+//   s_cnt    counters, used as a flat array [digit][NWAVES + 1]: the caller provides at least (NWAVES + 1) << NBITS
+//            words (declare [NWAVES + 1][ROW], ROW >= 1 << NBITS).  Digit-major with an odd stride: the thread that
+//            owns a digit reads its NWAVES counters at once (no read-modify-write chain through LDS) and the lanes of a
+//            wave, which hit different digits, still spread over the banks.
 template <int NWAVES, int NBITS, typename E, typename CntRow, typename Load, typename Digit, typename Store>
 __device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load, Digit digit, Store store)
 {
     static_assert(sizeof(CntRow) / sizeof(uint32_t) >= (1u << NBITS), "counter row too narrow for the digit");
     constexpr int ND = 1 << NBITS;
     constexpr int NT = NWAVES * 64;
+    constexpr int ST = NWAVES + 1;
+    uint32_t *cnt = &s_cnt[0][0];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t seg = ((n + (uint32_t)NT - 1u) / (uint32_t)NT) * 64u;
     const uint32_t a = wave * seg, b = (a + seg < n) ? a + seg : n;
-    for (int i = tid; i < NWAVES * ND; i += NT) s_cnt[i >> NBITS][i & (ND - 1)] = 0;
+    for (int i = tid; i < ND * ST; i += NT) cnt[i] = 0;
     __syncthreads();
-    for (uint32_t i = a + lane; i < b; i += 64) atomicAdd(&s_cnt[wave][digit(load(i))], 1u);
+    for (uint32_t i = a + lane; i < b; i += 64) atomicAdd(&cnt[digit(load(i)) * ST + wave], 1u);
     __syncthreads();
-    // offsets: thread d < ND walks the waves of digit d; then an exclusive scan over digits
+    // offsets: thread d < ND owns digit d: exclusive prefix over its waves in registers, then an exclusive scan over digits
+    uint32_t pre[NWAVES];
     uint32_t tot = 0;
     if (tid < ND) {
-        for (int w = 0; w < NWAVES; ++w) { uint32_t t = s_cnt[w][tid]; s_cnt[w][tid] = tot; tot += t; }
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) pre[w] = cnt[tid * ST + w];
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) { const uint32_t t = pre[w]; pre[w] = tot; tot += t; }
     }
     __shared__ uint32_t s_scan[18];
     uint32_t total;
-    uint32_t base = block_exclusive_scan<uint32_t>(tid < ND ? tot : 0u, OpAddU32(), 0u, s_scan, &total);
+    const uint32_t base = block_exclusive_scan<uint32_t>(tid < ND ? tot : 0u, OpAddU32(), 0u, s_scan, &total);
     if (tid < ND) {
-        for (int w = 0; w < NWAVES; ++w) s_cnt[w][tid] += base;
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) cnt[tid * ST + w] = pre[w] + base;
     }
     __syncthreads();
     for (uint32_t i0 = a; i0 < b; i0 += 64) {
@@ -166,10 +176,10 @@ __device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load,
             mask &= bit ? bal : ~bal;
         }
         const uint64_t below = mask & ((1ull << lane) - 1ull);
-        const uint32_t rank = __popcll(below), cnt = __popcll(mask);
+        const uint32_t rank = __popcll(below), num = __popcll(mask);
         const int leader = __ffsll((unsigned long long)mask) - 1;
         uint32_t old = 0;
-        if (valid && lane == leader) old = atomicAdd(&s_cnt[wave][d], cnt);
+        if (valid && lane == leader) old = atomicAdd(&cnt[d * ST + wave], num);
         old = __shfl(old, leader < 0 ? 0 : leader);
         if (valid) store(old + rank, e);
     }

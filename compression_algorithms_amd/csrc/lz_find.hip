@@ -30,7 +30,7 @@ __device__ __forceinline__ void lz_sort_home_block(const uint8_t *__restrict__ i
                                                    uint32_t lb)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_in[LZ_MAX_BLOCK + LZ_TAIL + 16];
-    __shared__ uint32_t s_cnt[16][256];
+    __shared__ uint32_t s_cnt[17][256];
     __shared__ int32_t  s_i32[18];
     __shared__ uint32_t s_u32[18];
     __shared__ uint32_t s_rot;
@@ -190,7 +190,7 @@ void k_lz_sort_home(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, LzS
 __global__ __launch_bounds__(1024)
 void k_lz_sort_cluster(LzScratch sc, uint32_t nb, const uint32_t *__restrict__ blist, const uint32_t *__restrict__ bcount)
 {
-    __shared__ uint32_t s_cnt[16][256];
+    __shared__ uint32_t s_cnt[17][256];
     const uint32_t count = bcount ? *bcount : nb;
     for (uint32_t bi = blockIdx.x; bi < count; bi += gridDim.x) {
     const uint32_t lb = blist ? blist[bi] : bi;
