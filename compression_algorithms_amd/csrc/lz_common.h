@@ -131,8 +131,10 @@ struct OpMaxI32 { __device__ int32_t operator()(int32_t a, int32_t b) const { re
 //            owns a digit reads its NWAVES counters at once (no read-modify-write chain through LDS) and the lanes of a
 //            wave, which hit different digits, still spread over the banks.
 template <int NWAVES, int NBITS, typename E, typename CntRow, typename Load, typename Digit, typename Store>
-__device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load, Digit digit, Store store)
+__device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load, Digit digit, Store store, uint64_t *dbg = nullptr)
 {
+    long long tk_ = dbg ? clock64() : 0;
+#define RP_TICK(k) do { if (dbg && threadIdx.x == 0) { long long t2 = clock64(); atomicAdd((unsigned long long *)&dbg[k], (unsigned long long)(t2 - tk_)); tk_ = t2; } } while (0)
     static_assert(sizeof(CntRow) / sizeof(uint32_t) >= (1u << NBITS), "counter row too narrow for the digit");
     constexpr int ND = 1 << NBITS;
     constexpr int NT = NWAVES * 64;
@@ -145,6 +147,7 @@ __device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load,
     __syncthreads();
     for (uint32_t i = a + lane; i < b; i += 64) atomicAdd(&cnt[digit(load(i)) * ST + wave], 1u);
     __syncthreads();
+    RP_TICK(8);
     // offsets: thread d < ND owns digit d: exclusive prefix over its waves in registers, then an exclusive scan over digits
     uint32_t pre[NWAVES];
     uint32_t tot = 0;
@@ -162,12 +165,18 @@ __device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load,
         for (int w = 0; w < NWAVES; ++w) cnt[tid * ST + w] = pre[w] + base;
     }
     __syncthreads();
+    RP_TICK(9);
+    // the element and its digit of the NEXT step are fetched while this step ranks and stores (two dependent LDS reads
+    // off the chain: measured, the scatter is a chain of LDS round trips, 58 % of a pass)
+    E en{};
+    uint32_t dn = 0;
+    if (a + lane < b) { en = load(a + lane); dn = digit(en); }
     for (uint32_t i0 = a; i0 < b; i0 += 64) {
         const uint32_t i = i0 + lane;
         const bool valid = i < b;
-        E e{};
-        uint32_t d = 0;
-        if (valid) { e = load(i); d = digit(e); }
+        const E e = en;
+        const uint32_t d = dn;
+        if (i + 64 < b) { en = load(i + 64); dn = digit(en); }
         uint64_t mask = __ballot(valid);
 #pragma unroll
         for (int k = 0; k < NBITS; ++k) {
@@ -184,7 +193,14 @@ __device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load,
         if (valid) store(old + rank, e);
     }
     __syncthreads();
+    RP_TICK(10);
 }
+
+// Measured in k_lz2_find (MI_LZ_DEBUG counters, 3.5k keys, 8 waves): count 2.8k, offsets 2.0k, scatter 6.6k cycles per 8-bit
+// pass; the scatter is bound by VALU issue — ~60 instructions per 64-element step, of which 5 per key bit build the
+// 64-bit peer mask — not by its LDS round trips (prefetching the next element changed nothing).  Ranking through
+// per-wave LDS masks (atomicOr of the lane bit, read back, popcount) costs the same at 6 bits and loses at 3 x 6 against
+// 2 x 8 bits (12.35 vs 13.1 GB/s); it was removed.
 
 template <int NBITS, typename E, typename CntRow, typename Load, typename Digit, typename Store>
 __device__ __forceinline__ void radix_pass_1024(uint32_t n, CntRow *s_cnt, Load load, Digit digit, Store store)
