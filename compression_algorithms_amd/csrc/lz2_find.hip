@@ -354,12 +354,16 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     __syncthreads();
 
     LZ2_TICK(4);
+    __shared__ uint32_t s_cls[LZ2_NCLASS], s_clsbase[LZ2_NCLASS], s_ent, s_entbase;
+    uint32_t my_rank[(LZ2_MAXBIG + LZ2_THREADS - 1) / LZ2_THREADS], my_dst[(LZ2_MAXBIG + LZ2_THREADS - 1) / LZ2_THREADS];
+    uint32_t nbig = 0;
     // ---- replay.  Clusters below LZ2_BIG entries: one lane each, lanes sorted by cluster size so that the
     //      64 lanes of a wave run the same number of steps.  Larger clusters are exported by size class.
     {
         // cluster heads -> compact list (order irrelevant), sizes from the next head
         __shared__ uint32_t s_ncl, s_bin[LZ2_BIG + 1], s_nquiet;
-        if (tid == 0) { s_ncl = 0; s_nquiet = 0; }
+        if (tid == 0) { s_ncl = 0; s_nquiet = 0; s_ent = 0; }
+        if (tid < (int)LZ2_NCLASS) s_cls[tid] = 0;
         if (tid <= (int)LZ2_BIG) s_bin[tid] = 0;
         __syncthreads();
         uint16_t *c_start = s_j1 + 0;                        // (s_j1 is still needed: cand back to time order) -> use s_pos, dead now
@@ -392,6 +396,22 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
         for (uint32_t c = 0; c < CH; ++c)
             if (my_n[c] >= 2 && my_n[c] < LZ2_BIG) c_start[atomicAdd(&s_bin[my_n[c]], 1u)] = (uint16_t)my_s[c];
         __syncthreads();
+        // reserve the output space of the clusters this part exports NOW — ONE global atomic per part and class (the class
+        // counters are shared by every workgroup of the batch), local ranks first in LDS — so that the round trips of
+        // those atomics pass while the lanes replay
+        nbig = s_nbigl < LZ2_MAXBIG ? s_nbigl : LZ2_MAXBIG;          // LZ2_CAP / LZ2_BIG clusters at most
+        {
+            uint32_t it = 0;
+            for (uint32_t q = tid; q < nbig; q += LZ2_THREADS, ++it) {
+                const uint32_t cnt = s_big[3 * q + 1] - s_big[3 * q];
+                const uint32_t cls = lz2_class_of(cnt, sc.wave_min, sc.row_mode);
+                my_rank[it] = atomicAdd(&s_cls[cls], 1u);
+                my_dst[it] = atomicAdd(&s_ent, LZ2_ALIGN8(cnt));        // every cluster starts on an 8-entry boundary
+            }
+        }
+        __syncthreads();
+        if (tid < (int)LZ2_NCLASS && s_cls[tid]) s_clsbase[tid] = atomicAdd(&sc.big_count[tid], s_cls[tid]);
+        if (tid == 32 && s_ent) { s_entbase = atomicAdd(&mt->nbig_entries, s_ent); atomicAdd(&mt->nbig, nbig); }
         for (uint32_t q = tid >> 6; q < s_nquiet; q += LZ2_NWAVES)
             for (uint32_t k = (uint32_t)s_quiet[2 * q] + (tid & 63u); k < s_quiet[2 * q + 1]; k += 64) {
                 const uint32_t id = e_pid[k];
@@ -409,28 +429,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     }
     __syncthreads();
     LZ2_TICK(5);
-    // ---- export the larger clusters (cooperatively, coalesced)
-    const uint32_t nbig = s_nbigl < LZ2_MAXBIG ? s_nbigl : LZ2_MAXBIG;   // LZ2_CAP / LZ2_BIG clusters at most
-    // reserve output space with ONE global atomic per part and class (the five class counters are shared by
-    // every workgroup of the batch): local ranks first, in LDS
-    __shared__ uint32_t s_cls[LZ2_NCLASS], s_clsbase[LZ2_NCLASS], s_ent, s_entbase;
-    if (tid < (int)LZ2_NCLASS) s_cls[tid] = 0;
-    if (tid == 0) s_ent = 0;
-    __syncthreads();
-    uint32_t my_rank[(LZ2_MAXBIG + LZ2_THREADS - 1) / LZ2_THREADS], my_dst[(LZ2_MAXBIG + LZ2_THREADS - 1) / LZ2_THREADS];
-    {
-        uint32_t it = 0;
-        for (uint32_t q = tid; q < nbig; q += LZ2_THREADS, ++it) {
-            const uint32_t cnt = s_big[3 * q + 1] - s_big[3 * q];
-            const uint32_t cls = lz2_class_of(cnt, sc.wave_min, sc.row_mode);
-            my_rank[it] = atomicAdd(&s_cls[cls], 1u);
-            my_dst[it] = atomicAdd(&s_ent, LZ2_ALIGN8(cnt));            // every cluster starts on an 8-entry boundary
-        }
-    }
-    __syncthreads();
-    if (tid < (int)LZ2_NCLASS && s_cls[tid]) s_clsbase[tid] = atomicAdd(&sc.big_count[tid], s_cls[tid]);
-    if (tid == 32 && s_ent) { s_entbase = atomicAdd(&mt->nbig_entries, s_ent); atomicAdd(&mt->nbig, nbig); }
-    __syncthreads();
+    // ---- export the larger clusters (cooperatively, coalesced); their space was reserved before the lane replay
     {
         uint32_t it = 0;
         for (uint32_t q = tid; q < nbig; q += LZ2_THREADS, ++it) {
