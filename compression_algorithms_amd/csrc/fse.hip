@@ -211,6 +211,35 @@ void k_fse_encode(const uint8_t *__restrict__ in, uint64_t n_total, FseP P, uint
         uint32_t x = N;
         uint64_t acc = 0; uint32_t nacc = 0, widx = word_off;
         uint32_t bits = 0;
+        auto step = [&](uint32_t s) {
+            const uint32_t nb = s_nbhi[s] - (x < s_thresh[s] ? 1u : 0u);
+            if (pass) {
+                acc |= (uint64_t)(x & ((1u << nb) - 1u)) << nacc;
+                nacc += nb;
+                if (nacc >= 32) { payload[widx++] = (uint32_t)acc; acc >>= 32; nacc -= 32; }
+            }
+            bits += nb;
+            x = s_next[(int32_t)(x >> nb) + s_delta[s]];
+        };
+        if ((len & 15u) == 0 && ((((uintptr_t)(src + a)) & 15u) == 0)) {
+            // Every lane walks its own 1 KiB sub-stream, so its loads never coalesce and each costs a trip to HBM that the
+            // serial state chain cannot hide: 16 bytes per load, and the next 16 are in flight while these are coded.
+            const uint4 *v16 = reinterpret_cast<const uint4 *>(src + a);
+            int32_t g = (int32_t)(len >> 4) - 1;
+            uint4 cur = make_uint4(0, 0, 0, 0);
+            if (g >= 0) cur = v16[g];
+            for (; g >= 0; --g) {
+                uint4 nxt = make_uint4(0, 0, 0, 0);
+                if (g > 0) nxt = v16[g - 1];
+                const uint32_t w4[4] = {cur.w, cur.z, cur.y, cur.x};       // backwards: last byte first
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int k = 3; k >= 0; --k) step((w4[q] >> (8 * k)) & 0xFFu);
+                }
+                cur = nxt;
+            }
+        } else {
         // walk backwards in 4-byte groups (sub-streams start 4-byte aligned relative to the block)
         for (uint32_t i = len; i > 0;) {
             const uint32_t take = ((i & 3u) ? (i & 3u) : 4u);
@@ -218,18 +247,9 @@ void k_fse_encode(const uint8_t *__restrict__ in, uint64_t n_total, FseP P, uint
             uint32_t w = 0;
             if (take == 4 && ((((uintptr_t)(src + a + base)) & 3u) == 0)) w = *reinterpret_cast<const uint32_t *>(src + a + base);
             else for (uint32_t k = 0; k < take; ++k) w |= (uint32_t)src[a + base + k] << (8 * k);
-            for (int k = (int)take - 1; k >= 0; --k) {
-                const uint32_t s = (w >> (8 * k)) & 0xFFu;
-                const uint32_t nb = s_nbhi[s] - (x < s_thresh[s] ? 1u : 0u);
-                if (pass) {
-                    acc |= (uint64_t)(x & ((1u << nb) - 1u)) << nacc;
-                    nacc += nb;
-                    if (nacc >= 32) { payload[widx++] = (uint32_t)acc; acc >>= 32; nacc -= 32; }
-                }
-                bits += nb;
-                x = s_next[(int32_t)(x >> nb) + s_delta[s]];
-            }
+            for (int k = (int)take - 1; k >= 0; --k) step((w >> (8 * k)) & 0xFFu);
             i = base;
+        }
         }
         if (pass == 0) {
             mybits = bits; final_t = x - N;
