@@ -206,40 +206,40 @@ void k_fse_encode(const uint8_t *__restrict__ in, uint64_t n_total, FseP P, uint
     const uint32_t m = fse_sub_len(n, S);
     const uint32_t a = lane * m;
     const uint32_t len = (lane < S && a < n) ? ((n - a < m) ? n - a : m) : 0u;
-    uint32_t mybits = 0, final_t = 0, word_off = 0;
-    for (int pass = 0; pass < 2; ++pass) {
-        uint32_t x = N;
-        uint64_t acc = 0; uint32_t nacc = 0, widx = word_off;
-        uint32_t bits = 0;
-        auto step = [&](uint32_t s) {
-            const uint32_t nb = s_nbhi[s] - (x < s_thresh[s] ? 1u : 0u);
-            if (pass) {
-                acc |= (uint64_t)(x & ((1u << nb) - 1u)) << nacc;
-                nacc += nb;
-                if (nacc >= 32) { payload[widx++] = (uint32_t)acc; acc >>= 32; nacc -= 32; }
-            }
-            bits += nb;
-            x = s_next[(int32_t)(x >> nb) + s_delta[s]];
-        };
-        if ((len & 15u) == 0 && ((((uintptr_t)(src + a)) & 15u) == 0)) {
-            // Every lane walks its own 1 KiB sub-stream, so its loads never coalesce and each costs a trip to HBM that the
-            // serial state chain cannot hide: 16 bytes per load, and the next 16 are in flight while these are coded.
-            const uint4 *v16 = reinterpret_cast<const uint4 *>(src + a);
-            int32_t g = (int32_t)(len >> 4) - 1;
-            uint4 cur = make_uint4(0, 0, 0, 0);
-            if (g >= 0) cur = v16[g];
-            for (; g >= 0; --g) {
-                uint4 nxt = make_uint4(0, 0, 0, 0);
-                if (g > 0) nxt = v16[g - 1];
-                const uint32_t w4[4] = {cur.w, cur.z, cur.y, cur.x};       // backwards: last byte first
+    // ONE pass over the symbols: the state chain is serial, so a dry run to learn the sub-stream sizes costs as much as the
+    // coding itself.  Every lane writes its words at a fixed stride (the worst case, which is what the record is sized
+    // for) and the wave then closes the gaps in place, left to right — a coalesced copy of at most 64 KiB.
+    const uint32_t lstr = (m * L + 31u) / 32u + 1u;            // words per lane before compaction
+    uint32_t x = N;
+    uint64_t acc = 0; uint32_t nacc = 0, widx = lane * lstr;
+    uint32_t bits = 0;
+    auto step = [&](uint32_t s) {
+        const uint32_t nb = s_nbhi[s] - (x < s_thresh[s] ? 1u : 0u);
+        acc |= (uint64_t)(x & ((1u << nb) - 1u)) << nacc;
+        nacc += nb;
+        if (nacc >= 32) { payload[widx++] = (uint32_t)acc; acc >>= 32; nacc -= 32; }
+        bits += nb;
+        x = s_next[(int32_t)(x >> nb) + s_delta[s]];
+    };
+    if ((len & 15u) == 0 && ((((uintptr_t)(src + a)) & 15u) == 0)) {
+        // Every lane walks its own 1 KiB sub-stream, so its loads never coalesce and each costs a trip to HBM that the
+        // serial state chain cannot hide: 16 bytes per load, and the next 16 are in flight while these are coded.
+        const uint4 *v16 = reinterpret_cast<const uint4 *>(src + a);
+        int32_t g = (int32_t)(len >> 4) - 1;
+        uint4 cur = make_uint4(0, 0, 0, 0);
+        if (g >= 0) cur = v16[g];
+        for (; g >= 0; --g) {
+            uint4 nxt = make_uint4(0, 0, 0, 0);
+            if (g > 0) nxt = v16[g - 1];
+            const uint32_t w4[4] = {cur.w, cur.z, cur.y, cur.x};       // backwards: last byte first
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < 4; ++q) {
 #pragma unroll
-                    for (int k = 3; k >= 0; --k) step((w4[q] >> (8 * k)) & 0xFFu);
-                }
-                cur = nxt;
+                for (int k = 3; k >= 0; --k) step((w4[q] >> (8 * k)) & 0xFFu);
             }
-        } else {
+            cur = nxt;
+        }
+    } else {
         // walk backwards in 4-byte groups (sub-streams start 4-byte aligned relative to the block)
         for (uint32_t i = len; i > 0;) {
             const uint32_t take = ((i & 3u) ? (i & 3u) : 4u);
@@ -250,23 +250,32 @@ void k_fse_encode(const uint8_t *__restrict__ in, uint64_t n_total, FseP P, uint
             for (int k = (int)take - 1; k >= 0; --k) step((w >> (8 * k)) & 0xFFu);
             i = base;
         }
-        }
-        if (pass == 0) {
-            mybits = bits; final_t = x - N;
-            const uint32_t nwords = (bits + 31u) >> 5;
-            uint32_t inc = nwords;
+    }
+    if (nacc) payload[widx] = (uint32_t)acc;
+    const uint32_t mybits = bits, final_t = x - N;
+    const uint32_t nwords = (bits + 31u) >> 5;
+    uint32_t inc = nwords;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += v; }
-            word_off = inc - nwords;
-            const uint32_t total_words = __shfl(inc, 63);
-            if (lane < S) {
-                states[2 * lane] = (uint8_t)final_t; states[2 * lane + 1] = (uint8_t)(final_t >> 8);
-                lens[4 * lane] = (uint8_t)mybits; lens[4 * lane + 1] = (uint8_t)(mybits >> 8);
-                lens[4 * lane + 2] = (uint8_t)(mybits >> 16); lens[4 * lane + 3] = (uint8_t)(mybits >> 24);
-            }
-            if (lane == 0) rec_bits[b] = 8ull * ((uint64_t)hdr + states_bytes + 4ull * S + 4ull * total_words);
-        } else {
-            if (nacc) payload[widx] = (uint32_t)acc;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += v; }
+    const uint32_t word_off = inc - nwords;
+    const uint32_t total_words = __shfl(inc, 63);
+    if (lane < S) {
+        states[2 * lane] = (uint8_t)final_t; states[2 * lane + 1] = (uint8_t)(final_t >> 8);
+        lens[4 * lane] = (uint8_t)mybits; lens[4 * lane + 1] = (uint8_t)(mybits >> 8);
+        lens[4 * lane + 2] = (uint8_t)(mybits >> 16); lens[4 * lane + 3] = (uint8_t)(mybits >> 24);
+    }
+    if (lane == 0) rec_bits[b] = 8ull * ((uint64_t)hdr + states_bytes + 4ull * S + 4ull * total_words);
+    // close the gaps: sub-stream l moves from l * lstr down to its prefix offset (never up, never past the next source)
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    for (uint32_t l = 1; l < S; ++l) {
+        const uint32_t cnt = __shfl(nwords, l), dsto = __shfl(word_off, l), srco = l * lstr;
+        if (dsto == srco) continue;
+        for (uint32_t k0 = 0; k0 < cnt; k0 += 64) {
+            const uint32_t k = k0 + lane;
+            uint32_t v = 0;
+            if (k < cnt) v = payload[srco + k];
+            if (k < cnt) payload[dsto + k] = v;
         }
     }
 }
