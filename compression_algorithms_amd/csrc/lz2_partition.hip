@@ -177,12 +177,17 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     uint16_t *stage = reinterpret_cast<uint16_t *>(s_grp);              // [8192], the group array is dead now
     uint8_t  *stage_part = reinterpret_cast<uint8_t *>(s_grp) + 16384;  // [8192]
     uint16_t *plist = sc.plist + (size_t)lb * LZ_MAX_BLOCK;
-    auto part_of = [&](uint32_t p) -> uint32_t {
-        const uint32_t h = (home_of(p) - base) & Tmask;
+    // part of every rotated group, tabulated once (part boundaries are group boundaries): a position's part is then one
+    // LDS read instead of a five-step binary search over the thresholds
+    uint8_t  *gpart = reinterpret_cast<uint8_t *>(s_grp) + 32768;      // [LZ2_NG]
+    for (uint32_t gr = tid; gr < LZ2_NG; gr += 1024) {
+        const uint32_t h = gr << gshift;
         uint32_t lo = 0, hi = K - 1;                    // last k with thr[k] <= h
         while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (s_thr[mid] <= h) lo = mid; else hi = mid - 1; }
-        return lo;
-    };
+        gpart[gr] = (uint8_t)lo;
+    }
+    __syncthreads();
+    auto part_of = [&](uint32_t p) -> uint32_t { return gpart[((home_of(p) - base) & Tmask) >> gshift]; };
     uint8_t  *part_in = reinterpret_cast<uint8_t *>(s_grp) + 24576;    // [8192] part of every position of the slab (hashed once)
     for (uint32_t e0 = 0; e0 < n; e0 += 8192u) {
         const uint32_t en = (n - e0) < 8192u ? (n - e0) : 8192u;
