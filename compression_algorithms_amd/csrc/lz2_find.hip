@@ -578,7 +578,9 @@ __device__ __forceinline__ void big_replay(uint32_t *s_occ, uint16_t *s_slot, ui
             }
             const uint32_t b = bm.first_zero_from(r, lane);         // insert: first fit
             bm.flip(b, lane);
-            if (lane == 0) { s_occ[b] = id | (p << 16); s_slot[i] = (uint16_t)b; }
+            // every lane stores the same value to the same address: no exec-mask juggling (scalar instructions) for a
+            // one-lane store, and identical-address stores of a wave do not conflict
+            s_occ[b] = id | (p << 16); s_slot[i] = (uint16_t)b;
             if (lane == t) out_acc = res;
             __builtin_amdgcn_wave_barrier();
         }
