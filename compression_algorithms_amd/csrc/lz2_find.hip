@@ -288,6 +288,14 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
         }
     }
     __syncthreads();
+    if (!P.deflate && W >= nblk) {
+        // lz77 flavour with a window that covers the block (the 64 KiB-window build): nothing is ever retired, find() never
+        // stops at the table end, and the spurious clear of bucket 0 happens at the last insertion — so find() is the
+        // first occurrence of the word for EVERY position (2.3 above): no clusters, no second sort, no replay.
+        uint16_t *cout = sc.cand + (size_t)lb * LZ_MAX_BLOCK + pstart;
+        for (uint32_t j = tid; j < m; j += LZ2_THREADS) { const uint32_t id = s_pid[j]; cout[j] = (id != s_pos[j]) ? (uint16_t)id : (uint16_t)LZ_NONE16; }
+        return;
+    }
     // bucket 0 (= bucket T on deflate's ring) sits at home' Z: the cluster that covers it gets the one-time
     // spurious clear and, for deflate, the point where find() stops instead of wrapping
     if (tid == 0) {
