@@ -406,6 +406,45 @@ void k_lz_emulate_giant(LzP P, LzScratch sc)
         uint16_t *cand = sc.cand + (size_t)lb * LZ_MAX_BLOCK;
         const bool first = a == 0;
         const uint32_t anom = first ? mt.anom_idx : ~0u, limit = first ? mt.limit_idx : ~0u;
+        // A cluster of ONE word (a run of one byte value: zero pages, padding) needs no table: every entry has the same
+        // home, find() only ever looks at that slot, and its occupant — the "anchor" — changes exactly when it is
+        // retired: the step that retires it finds the slot empty and then takes it.  anchors: a(0) = first entry,
+        // a(k+1) = first entry more than W positions after a(k); result = position of the current anchor, none at an
+        // anchor.  (Not for the cluster that covers bucket 0 / T: spurious clear, non-wrapping find.)
+        __shared__ uint32_t s_pure, s_nanch, s_anch[LZ_MAX_BLOCK / 256 + 4];
+        if (tid == 0) s_pure = (anom == ~0u && limit == ~0u) ? 1u : 0u;
+        __syncthreads();
+        {
+            const uint32_t pid0 = (uint32_t)(E[a] >> 48);
+            bool same = true;
+            for (uint32_t i = tid; i < m && same; i += 256) same = ((uint32_t)(E[a + i] >> 48) == pid0);
+            if (!same) atomicAnd(&s_pure, 0u);
+        }
+        __syncthreads();
+        if (s_pure) {
+            if (tid == 0) {
+                uint32_t k = 0, cur = 0;
+                s_anch[0] = 0;
+                for (;;) {
+                    const uint32_t lim = ((uint32_t)(E[a + cur] >> 16) & 0xFFFFu) + W;      // retired by the first position beyond this
+                    uint32_t lo = cur + 1, hi = m;                                          // first i in (cur, m) with pos_i > lim
+                    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (((uint32_t)(E[a + mid] >> 16) & 0xFFFFu) > lim) hi = mid; else lo = mid + 1; }
+                    if (lo >= m) break;
+                    cur = lo; s_anch[++k] = cur;
+                }
+                s_nanch = k + 1;
+            }
+            __syncthreads();
+            const uint32_t na = s_nanch;
+            for (uint32_t i = tid; i < m; i += 256) {
+                uint32_t lo = 0, hi = na - 1;                                               // last anchor <= i
+                while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (s_anch[mid] <= i) lo = mid; else hi = mid - 1; }
+                const uint32_t an = s_anch[lo];
+                if (an != i) cand[(uint32_t)(E[a + i] >> 16) & 0xFFFFu] = (uint16_t)((uint32_t)(E[a + an] >> 16) & 0xFFFFu);
+            }
+            __syncthreads();
+            continue;
+        }
         for (uint32_t i = tid; i < LZ_MAX_BLOCK / 32 + 2; i += 256) s_bm[i] = 0;
         if (tid < LZ_MAX_BLOCK / 1024 + 2) s_bm1[tid] = 0;
         if (m <= LZ_GIANT_CAP) {

@@ -65,3 +65,22 @@ def test_source_code_like(flavour, wbits):
 @pytest.mark.parametrize("block", [4096, 10000, 65536])
 def test_block_sizes(block):
     _check(synth.enwik_like(150_000, seed=9).numpy(), "deflate", None, block)
+
+
+@pytest.mark.parametrize("flavour,wbits", CONFIGS)
+@pytest.mark.parametrize("run", [5000, 10000, 20000, 40000])
+def test_zero_run_inside_random(flavour, wbits, run):
+    """a long single-byte run inside random data: one giant cluster that foreign entries join (the general fallback
+    replay, in LDS up to 18432 entries and through global scratch beyond); the pure-run closed form must NOT fire"""
+    rng = np.random.default_rng(run)
+    data = rng.integers(0, 256, 65536 + 3000, dtype=np.uint8)
+    data[9000:9000 + run] = 0
+    _check(data, flavour, wbits)
+
+
+@pytest.mark.parametrize("flavour,wbits", CONFIGS)
+def test_pure_runs_closed_form(flavour, wbits):
+    """blocks that are one byte value throughout (closed form: anchors) next to a block that is not"""
+    data = np.concatenate([np.zeros(65536, np.uint8), np.full(65536, 0x41, np.uint8),
+                           synth.enwik_like(65536, seed=3).numpy(), np.full(30000, 0xFF, np.uint8)])
+    _check(data, flavour, wbits)
