@@ -153,23 +153,46 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
 
     // ---- gather: positions (coalesced) and their words (4 unaligned bytes each from the block; bytes
     //      past the block end read as zero, the parity definition of the reference's over-read)
-    for (uint32_t j = tid; j < m; j += LZ2_THREADS) {
-        const uint32_t p = plist[j];
-        s_pos[j] = (uint16_t)p;
-        uint32_t w = 0;
-        if (p + 8 <= nblk && (((uintptr_t)src) & 3u) == 0) {
-            const uint8_t *q = src + p;
-            const uintptr_t a = (uintptr_t)q & ~(uintptr_t)3;
-            const uint32_t sh = ((uintptr_t)q & 3u) * 8u;
-            const uint32_t lo = *reinterpret_cast<const uint32_t *>(a);
-            if (sh == 0) w = lo;
-            else w = (lo >> sh) | (*reinterpret_cast<const uint32_t *>(a + 4) << (32u - sh));
-        } else {
-            for (uint32_t k = 0; k < 4 && p + k < nblk; ++k) w |= (uint32_t)src[p + k] << (8 * k);
+    {
+        // all of a thread's positions first, then all of their words, then the hashing: the two dependent global loads of
+        // every entry are in flight together instead of one entry at a time
+        constexpr uint32_t GCH = LZ2_CAP / LZ2_THREADS;
+        uint32_t gp[GCH], glo[GCH], ghi[GCH];
+        const bool aligned = (((uintptr_t)src) & 3u) == 0;
+#pragma unroll
+        for (uint32_t c = 0; c < GCH; ++c) { const uint32_t j = tid + c * LZ2_THREADS; gp[c] = j < m ? (uint32_t)plist[j] : 0u; }
+#pragma unroll
+        for (uint32_t c = 0; c < GCH; ++c) {
+            const uint32_t j = tid + c * LZ2_THREADS, p = gp[c];
+            glo[c] = 0; ghi[c] = 0;
+            if (j < m) {
+                if (p + 8 <= nblk && aligned) {
+                    const uintptr_t a = (uintptr_t)(src + p) & ~(uintptr_t)3;
+                    glo[c] = *reinterpret_cast<const uint32_t *>(a);
+                    ghi[c] = *reinterpret_cast<const uint32_t *>(a + 4);
+                } else {
+                    // bytes past the block end read as zero (the parity definition of the reference's over-read)
+                    uint32_t w = 0;
+                    for (uint32_t k = 0; k < 4 && p + k < nblk; ++k) w |= (uint32_t)src[p + k] << (8 * k);
+                    glo[c] = w;
+                }
+            }
         }
-        // every step of the reference hash is invertible (odd multipliers, rotations, xor-shifts), so the mixed
-        // value identifies the word: keep it instead of the word — the home is a mask away, equality is equality
-        s_word[j] = lz_mix32(w);
+#pragma unroll
+        for (uint32_t c = 0; c < GCH; ++c) {
+            const uint32_t j = tid + c * LZ2_THREADS, p = gp[c];
+            if (j < m) {
+                uint32_t w = glo[c];
+                if (p + 8 <= nblk && aligned) {
+                    const uint32_t sh = ((uint32_t)((uintptr_t)(src + p) & 3u)) * 8u;
+                    if (sh) w = (glo[c] >> sh) | (ghi[c] << (32u - sh));
+                }
+                s_pos[j] = (uint16_t)p;
+                // every step of the reference hash is invertible (odd multipliers, rotations, xor-shifts), so the mixed
+                // value identifies the word: keep it instead of the word — the home is a mask away, equality is equality
+                s_word[j] = lz_mix32(w);
+            }
+        }
     }
     for (uint32_t i = tid; i < LZ2_CAP / 32 + 2; i += LZ2_THREADS) s_bm[i] = 0;
     if (tid == 0) { s_zslot = ~0u; s_zgid = ~0u; s_nbigl = 0; }
