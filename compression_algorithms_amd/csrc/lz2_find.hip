@@ -574,9 +574,12 @@ __device__ __forceinline__ void big_replay(uint32_t *s_occ, uint16_t *s_slot, ui
     // position of the oldest entry still in the table, kept in a scalar: "nothing to retire" is one compare per step
     uint32_t ev_pos = lane < n ? bp[lane] : 0u;
     uint32_t pe = RLANE(ev_pos, 0);
+    uint32_t n_pos = ev_pos, n_rs = 0, n_pid = 0;                   // the next 64 entries are in flight while these are replayed
+    if (lane < n) { n_rs = br[lane]; n_pid = bi[lane]; }
     for (uint32_t i0 = 0; i0 < n; i0 += 64) {
         const uint32_t ii = i0 + lane;
-        if (ii < n) { c_pos = bp[ii]; c_rs = br[ii]; c_pid = bi[ii]; }
+        c_pos = n_pos; c_rs = n_rs; c_pid = n_pid;
+        if (ii + 64 < n) { n_pos = bp[ii + 64]; n_rs = br[ii + 64]; n_pid = bi[ii + 64]; }
         const uint32_t lim = (n - i0) < 64u ? (n - i0) : 64u;
         for (uint32_t t = 0; t < lim; ++t) {
             const uint32_t i = i0 + t;
