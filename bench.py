@@ -53,7 +53,8 @@ def make_step(workload, x, ctx):
         holder = {}
 
         def step():
-            holder["st"] = lz.compress(x, p, ctx)
+            holder["st"] = None          # release the previous output first: the caching allocator then reuses its block
+            holder["st"] = lz.compress(x, p, ctx)      # (otherwise the first timed step pays a 2 GB hipMalloc)
 
         desc = {"deflate": "deflate tokeniser (LZ77, W=32 KiB, len<=31, byte tokens), independent 64 KiB blocks",
                 "lz77w16": "lz77 (W=64 KiB, len<=15, bit-packed), independent 64 KiB blocks",
@@ -64,6 +65,7 @@ def make_step(workload, x, ctx):
         p = lz.params("deflate")
 
         def step():
+            holder["st"] = None
             holder["st"] = lz.compress_h(x, p, ctx)
 
         return step, (lambda: holder["st"].nbytes), (lambda: holder["st"]), "u8", \
@@ -72,6 +74,7 @@ def make_step(workload, x, ctx):
         holder = {}
 
         def step():
+            holder["r"] = None
             holder["r"] = huffman.huffman_compress(x, ctx)
 
         return step, (lambda: (holder["r"].total_bits + 7) // 8), (lambda: holder["r"]), "u8", "whole-buffer Huffman, one tree"
@@ -81,6 +84,7 @@ def make_step(workload, x, ctx):
         p = fse.params()
 
         def step():
+            holder["r"] = None
             holder["r"] = fse.compress(x, p, ctx)
 
         return step, (lambda: holder["r"].nbytes), (lambda: holder["r"]), "u8", "FSE/tANS table_log 8, independent 64 KiB blocks x 64 sub-streams"
