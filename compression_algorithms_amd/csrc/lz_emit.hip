@@ -86,9 +86,16 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     const uint32_t nbig = lists ? s2.meta[lb].nbig_entries : 0u;
     // (position, candidate) pairs of a list, 8 per lane per step: two 16-byte loads instead of sixteen 2-byte ones
     auto for_each_pair = [&](const uint16_t *lp, const uint16_t *lc, uint32_t cnt, auto &&fn) {
-        for (uint32_t j0 = tid * 8u; j0 < cnt; j0 += 1024u * 8u) {
+        // the next 8 pairs are in flight while these are worked on (the body is LDS work the compiler will not hoist
+        // the loads over: measured, this loop was waiting on HBM, not on LDS)
+        uint4 np = make_uint4(0, 0, 0, 0), nc = make_uint4(0, 0, 0, 0);
+        uint32_t j0 = tid * 8u;
+        if (j0 + 8u <= cnt) { np = *reinterpret_cast<const uint4 *>(lp + j0); nc = *reinterpret_cast<const uint4 *>(lc + j0); }
+        for (; j0 < cnt; j0 += 1024u * 8u) {
             if (j0 + 8u <= cnt) {
-                const uint4 vp = *reinterpret_cast<const uint4 *>(lp + j0), vc = *reinterpret_cast<const uint4 *>(lc + j0);
+                const uint4 vp = np, vc = nc;
+                const uint32_t j1 = j0 + 1024u * 8u;
+                if (j1 + 8u <= cnt) { np = *reinterpret_cast<const uint4 *>(lp + j1); nc = *reinterpret_cast<const uint4 *>(lc + j1); }
                 const uint32_t wp[4] = {vp.x, vp.y, vp.z, vp.w}, wc[4] = {vc.x, vc.y, vc.z, vc.w};
 #pragma unroll
                 for (int k = 0; k < 8; ++k) fn((wp[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu, (wc[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu);
@@ -97,9 +104,56 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
             }
         }
     };
+    // token lengths of a list, eight pairs at a time: the first compare step (bytes 4..7 — where most matches of a text
+    // end) of all eight is issued together; a per-pair loop would walk its LDS round trips one pair after the other
+    auto lengths_of_list = [&](const uint16_t *lp, const uint16_t *lc, uint32_t cnt) {
+        uint4 np = make_uint4(0, 0, 0, 0), nc = make_uint4(0, 0, 0, 0);
+        uint32_t j0 = tid * 8u;
+        if (j0 + 8u <= cnt) { np = *reinterpret_cast<const uint4 *>(lp + j0); nc = *reinterpret_cast<const uint4 *>(lc + j0); }
+        for (; j0 < cnt; j0 += 1024u * 8u) {
+            if (j0 + 8u <= cnt) {
+                const uint4 vp = np, vc = nc;
+                const uint32_t j1 = j0 + 1024u * 8u;
+                if (j1 + 8u <= cnt) { np = *reinterpret_cast<const uint4 *>(lp + j1); nc = *reinterpret_cast<const uint4 *>(lc + j1); }
+                const uint32_t wp[4] = {vp.x, vp.y, vp.z, vp.w}, wc[4] = {vc.x, vc.y, vc.z, vc.w};
+                uint32_t pp[8], cc[8], xx[8];
+                bool act[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    pp[k] = (wp[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu; cc[k] = (wc[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+                    const uint32_t dist = pp[k] - cc[k];
+                    // a candidate that the literal rule does not reject (deflate lz77.c:223 / lz77.c:290); c == p: pending or pad
+                    act[k] = cc[k] != LZ_NONE16 && cc[k] != pp[k] && !(P.deflate ? (dist >= W - 1u) : (dist == W));
+                    xx[k] = 0;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if (act[k]) xx[k] = lds_word(s_r0, cc[k] + 4u) ^ lds_word(s_r0, pp[k] + 4u);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (cc[k] == pp[k]) continue;                      // pending / pad: the other list (or nobody) writes it
+                    uint32_t len = 0;
+                    if (act[k]) {
+                        if (xx[k]) len = 4u + ((uint32_t)__builtin_ctz(xx[k]) >> 3);
+                        else {
+                            len = 8;
+                            while (len < max_len) {
+                                const uint32_t x = lds_word(s_r0, cc[k] + len) ^ lds_word(s_r0, pp[k] + len);
+                                if (x) { len += (uint32_t)__builtin_ctz(x) >> 3; break; }
+                                len += 4;
+                            }
+                        }
+                        if (len > max_len) len = max_len;
+                    }
+                    s_L[pp[k]] = (uint8_t)len;
+                }
+            } else {
+                for (uint32_t j = j0; j < cnt; ++j) { const uint32_t p = lp[j], c = lc[j]; if (c != p) s_L[p] = (uint8_t)token_len(p, c); }
+            }
+        }
+    };
     if (lists) {
-        for_each_pair(l_pos, l_cand, n, [&](uint32_t p, uint32_t c) { if (c != p) s_L[p] = (uint8_t)token_len(p, c); });
-        for_each_pair(b_pos, b_cand, nbig, [&](uint32_t p, uint32_t c) { if (c != p) s_L[p] = (uint8_t)token_len(p, c); });    // c == p: an alignment pad
+        lengths_of_list(l_pos, l_cand, n);
+        lengths_of_list(b_pos, b_cand, nbig);
     } else {
         for (uint32_t p = tid; p < n; p += 1024u) s_L[p] = (uint8_t)token_len(p, cand[p]);
     }
