@@ -279,28 +279,40 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
         if (tid == 0) sc.block_bits[lb] = ntok;
         return;
     }
+    // a token's fields; a literal's byte comes from global memory (the block's LDS copy is long overwritten), so the
+    // lookups and byte loads of round r+1 are issued before round r goes through its barriers
+    struct Tok { uint64_t q; uint32_t v, nbits, byte; bool valid, lit; };
+    auto look = [&](uint32_t t, Tok &k) {
+        k.q = 0; k.v = 0; k.nbits = 0; k.byte = 0; k.lit = false;
+        k.valid = t < ntok;
+        if (k.valid) {
+            const uint32_t c = chunk_of(t), o = select_bit(s_tok[c], t - tb[c]);   // last chunk with tb[c] <= t
+            const uint32_t p = c * 64u + o;
+            const uint64_t below = (1ull << o) - 1ull;
+            const uint32_t mbefore = mb[c] + (uint32_t)__popcll(s_mat[c] & below);
+            k.q = (uint64_t)(t - mbefore) * LB + (uint64_t)mbefore * MB;
+            if ((s_mat[c] >> o) & 1ull) {
+                const uint32_t d = lists ? (uint32_t)md[mbefore] : p - cand[p], l = s_L[p];
+                k.v = P.deflate ? (1u | (d << 8) | (l << 24)) : (1u | (d << 1) | (l << (1u + P.wbits)));
+                k.nbits = MB;
+            } else {
+                k.lit = true; k.byte = src[p];
+                k.nbits = LB;
+            }
+        }
+    };
+    Tok cur[2], nxt[2];
+    look((uint32_t)tid, cur[0]); look(1024u + (uint32_t)tid, cur[1]);
     for (uint32_t t0 = 0; t0 < ntok; t0 += 2048u) {
-        uint64_t q[2] = {0, 0}; uint32_t v[2] = {0, 0}, nbits[2] = {0, 0};
+        look(t0 + 2048u + (uint32_t)tid, nxt[0]); look(t0 + 3072u + (uint32_t)tid, nxt[1]);
+        uint64_t q[2]; uint32_t v[2], nbits[2];
         bool valid[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const uint32_t t = t0 + (uint32_t)u * 1024u + tid;
-            valid[u] = t < ntok;
+            valid[u] = cur[u].valid; q[u] = cur[u].q; nbits[u] = cur[u].nbits;
+            v[u] = cur[u].lit ? (P.deflate ? (cur[u].byte << 8) : (cur[u].byte << 1)) : cur[u].v;
             if (valid[u]) {
-                const uint32_t c = chunk_of(t), o = select_bit(s_tok[c], t - tb[c]);   // last chunk with tb[c] <= t
-                const uint32_t p = c * 64u + o;
-                const uint64_t below = (1ull << o) - 1ull;
-                const uint32_t mbefore = mb[c] + (uint32_t)__popcll(s_mat[c] & below);
-                q[u] = (uint64_t)(t - mbefore) * LB + (uint64_t)mbefore * MB;
-                if ((s_mat[c] >> o) & 1ull) {
-                    const uint32_t d = lists ? (uint32_t)md[mbefore] : p - cand[p], l = s_L[p];
-                    v[u] = P.deflate ? (1u | (d << 8) | (l << 24)) : (1u | (d << 1) | (l << (1u + P.wbits)));
-                    nbits[u] = MB;
-                } else {
-                    const uint32_t byte = src[p];
-                    v[u] = P.deflate ? (byte << 8) : (byte << 1);
-                    nbits[u] = LB;
-                }
                 if (u == 0 && tid == 0) s_q0 = q[0];
                 if (t == ntok - 1 || (u == 1 && tid == 1023)) s_q1 = q[u] + nbits[u];
             }
@@ -324,6 +336,7 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
         for (uint32_t i = tid; i < ncomplete; i += 1024u) slot[w0 + i] = stage[i];
         carry = stage[ncomplete];
         __syncthreads();
+        cur[0] = nxt[0]; cur[1] = nxt[1];
     }
     PE_TICK(6);
     if (s2.dbg && tid == 0) atomicAdd((unsigned long long *)&s2.dbg[31], 1ull);
