@@ -1,16 +1,20 @@
 // lz2_find.hip — stage 2 and 3 of the LDS-resident match finder.
 //
-//   k_lz2_find   one workgroup per part (<= LZ2_CAP positions whose clusters lie inside the
-//                part, certified by stage 1).  Everything happens in LDS: words gathered once,
-//                positions sorted by home (3 stable radix passes), clusters from the parking
-//                sweep, a second sort by (cluster, time), then every cluster below LZ2_BIG
-//                entries is replayed by one lane; larger ones are exported.
-//   k_lz2_big    one WAVE per exported cluster: the occupancy bitmap lives in registers
-//                (4 dwords per lane), first-fit is a wave min-reduction instead of LDS round
-//                trips, entries stream through registers 64 at a time.  LDS holds only
-//                slot -> (word id, position) and entry -> slot, 6 bytes per entry, so dozens
-//                of clusters are in flight per CU and the serial chain of one cluster hides
-//                behind the others.
+//   k_lz2_find        one workgroup per part (<= LZ2_CAP positions whose clusters lie inside the part, certified by
+//                     stage 1).  Everything happens in LDS: words gathered once (mixed: home = mask, equality =
+//                     equality), positions sorted by home (2-3 stable 8-bit radix passes), clusters / dense home
+//                     slots / word ids from the parking sweep, a second sort by (cluster, time).  Then
+//                       - while a cluster has retired nothing, find() is the first occurrence of the word = the word
+//                         id: quiet clusters are answered without any replay, and lz77 with a window
+//                         that covers the block stops right after the sweep;
+//                       - clusters of 2..7 entries are replayed one lane each, their table in two registers;
+//                       - larger ones are exported on 16-byte boundaries, by size class.
+//   k_lz2_mid_direct  lane per exported cluster of 8..127 entries (64 clusters per wave, LDS regions per lane),
+//                     eight entries per load.
+//   k_lz2_big         one WAVE per exported cluster of >= 128 entries: occupancy bitmap in registers, first fit by
+//                     ballot + v_readlane, 6 bytes of LDS per entry; bound by scalar-instruction issue.
+//   k_lz2_row         the same by a 16-lane DPP row per cluster (opt-in, measured slower: lz2_carve).
+//   k_lz2_scatter     lists -> by-position array (test hook and fallback boundary).
 //
 // Replaces the same reference functions as lz_find.hip (hash / insert_hash_table / find,
 // algorithms/lz77/lz77.c:13-108 and algorithms/deflate/lz77.c:14-174).
