@@ -46,7 +46,7 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     __shared__ uint64_t s_scan64[18];
     __shared__ uint32_t s_scan32[18];
     __shared__ uint32_t s_thr[LZ2_MAXPARTS + 1];     // part k = home' in [s_thr[k], s_thr[k+1])
-    __shared__ uint32_t s_pstart[LZ2_MAXPARTS + 1], s_pdone[LZ2_MAXPARTS], s_seg[LZ2_MAXPARTS + 1];
+    __shared__ uint32_t s_pstart[LZ2_MAXPARTS + 1];
     __shared__ uint32_t s_s0, s_flag;
 
     const int tid = threadIdx.x;
@@ -154,7 +154,6 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
         };
         const uint32_t cnt = b > a ? cnt_below(b) - cnt_below(a) : 0u;
         s_pstart[tid] = cnt_below(a);
-        s_pdone[tid] = 0;
         if (cnt > LZ2_CAP) atomicOr(&s_flag, 1u);
         mt->part_start[tid] = cnt_below(a);
         mt->part_count[tid] = cnt;
@@ -173,55 +172,28 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     }
     if (s_flag != 0 || (P.deflate && no_safe)) return;
 
-    // ---- positions -> part lists, time order kept: 8192 positions at a time through LDS
-    uint16_t *stage = reinterpret_cast<uint16_t *>(s_grp);              // [8192], the group array is dead now
-    uint8_t  *stage_part = reinterpret_cast<uint8_t *>(s_grp) + 16384;  // [8192]
+    // ---- positions -> part lists, time order kept: ONE stable radix pass over the whole block by part number.  The part of
+    //      every position is tabulated first (one hash per position), the pass then stores straight to the block's list in
+    //      HBM: consecutive positions of one part land on consecutive addresses, and the exclusive scan over the parts is
+    //      exactly the list layout (part k starts at the number of entries in parts < k).  (Staging 8192 positions at a
+    //      time through LDS paid the pass's fixed costs eight times: 7.5 -> see DESIGN.md for the measurement.)
     uint16_t *plist = sc.plist + (size_t)lb * LZ_MAX_BLOCK;
-    // part of every rotated group, tabulated once (part boundaries are group boundaries): a position's part is then one
-    // LDS read instead of a five-step binary search over the thresholds
-    uint8_t  *gpart = reinterpret_cast<uint8_t *>(s_grp) + 32768;      // [LZ2_NG]
+    uint8_t  *part_in = reinterpret_cast<uint8_t *>(s_grp);             // [65536] part of every position; the group array is dead now
+    __shared__ uint8_t s_gpart[LZ2_NG];                                 // part of every rotated group (part boundaries are group boundaries)
     for (uint32_t gr = tid; gr < LZ2_NG; gr += 1024) {
         const uint32_t h = gr << gshift;
         uint32_t lo = 0, hi = K - 1;                    // last k with thr[k] <= h
         while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (s_thr[mid] <= h) lo = mid; else hi = mid - 1; }
-        gpart[gr] = (uint8_t)lo;
+        s_gpart[gr] = (uint8_t)lo;
     }
     __syncthreads();
-    auto part_of = [&](uint32_t p) -> uint32_t { return gpart[((home_of(p) - base) & Tmask) >> gshift]; };
-    uint8_t  *part_in = reinterpret_cast<uint8_t *>(s_grp) + 24576;    // [8192] part of every position of the slab (hashed once)
-    for (uint32_t e0 = 0; e0 < n; e0 += 8192u) {
-        const uint32_t en = (n - e0) < 8192u ? (n - e0) : 8192u;
-        for (uint32_t i = tid; i < en; i += 1024) part_in[i] = (uint8_t)part_of(e0 + i);
-        __syncthreads();
-        radix_pass_1024<5, uint32_t>(en, s_cnt,
-            [&](uint32_t i) { return (e0 + i) | ((uint32_t)part_in[i] << 16); },
-            [&](uint32_t e) { return e >> 16; },
-            [&](uint32_t j, uint32_t e) { stage[j] = (uint16_t)e; stage_part[j] = (uint8_t)(e >> 16); });
-        // segment starts of this slab: first index of each part in the staged order
-        if (tid <= (int)K) s_seg[tid] = en;
-        __syncthreads();
-        for (uint32_t i = tid; i < en; i += 1024) {
-            const uint32_t pk = stage_part[i];
-            if (i == 0 || stage_part[i - 1] != pk) s_seg[pk] = i;
-        }
-        __syncthreads();
-        for (uint32_t i = tid; i < en; i += 1024) {
-            const uint32_t pk = stage_part[i];
-            plist[s_pstart[pk] + s_pdone[pk] + (i - s_seg[pk])] = stage[i];
-        }
-        __syncthreads();
-        if (tid < (int)K) {
-            // count of part tid in this slab = next present segment start - own start
-            uint32_t nxt = en;
-            if (s_seg[tid] != en) {
-                for (uint32_t k2 = tid + 1; k2 < K; ++k2) if (s_seg[k2] != en) { nxt = s_seg[k2]; break; }
-                s_pdone[tid] += nxt - s_seg[tid];
-            }
-        }
-        __syncthreads();
-    }
+    for (uint32_t p = tid; p < n; p += 1024) part_in[p] = s_gpart[((home_of(p) - base) & Tmask) >> gshift];
+    __syncthreads();
+    radix_pass_1024<5, uint32_t>(n, s_cnt,
+        [&](uint32_t i) { return i | ((uint32_t)part_in[i] << 16); },
+        [&](uint32_t e) { return e >> 16; },
+        [&](uint32_t j, uint32_t e) { plist[j] = (uint16_t)e; });
 }
-
 
 void lz2_launch_partition(const uint8_t *d_in, uint64_t n, const LzP &P, const Lz2Scratch &sc, uint64_t block0, uint32_t nb, hipStream_t s)
 {
