@@ -237,8 +237,9 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     const uint32_t mbase = block_exclusive_scan<uint32_t>((uint32_t)__popcll(my_mat), OpAddU32(), 0u, s_scan, &nmat);
     uint32_t *tb = reinterpret_cast<uint32_t *>(s_r0);            // [1025]
     uint32_t *mb = tb + 1026;                                      // [1025]
-    uint32_t *stage = mb + 1026;                                   // [2048 + 8]
-    uint16_t *md = reinterpret_cast<uint16_t *>(stage + 2064);   // [<= 16384] distance of the k-th match token
+    uint32_t *stage = mb + 1026;                                   // [TPR * 1024 + 16]
+    constexpr uint32_t TPR = 4;                                   // tokens per thread and emit round
+    uint16_t *md = reinterpret_cast<uint16_t *>(stage + TPR * 1024 + 16);   // [<= 16384] distance of the k-th match token
     uint16_t *tch = md + 16384;                                    // [<= 1024] chunk that holds token 64 * k
     tb[tid] = tbase; mb[tid] = mbase;
     if (tid == 0) { tb[1024] = ntok; mb[1024] = nmat; }
@@ -301,20 +302,22 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
             }
         }
     };
-    Tok cur[2], nxt[2];
-    look((uint32_t)tid, cur[0]); look(1024u + (uint32_t)tid, cur[1]);
-    for (uint32_t t0 = 0; t0 < ntok; t0 += 2048u) {
-        look(t0 + 2048u + (uint32_t)tid, nxt[0]); look(t0 + 3072u + (uint32_t)tid, nxt[1]);
-        uint64_t q[2]; uint32_t v[2], nbits[2];
-        bool valid[2];
+    Tok cur[TPR], nxt[TPR];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint32_t t = t0 + (uint32_t)u * 1024u + tid;
+    for (uint32_t u = 0; u < TPR; ++u) look(u * 1024u + (uint32_t)tid, cur[u]);
+    for (uint32_t t0 = 0; t0 < ntok; t0 += TPR * 1024u) {
+#pragma unroll
+        for (uint32_t u = 0; u < TPR; ++u) look(t0 + (TPR + u) * 1024u + (uint32_t)tid, nxt[u]);
+        uint64_t q[TPR]; uint32_t v[TPR], nbits[TPR];
+        bool valid[TPR];
+#pragma unroll
+        for (uint32_t u = 0; u < TPR; ++u) {
+            const uint32_t t = t0 + u * 1024u + tid;
             valid[u] = cur[u].valid; q[u] = cur[u].q; nbits[u] = cur[u].nbits;
             v[u] = cur[u].lit ? (P.deflate ? (cur[u].byte << 8) : (cur[u].byte << 1)) : cur[u].v;
             if (valid[u]) {
                 if (u == 0 && tid == 0) s_q0 = q[0];
-                if (t == ntok - 1 || (u == 1 && tid == 1023)) s_q1 = q[u] + nbits[u];
+                if (t == ntok - 1 || (u == TPR - 1 && tid == 1023)) s_q1 = q[u] + nbits[u];
             }
         }
         __syncthreads();
@@ -324,7 +327,7 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
         for (uint32_t i = tid; i < nwords + 1; i += 1024u) stage[i] = (i == 0) ? carry : 0u;
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (uint32_t u = 0; u < TPR; ++u) {
             if (valid[u]) {
                 const uint32_t rel = (uint32_t)(q[u] - (w0 << 5)), wi = rel >> 5, sh = rel & 31u;
                 atomicOr(&stage[wi], v[u] << sh);
@@ -336,7 +339,8 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
         for (uint32_t i = tid; i < ncomplete; i += 1024u) slot[w0 + i] = stage[i];
         carry = stage[ncomplete];
         __syncthreads();
-        cur[0] = nxt[0]; cur[1] = nxt[1];
+#pragma unroll
+        for (uint32_t u = 0; u < TPR; ++u) cur[u] = nxt[u];
     }
     PE_TICK(6);
     if (s2.dbg && tid == 0) atomicAdd((unsigned long long *)&s2.dbg[31], 1ull);
