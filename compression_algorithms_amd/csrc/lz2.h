@@ -5,11 +5,9 @@
 #define LZ2_NG_BITS   14
 #define LZ2_NG        (1u << LZ2_NG_BITS)   // bucket groups per block for the overflow certificate
 // tuning points (overridable at build time for A/B runs: make OUT=... EXTRA="-DLZ2_THREADS=..."; MI_CODEC_LIB selects the
-// library at run time).  Same-box A/B on MI355X, 1 GB deflate: 2304 / 3584 / 512 threads 11.29 GB/s; 2048 / 3072 / 768
-// threads 11.03; 2048 / 3072 / 1024 threads 11.07 — the kernel is not short of waves.
-#ifndef LZ2_TS
-#define LZ2_TS        2304u                 // target entries per part
-#endif
+// library at run time).  Same-box A/B on MI355X, 1 GB deflate, when parts still had a target size: target 2304 / capacity
+// 3584 / 512 threads 11.29 GB/s; 2048 / 3072 / 768 threads 11.03; 2048 / 3072 / 1024 threads 11.07 — the kernel is not
+// short of waves.  Parts are now cut greedily up to the capacity (lz2_partition.hip).
 #ifndef LZ2_CAP
 #define LZ2_CAP       3584u                 // LDS capacity of a part (entries): 2 workgroups of k_lz2_find per CU
 #endif
@@ -18,7 +16,6 @@
 #endif
 #define LZ2_NWAVES    (LZ2_THREADS / 64)
 #define LZ2_MAXPARTS  32u
-static_assert((LZ_MAX_BLOCK + LZ2_TS - 1) / LZ2_TS <= LZ2_MAXPARTS, "a block may not be cut into more than LZ2_MAXPARTS parts");
 static_assert(LZ2_CAP % LZ2_THREADS == 0, "entries per thread must be whole");
 #define LZ2_BIG       8u                    // clusters of at least this many entries leave k_lz2_find
 #define LZ2_WAVE      128u                  // ... and from this size on a whole wave replays one cluster
@@ -69,6 +66,7 @@ struct Lz2Scratch {
     uint16_t     *cand;         // [nb][65536] find() result aligned with plist (own position = pending: see bigcand)
     Lz2BlockMeta *meta;         // [nb]
     uint32_t     *fallback_count, *fallback_list;    // blocks the first pipeline has to do
+    uint32_t     *work_count, *work;                 // parts of the batch, appended by the partition: block | part << 16
     uint16_t     *bigpos, *bigrs, *bigpid, *bigcand; // [nb][LZ2_BIG_STRIDE] entries of exported clusters, (cluster, time) order
     Lz2BigDesc   *desc[LZ2_NCLASS];                  // per class: [nb * capacity of the class]
     uint32_t     *big_count;                         // [LZ2_NCLASS]

@@ -140,7 +140,9 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     static_assert(3 * LZ2_MAXBIG * 4 + 2 * LZ2_MAXBIG * 2 <= sizeof(uint32_t) * LZ2_NWAVES * 256, "export lists must fit the radix counters");
 
     const int tid = threadIdx.x;
-    const uint32_t lb = blockIdx.y, part = blockIdx.x;
+    if (blockIdx.x >= *sc.work_count) return;           // the grid covers the worst case; the listed parts come first
+    const uint32_t item = sc.work[blockIdx.x];
+    const uint32_t lb = item & 0xFFFFu, part = item >> 16;
     Lz2BlockMeta *mt = sc.meta + lb;
     long long tk = clock64();
 #define LZ2_TICK(k) do { if (sc.dbg && tid == 0) { long long t2 = clock64(); atomicAdd((unsigned long long *)&sc.dbg[k], (unsigned long long)(t2 - tk)); tk = t2; } } while (0)
@@ -928,7 +930,7 @@ static uint32_t lz2_class_cap(uint32_t c)
 
 size_t lz2_scratch_bytes(uint32_t nb)
 {
-    return (size_t)nb * (LZ_MAX_BLOCK * 2 * 2 + LZ2_BIG_STRIDE * 2 * 4 + sizeof(Lz2BlockMeta) + 4 + 3 * LZ2_DESC_SMALL * sizeof(Lz2BigDesc)) + 16 * 256 + 4096;
+    return (size_t)nb * (LZ_MAX_BLOCK * 2 * 2 + LZ2_BIG_STRIDE * 2 * 4 + sizeof(Lz2BlockMeta) + 4 + 4 * LZ2_MAXPARTS + 3 * LZ2_DESC_SMALL * sizeof(Lz2BigDesc)) + 16 * 256 + 4096;
 }
 
 void lz2_carve(mi_carver &cv, uint32_t nb, Lz2Scratch *sc)
@@ -944,6 +946,8 @@ void lz2_carve(mi_carver &cv, uint32_t nb, Lz2Scratch *sc)
     sc->bigcand = cv.take<uint16_t>((size_t)nb * LZ2_BIG_STRIDE);
     for (uint32_t c = 0; c < LZ2_NCLASS; ++c) sc->desc[c] = cv.take<Lz2BigDesc>((size_t)nb * lz2_class_cap(c));
     sc->big_count = sc->fallback_count + 16;
+    sc->work_count = sc->fallback_count + 32;            // zeroed with the other counters by stage 1
+    sc->work = cv.take<uint32_t>((size_t)nb * LZ2_MAXPARTS);
     sc->dbg = getenv("MI_LZ_DEBUG") ? cv.take<uint64_t>(32) : nullptr;
     sc->wave_min = LZ2_WAVE;
     // quarter-wave replay of 128..1024-entry clusters (k_lz2_row) is OPT-IN: alone it is no faster than k_lz2_big
@@ -980,8 +984,9 @@ mi_status lz2_stage_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_
                          const Lz2Scratch &sc, hipStream_t s)
 {
     mi_prof_scope p(ctx, "k_lz2_find", s, (uint64_t)nb * P.block);
-    const uint32_t parts = (P.block + LZ2_TS - 1) / LZ2_TS;
-    hipLaunchKernelGGL(k_lz2_find, dim3(parts, nb), dim3(LZ2_THREADS), 0, s, d_in, n, P, sc, block0);
+    // the partition cuts at most LZ2_MAXPARTS parts per block (greedy, data dependent: ~19 for a full block) and lists them
+    const uint32_t parts = P.block / 64u + 1u < LZ2_MAXPARTS ? P.block / 64u + 1u : LZ2_MAXPARTS;
+    hipLaunchKernelGGL(k_lz2_find, dim3(parts * nb), dim3(LZ2_THREADS), 0, s, d_in, n, P, sc, block0);
     MI_HIP(ctx, hipGetLastError());
     return MI_OK;
 }

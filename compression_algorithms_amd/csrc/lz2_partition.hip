@@ -128,23 +128,36 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
         const uint32_t g = (gstart + gr) & (LZ2_NG - 1u);
         return (s_safe[g >> 5] >> (g & 31u)) & 1u;
     };
-    const uint32_t K = (n + LZ2_TS - 1) / LZ2_TS;       // <= LZ2_MAXPARTS
-    if (tid < K + 1) {
-        uint32_t thr;
-        if (tid == 0) thr = 0;
-        else if ((uint32_t)tid == K) thr = T;           // the last part takes everything up to the cut
-        else {
-            const uint32_t target = tid * LZ2_TS;
-            uint32_t lo = 0, hi = LZ2_NG - 1;           // first rotated group whose inclusive count exceeds target
-            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cum_incl(mid) > target) hi = mid; else lo = mid + 1; }
-            // boundary after the last certified group strictly before `lo`
-            int32_t gr = (int32_t)lo - 1;
-            while (gr >= 0 && !is_safe((uint32_t)gr)) --gr;
-            thr = gr < 0 ? 0u : ((uint32_t)gr + 1u) << gshift;
+    // Greedy cuts: every part takes as many entries as stage 2 can hold (LZ2_CAP), ending at the last certified group
+    // that fits.  A fixed target with a fixed margin (parts of TS + "how far back the cut had to move") fails as soon as
+    // a block holds one cluster larger than the margin — measured: target 3072 gave +5 % on one corpus and a 6x collapse
+    // (every block in the fallback) on another seed whose text has a 1000-entry cluster — while greedy parts only fail when
+    // a single cluster exceeds LZ2_CAP.  The cuts depend on each other, so one lane walks them (<= 32 binary searches).
+    __shared__ uint32_t s_K;
+    if (tid == 0) {
+        uint32_t k = 0, cur = 0, glo = 0;               // parts so far, entries before the current part, its first rotated group
+        bool bad = false;
+        s_thr[0] = 0;
+        while (n - cur > LZ2_CAP) {
+            const uint32_t limit = cur + LZ2_CAP;
+            // (a part of a 2^20-bucket table is also kept below 2^16 homes: stage 2 then sorts 16-bit keys in two radix
+            //  passes instead of three; a 2^22-bucket table spreads 3584 entries over ~2^18 homes whatever the cut)
+            const uint32_t span = (gshift <= 6u) ? (65536u >> gshift) : LZ2_NG;
+            uint32_t lo = glo, hi = (glo + span < LZ2_NG) ? glo + span : LZ2_NG - 1;   // first rotated group whose inclusive count exceeds the limit
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cum_incl(mid) > limit) hi = mid; else lo = mid + 1; }
+            int32_t gr = (int32_t)lo - 1;               // boundary after the last certified group before it, inside this part
+            while (gr >= (int32_t)glo && !is_safe((uint32_t)gr)) --gr;
+            if (gr < (int32_t)glo || k + 2 > LZ2_MAXPARTS) { bad = true; break; }     // one cluster larger than stage 2 can hold
+            cur = cum_incl((uint32_t)gr);
+            glo = (uint32_t)gr + 1u;
+            s_thr[++k] = glo << gshift;
         }
-        s_thr[tid] = thr;
+        s_thr[k + 1] = T;                               // the last part takes everything up to the cut
+        s_K = k + 1;
+        if (bad) s_flag = 1;
     }
     __syncthreads();
+    const uint32_t K = s_K;                             // <= LZ2_MAXPARTS
     // part sizes; refuse the block if any part exceeds the LDS capacity of stage 2
     if (tid < K) {
         const uint32_t a = s_thr[tid], b = s_thr[tid + 1];
@@ -171,6 +184,15 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
         if (fb) { const uint32_t k = atomicAdd(sc.fallback_count, 1u); sc.fallback_list[k] = lb; }
     }
     if (s_flag != 0 || (P.deflate && no_safe)) return;
+    // this block's parts join the batch's work list: stage 2 runs one workgroup per LISTED part.  (A grid of
+    // blocks x "most parts a block can have" interleaved a third of empty workgroups with the real ones; each still had to
+    // be given stage 2's 67 KiB of LDS before it could leave: 14.65 -> 11.4 GB/s.)
+    {
+        __shared__ uint32_t s_wbase;
+        if (tid == 0) s_wbase = atomicAdd(sc.work_count, K);
+        __syncthreads();
+        if (tid < (int)K) sc.work[s_wbase + tid] = lb | ((uint32_t)tid << 16);
+    }
 
     // ---- positions -> part lists, time order kept: ONE stable radix pass over the whole block by part number.  The part of
     //      every position is tabulated first (one hash per position), the pass then stores straight to the block's list in
