@@ -141,7 +141,7 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
         while (n - cur > LZ2_CAP) {
             const uint32_t limit = cur + LZ2_CAP;
             // (a part of a 2^20-bucket table is also kept below 2^16 homes: stage 2 then sorts 16-bit keys in two radix
-            //  passes instead of three; a 2^22-bucket table spreads 3584 entries over ~2^18 homes whatever the cut)
+            //  passes instead of three; a 2^22-bucket table spreads 4096 entries over ~2^18 homes whatever the cut)
             const uint32_t span = (gshift <= 6u) ? (65536u >> gshift) : LZ2_NG;
             uint32_t lo = glo, hi = (glo + span < LZ2_NG) ? glo + span : LZ2_NG - 1;   // first rotated group whose inclusive count exceeds the limit
             while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cum_incl(mid) > limit) hi = mid; else lo = mid + 1; }
