@@ -132,29 +132,50 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     // that fits.  A fixed target with a fixed margin (parts of TS + "how far back the cut had to move") fails as soon as
     // a block holds one cluster larger than the margin — measured: target 3072 gave +5 % on one corpus and a 6x collapse
     // (every block in the fallback) on another seed whose text has a 1000-entry cluster — while greedy parts only fail when
-    // a single cluster exceeds LZ2_CAP.  The cuts depend on each other, so one lane walks them (<= 32 binary searches).
+    // a single cluster exceeds LZ2_CAP.  The cuts depend on each other, so one wave walks them (<= 32 64-way searches).
     __shared__ uint32_t s_K;
-    if (tid == 0) {
+    if (tid < 64) {                                     // wave 0, every lane with the same cur / glo / k
+        const uint32_t lane = (uint32_t)tid;
         uint32_t k = 0, cur = 0, glo = 0;               // parts so far, entries before the current part, its first rotated group
         bool bad = false;
-        s_thr[0] = 0;
+        if (lane == 0) s_thr[0] = 0;
         while (n - cur > LZ2_CAP) {
             const uint32_t limit = cur + LZ2_CAP;
             // (a part of a 2^20-bucket table is also kept below 2^16 homes: stage 2 then sorts 16-bit keys in two radix
             //  passes instead of three; a 2^22-bucket table spreads 4096 entries over ~2^18 homes whatever the cut)
             const uint32_t span = (gshift <= 6u) ? (65536u >> gshift) : LZ2_NG;
-            uint32_t lo = glo, hi = (glo + span < LZ2_NG) ? glo + span : LZ2_NG - 1;   // first rotated group whose inclusive count exceeds the limit
-            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cum_incl(mid) > limit) hi = mid; else lo = mid + 1; }
-            int32_t gr = (int32_t)lo - 1;               // boundary after the last certified group before it, inside this part
-            while (gr >= (int32_t)glo && !is_safe((uint32_t)gr)) --gr;
+            // first rotated group in [glo, hi) whose inclusive count exceeds the limit, else hi: a 64-way search
+            uint32_t lo = glo, hi = (glo + span < LZ2_NG) ? glo + span : LZ2_NG - 1;
+            while (lo < hi) {
+                const uint32_t len = hi - lo, step = (len + 63u) / 64u;
+                const uint32_t pr = lo + lane * step;
+                const bool over = (pr < hi) && cum_incl(pr) > limit;
+                const uint64_t mk = __ballot(over);
+                if (mk == 0ull) lo = lo + ((len - 1u) / step) * step + 1u;         // every probe is below: continue behind the last one
+                else {
+                    const uint32_t j = (uint32_t)__builtin_ctzll(mk);
+                    hi = lo + j * step;
+                    if (j) lo = lo + (j - 1u) * step + 1u;
+                }
+            }
+            // boundary after the last certified group before it, inside this part: 64 groups per look
+            int32_t gr = -1;
+            for (int32_t g = (int32_t)lo - 1; g >= (int32_t)glo; g -= 64) {
+                const int32_t c = g - (int32_t)lane;
+                const uint64_t mk = __ballot(c >= (int32_t)glo && is_safe((uint32_t)c));
+                if (mk) { gr = g - (int32_t)__builtin_ctzll(mk); break; }
+            }
             if (gr < (int32_t)glo || k + 2 > LZ2_MAXPARTS) { bad = true; break; }     // one cluster larger than stage 2 can hold
             cur = cum_incl((uint32_t)gr);
             glo = (uint32_t)gr + 1u;
-            s_thr[++k] = glo << gshift;
+            ++k;
+            if (lane == 0) s_thr[k] = glo << gshift;
         }
-        s_thr[k + 1] = T;                               // the last part takes everything up to the cut
-        s_K = k + 1;
-        if (bad) s_flag = 1;
+        if (lane == 0) {
+            s_thr[k + 1] = T;                           // the last part takes everything up to the cut
+            s_K = k + 1;
+            if (bad) s_flag = 1;
+        }
     }
     __syncthreads();
     const uint32_t K = s_K;                             // <= LZ2_MAXPARTS
