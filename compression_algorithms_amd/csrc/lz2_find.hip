@@ -913,7 +913,7 @@ void k_lz2_scatter(Lz2Scratch sc, uint16_t *__restrict__ cand_by_pos /* [nb][655
 template __global__ void k_lz2_mid_direct<16, 64>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_mid_direct<32, 64>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_mid_direct<64, 64>(LzP, Lz2Scratch, int);
-template __global__ void k_lz2_mid_direct<128, 64>(LzP, Lz2Scratch, int);
+template __global__ void k_lz2_mid_direct<128, 48>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_big<LZ2_BIG_SMALL, 1>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_big<LZ2_CAP, 4>(LzP, Lz2Scratch, int);
 
@@ -1002,7 +1002,8 @@ mi_status lz2_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &
     { mi_prof_scope p(ctx, "k_lz2_mid<64>", s, (uint64_t)nb * P.block);
       hipLaunchKernelGGL((k_lz2_mid_direct<64, 64>), dim3(nb * lz2_class_cap(1) / 64 + 1), dim3(64), 0, s, P, sc, 1); }
     { mi_prof_scope p(ctx, "k_lz2_mid<128>", s, (uint64_t)nb * P.block);
-      hipLaunchKernelGGL((k_lz2_mid_direct<128, 64>), dim3(nb * lz2_class_cap(2) / 64 + 1), dim3(64), 0, s, P, sc, 2); }
+      // 48 clusters per wave: 31 KiB of LDS instead of 42, five waves per CU instead of three (240 replaying lanes, not 192)
+      hipLaunchKernelGGL((k_lz2_mid_direct<128, 48>), dim3(nb * lz2_class_cap(2) / 48 + 1), dim3(64), 0, s, P, sc, 2); }
     if (sc.row_mode) {
         mi_prof_scope p(ctx, "k_lz2_row", s, (uint64_t)nb * P.block);
         hipLaunchKernelGGL(k_lz2_row, dim3(nb * (lz2_class_cap(5) + lz2_class_cap(4) + lz2_class_cap(3)) / 4 + 3), dim3(64), 0, s, P, sc);
