@@ -38,7 +38,9 @@ mi_status mi_ctx_create(mi_ctx **out, int device)
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
     // The host-buffer stream is created on first use (mi_host_stream).  Measured on the deflate pipeline, same box: the
     // creation order of these streams does not matter (11.83 .. 11.93 GB/s for three orders); a HIGH-priority stream for
-    // the partition + find stage cost 5-7 % even while it sat idle, so there is none.
+    // the partition + find stage cost 5-7 % even while it sat idle, so there is none; a fifth normal-priority stream
+    // (the wave replay beside the lane replays) cost 4 % with the wave replay on it and 7 % idle: the process's streams
+    // share a handful of hardware queues, and one more stream re-deals them.
     {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // lo = least urgent
