@@ -607,11 +607,18 @@ __device__ __forceinline__ void big_replay(uint32_t *s_occ, uint16_t *s_slot, ui
                 if (bm.test(r)) {
                     if ((h & 0xFFFFu) == id) res = h >> 16;
                     else {
-                        for (uint32_t b = r + 1;; ++b) {            // rare: the home holds another word
-                            if (!PLAIN && b == d_limit && r < d_limit) break;
-                            if (!bm.test(b)) break;
-                            const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_occ[b]);
-                            if ((o & 0xFFFFu) == id) { res = o >> 16; break; }
+                        // The home holds another word: find() walks on to the first copy of this word or the first empty
+                        // bucket.  Inside a long single-byte run that walk is thousands of buckets for every foreign word whose
+                        // home lies in the run (the reference pays it too: up to 670 probes per call on indented source);
+                        // here the end of the walk is one bitmap query and 64 occupants are compared per step.
+                        uint32_t e = bm.first_zero_from(r + 1u, lane);
+                        if (e > (uint32_t)LDS_ENTRIES) e = (uint32_t)LDS_ENTRIES;
+                        if (!PLAIN && r < d_limit && d_limit < e) e = d_limit;          // deflate's find() does not wrap past bucket T
+                        for (uint32_t b0 = r + 1u; b0 < e; b0 += 64u) {
+                            const uint32_t b = b0 + lane;
+                            const uint32_t o = b < e ? s_occ[b] : 0u;
+                            const uint64_t hit = __ballot(b < e && (o & 0xFFFFu) == id);
+                            if (hit) { res = RLANE(o, (uint32_t)__builtin_ctzll(hit)) >> 16; break; }
                         }
                     }
                 }
@@ -1009,9 +1016,10 @@ mi_status lz2_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &
         hipLaunchKernelGGL(k_lz2_row, dim3(nb * (lz2_class_cap(5) + lz2_class_cap(4) + lz2_class_cap(3)) / 4 + 3), dim3(64), 0, s, P, sc);
         hipLaunchKernelGGL((k_lz2_big<LZ2_CAP, 4>), dim3(nb * lz2_class_cap(6) < 4096 ? nb * lz2_class_cap(6) : 4096), dim3(64), 0, s, P, sc, 1);
     } else {
-        mi_prof_scope p(ctx, "k_lz2_big", s, (uint64_t)nb * P.block);
-        hipLaunchKernelGGL((k_lz2_big<LZ2_BIG_SMALL, 1>), dim3(nb * (lz2_class_cap(4) + lz2_class_cap(5))), dim3(64), 0, s, P, sc, 0);
-        hipLaunchKernelGGL((k_lz2_big<LZ2_CAP, 4>), dim3(nb * lz2_class_cap(6) < 4096 ? nb * lz2_class_cap(6) : 4096), dim3(64), 0, s, P, sc, 1);
+        { mi_prof_scope p(ctx, "k_lz2_big", s, (uint64_t)nb * P.block);
+          hipLaunchKernelGGL((k_lz2_big<LZ2_BIG_SMALL, 1>), dim3(nb * (lz2_class_cap(4) + lz2_class_cap(5))), dim3(64), 0, s, P, sc, 0); }
+        { mi_prof_scope p(ctx, "k_lz2_big<4096>", s, (uint64_t)nb * P.block);
+          hipLaunchKernelGGL((k_lz2_big<LZ2_CAP, 4>), dim3(nb * lz2_class_cap(6) < 4096 ? nb * lz2_class_cap(6) : 4096), dim3(64), 0, s, P, sc, 1); }
     }
     MI_HIP(ctx, hipGetLastError());
     return MI_OK;
