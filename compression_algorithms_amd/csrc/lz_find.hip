@@ -15,6 +15,7 @@
 // Output: cand[p] = what find(word at p) returns in the table state after positions 0..p-1
 // were inserted (0xFFFF = none).  The parse consumes it in lz_emit.hip.
 #include "lz_common.h"
+#include "lz_replay.h"
 #include "lz2.h"
 #include <stdlib.h>
 
@@ -364,6 +365,11 @@ __device__ __forceinline__ void lz_emulate_tile(LzP P, LzScratch sc, uint32_t lb
         uint32_t e = s + 1;
         while (e < m && !(s_rs[e] & RS_HEAD)) ++e;
         if (e - s < 2) continue;                 // a lone entry finds nothing and blocks nobody
+        if (e - s >= LZ_WAVE_MIN) {              // a wave replays it (k_lz_emulate_giant): a lane would walk its probe chains bucket by bucket
+            const uint32_t k = atomicAdd(sc.giant_count, 1u);
+            sc.giant_list[2 * k] = lb; sc.giant_list[2 * k + 1] = a + s;
+            continue;
+        }
         const bool first = (a + s) == 0;
         replay_cluster(v, s, e, W, first ? mt.anom_idx : ~0u, first ? mt.limit_idx : ~0u, cand);
     }
@@ -379,12 +385,14 @@ void k_lz_emulate(LzP P, LzScratch sc, uint32_t nb, const uint32_t *__restrict__
     }
 }
 
-// one workgroup per giant cluster.  <= LZ_GIANT_CAP entries: same replay from LDS, lane 0.
-// Larger: slots/occupants live in global scratch (eB, free after the sort), bitmap in LDS.
+// one workgroup per giant cluster (and per cluster of >= LZ_WAVE_MIN entries the tile kernel hands over).
+// One word only: closed form.  <= LZ_GIANT_CAP entries: wave replay (lz_replay.h).  Larger: one lane, slots/occupants in
+// global scratch, bitmap in LDS.
 __global__ __launch_bounds__(256)
 void k_lz_emulate_giant(LzP P, LzScratch sc)
 {
-    __shared__ uint16_t s_pos[LZ_GIANT_CAP], s_rs[LZ_GIANT_CAP], s_pid[LZ_GIANT_CAP], s_occ[LZ_GIANT_CAP];
+    __shared__ uint32_t s_occ32[LZ_GIANT_CAP];          // wave replay (lz_replay.h): slot -> word id | position << 16
+    __shared__ uint16_t s_slot16[LZ_GIANT_CAP];         //                            entry -> slot
     __shared__ uint32_t s_bm[LZ_MAX_BLOCK / 32 + 2];
     __shared__ uint32_t s_bm1[LZ_MAX_BLOCK / 1024 + 2];
     __shared__ uint32_t s_end;
@@ -448,23 +456,35 @@ void k_lz_emulate_giant(LzP P, LzScratch sc)
         for (uint32_t i = tid; i < LZ_MAX_BLOCK / 32 + 2; i += 256) s_bm[i] = 0;
         if (tid < LZ_MAX_BLOCK / 1024 + 2) s_bm1[tid] = 0;
         if (m <= LZ_GIANT_CAP) {
+            // One WAVE replays the cluster (lz_replay.h: bitmap in registers, the probe walk 64 buckets per step) — a
+            // cluster this large is a long run of one word with foreign words inside its bucket range, and every find() of
+            // a foreign word walks the run: lane-serial, that was seconds per block.  The entries are first laid out as
+            // four u16 arrays in this block's eB (free after the sort; clusters use disjoint ranges [a, a + m)).
+            uint16_t *g16 = reinterpret_cast<uint16_t *>(sc.eB + (size_t)lb * LZ_MAX_BLOCK);
+            uint16_t *gp = g16 + a, *grs = g16 + LZ_MAX_BLOCK + a, *gid = g16 + 2 * LZ_MAX_BLOCK + a, *gc = g16 + 3 * LZ_MAX_BLOCK + a;
             for (uint32_t i = tid; i < m; i += 256) {
                 const uint64_t e = E[a + i];
-                s_pos[i] = (uint16_t)(e >> 16);
-                s_rs[i] = (uint16_t)((((uint32_t)(e >> 32) & 0xFFFFu) - a) | (i == 0 ? RS_HEAD : 0u));
-                s_pid[i] = (uint16_t)(e >> 48);
+                gp[i] = (uint16_t)(e >> 16);
+                grs[i] = (uint16_t)(((uint32_t)(e >> 32) & 0xFFFFu) - a);
+                gid[i] = (uint16_t)(e >> 48);
+            }
+            __threadfence();
+            __syncthreads();
+            if (tid < 64) {
+                if (anom == ~0u && limit == ~0u) big_replay<LZ_GIANT_CAP, (LZ_GIANT_CAP + 2047) / 2048, true>(s_occ32, s_slot16, (uint32_t)tid, W, m, anom, limit, gp, grs, gid, gc);
+                else big_replay<LZ_GIANT_CAP, (LZ_GIANT_CAP + 2047) / 2048, false>(s_occ32, s_slot16, (uint32_t)tid, W, m, anom, limit, gp, grs, gid, gc);
+                __threadfence();
             }
             __syncthreads();
-            if (tid == 0) {
-                TileView v{s_pos, s_rs, s_pid, s_occ, s_bm, s_bm1, m};
-                replay_cluster(v, 0, m, W, anom, limit, cand);
-            }
+            for (uint32_t i = tid; i < m; i += 256) { const uint32_t c = gc[i]; if (c != LZ_NONE16) cand[gp[i]] = (uint16_t)c; }
         } else {
             // global-memory replay: slot[] and occ[] (u16 each) carved from this block's eB
             __syncthreads();
             if (tid == 0) {
-                uint16_t *slot = reinterpret_cast<uint16_t *>(sc.eB + (size_t)lb * LZ_MAX_BLOCK);
-                uint16_t *occ = slot + LZ_MAX_BLOCK;
+                // (posA / posB are free after k_lz_sort_home; every cluster uses its own range [a, a + m): several giants of
+                //  one block are replayed at the same time by different workgroups, some of them through eB above)
+                uint16_t *slot = sc.posA + (size_t)lb * LZ_MAX_BLOCK + a;
+                uint16_t *occ = sc.posB + (size_t)lb * LZ_MAX_BLOCK + a;
                 uint32_t ev = 0;
                 bool anom_pending = anom != ~0u;
                 for (uint32_t i = 0; i < m; ++i) {

@@ -1,0 +1,131 @@
+// lz_replay.h — wave-per-cluster replay shared by k_lz2_big (lz2_find.hip) and the fallback's giant clusters
+// (lz_find.hip): occupancy bitmap in registers, first fit by ballot + v_readlane, slot -> occupant and entry -> slot in
+// LDS.  Reference functions replaced: insert_hash_table / find, algorithms/lz77/lz77.c:55-108 and
+// algorithms/deflate/lz77.c:77-174.
+#pragma once
+#include "lz_common.h"
+
+#define RLANE(v, l) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (int)(l)))
+
+// occupancy bitmap of one cluster held in registers: slot s = bit (s & 31) of word (s >> 5); word w lives in
+// lane (w & 63), register (w >> 6).  Every index into w[] is a compile-time constant (unrolled), so the
+// array stays in VGPRs; all cross-lane traffic is v_readlane / ballots on wave-uniform indices.
+template <int NW>
+struct WaveBitmap {
+    uint32_t w[NW];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int q = 0; q < NW; ++q) w[q] = 0;
+    }
+    __device__ __forceinline__ uint32_t word(uint32_t wi) const {
+        const uint32_t wq = wi >> 6, ln = wi & 63u;
+        uint32_t r = 0;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) { const uint32_t t = RLANE(w[q], ln); if (NW == 1 || (uint32_t)q == wq) r = t; }
+        return r;
+    }
+    __device__ __forceinline__ bool test(uint32_t slot) const { return (word(slot >> 5) >> (slot & 31u)) & 1u; }
+    __device__ __forceinline__ void clear_bit(uint32_t slot, uint32_t lane) {      // whoever sits there, or nobody
+        const uint32_t wi = slot >> 5, wq = wi >> 6;
+        const uint32_t keep = (lane == (wi & 63u)) ? ~(1u << (slot & 31u)) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) w[q] &= (NW == 1 || (uint32_t)q == wq) ? keep : 0xFFFFFFFFu;
+    }
+    __device__ __forceinline__ void flip(uint32_t slot, uint32_t lane) {
+        const uint32_t wi = slot >> 5, wq = wi >> 6;
+        const uint32_t bit = (lane == (wi & 63u)) ? (1u << (slot & 31u)) : 0u;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) w[q] ^= (NW == 1 || (uint32_t)q == wq) ? bit : 0u;
+    }
+    __device__ __forceinline__ uint32_t first_zero_from(uint32_t r, uint32_t lane) const {
+        const uint32_t rw = r >> 5, lowmask = (1u << (r & 31u)) - 1u;
+        uint32_t res = ~0u;
+        bool found = false;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            const uint32_t wi = (uint32_t)q * 64u + lane;
+            uint32_t v = w[q];
+            if (wi < rw) v = 0xFFFFFFFFu; else if (wi == rw) v |= lowmask;
+            const uint64_t nz = __ballot(v != 0xFFFFFFFFu);
+            if (!found && nz) {
+                const uint32_t ln = (uint32_t)__builtin_ctzll(nz);
+                const uint32_t mv = RLANE(v, ln);
+                res = (((uint32_t)q * 64u + ln) << 5) + (uint32_t)__builtin_ctz(~mv);
+                found = true;
+            }
+        }
+        return res;
+    }
+};
+
+// one cluster, one wave.  PLAIN: the cluster does not cover bucket 0 / T (all but one per block): the spurious clear and
+// the non-wrapping find() drop out of the loop, which is bound by the number of scalar instructions per step.
+template <int LDS_ENTRIES, int NW, bool PLAIN>
+__device__ __forceinline__ void big_replay(uint32_t *s_occ, uint16_t *s_slot, uint32_t lane, uint32_t W, uint32_t n,
+                                           uint32_t d_anom, uint32_t d_limit, const uint16_t *bp, const uint16_t *br,
+                                           const uint16_t *bi, uint16_t *bc)
+{
+    WaveBitmap<NW> bm;
+    bm.clear();
+    uint32_t ev = 0;
+    bool anom_pending = !PLAIN && d_anom != ~0u;
+    uint32_t c_pos = 0, c_rs = 0, c_pid = 0, out_acc = 0;
+    // position of the oldest entry still in the table, kept in a scalar: "nothing to retire" is one compare per step
+    uint32_t ev_pos = lane < n ? bp[lane] : 0u;
+    uint32_t pe = RLANE(ev_pos, 0);
+    uint32_t n_pos = ev_pos, n_rs = 0, n_pid = 0;                   // the next 64 entries are in flight while these are replayed
+    if (lane < n) { n_rs = br[lane]; n_pid = bi[lane]; }
+    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+        const uint32_t ii = i0 + lane;
+        c_pos = n_pos; c_rs = n_rs; c_pid = n_pid;
+        if (ii + 64 < n) { n_pos = bp[ii + 64]; n_rs = br[ii + 64]; n_pid = bi[ii + 64]; }
+        const uint32_t lim = (n - i0) < 64u ? (n - i0) : 64u;
+        for (uint32_t t = 0; t < lim; ++t) {
+            const uint32_t i = i0 + t;
+            const uint32_t p = RLANE(c_pos, t), r = RLANE(c_rs, t), id = RLANE(c_pid, t);
+            while (ev < i && pe + W < p) {                          // FIFO retirement (lz77.c:70-76)
+                const uint32_t sl = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_slot[ev]);
+                bm.clear_bit(sl, lane);                             // clears the bucket, whoever sits there
+                ++ev;
+                if ((ev & 63u) == 0) { const uint32_t q = ev + lane; ev_pos = q < n ? bp[q] : 0u; }
+                pe = RLANE(ev_pos, ev & 63u);
+            }
+            if (!PLAIN && anom_pending && p > W - 1u) { bm.clear_bit(d_anom, lane); anom_pending = false; }
+            uint32_t res = LZ_NONE16;
+            if (PLAIN && ev == 0) {
+                // nothing evicted yet: find() = the word's first occurrence = the word id (k_lz2_find, the sweep)
+                if (id != p) res = id;
+            } else {
+                const uint32_t h = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_occ[r]);
+                if (bm.test(r)) {
+                    if ((h & 0xFFFFu) == id) res = h >> 16;
+                    else {
+                        // The home holds another word: find() walks on to the first copy of this word or the first empty
+                        // bucket.  Inside a long single-byte run that walk is thousands of buckets for every foreign word whose
+                        // home lies in the run (the reference pays it too: up to 670 probes per call on indented source);
+                        // here the end of the walk is one bitmap query and 64 occupants are compared per step.
+                        uint32_t e = bm.first_zero_from(r + 1u, lane);
+                        if (e > (uint32_t)LDS_ENTRIES) e = (uint32_t)LDS_ENTRIES;
+                        if (!PLAIN && r < d_limit && d_limit < e) e = d_limit;          // deflate's find() does not wrap past bucket T
+                        for (uint32_t b0 = r + 1u; b0 < e; b0 += 64u) {
+                            const uint32_t b = b0 + lane;
+                            const uint32_t o = b < e ? s_occ[b] : 0u;
+                            const uint64_t hit = __ballot(b < e && (o & 0xFFFFu) == id);
+                            if (hit) { res = RLANE(o, (uint32_t)__builtin_ctzll(hit)) >> 16; break; }
+                        }
+                    }
+                }
+            }
+            const uint32_t b = bm.first_zero_from(r, lane);         // insert: first fit
+            bm.flip(b, lane);
+            // every lane stores the same value to the same address: no exec-mask juggling (scalar instructions) for a
+            // one-lane store, and identical-address stores of a wave do not conflict
+            s_occ[b] = id | (p << 16); s_slot[i] = (uint16_t)b;
+            if (lane == t) out_acc = res;
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (ii < n) bc[ii] = (uint16_t)out_acc;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
