@@ -391,10 +391,13 @@ void k_lz_emulate(LzP P, LzScratch sc, uint32_t nb, const uint32_t *__restrict__
 __global__ __launch_bounds__(256)
 void k_lz_emulate_giant(LzP P, LzScratch sc)
 {
-    __shared__ uint32_t s_occ32[LZ_GIANT_CAP];          // wave replay (lz_replay.h): slot -> word id | position << 16
-    __shared__ uint16_t s_slot16[LZ_GIANT_CAP];         //                            entry -> slot
-    __shared__ uint32_t s_bm[LZ_MAX_BLOCK / 32 + 2];
-    __shared__ uint32_t s_bm1[LZ_MAX_BLOCK / 1024 + 2];
+    // one LDS buffer, two uses: wave replay of <= LZ_GIANT_CAP entries (slot -> word id | position << 16, entry -> slot) or of
+    // up to 65 536 entries (slot -> word id only; lz_replay.h huge_replay)
+    __shared__ __attribute__((aligned(16))) uint8_t s_raw[2 * LZ_MAX_BLOCK];
+    uint32_t *s_occ32 = reinterpret_cast<uint32_t *>(s_raw);                              // [LZ_GIANT_CAP]
+    uint16_t *s_slot16 = reinterpret_cast<uint16_t *>(s_raw + 4 * LZ_GIANT_CAP);          // [LZ_GIANT_CAP]
+    uint16_t *s_oid16 = reinterpret_cast<uint16_t *>(s_raw);                              // [65536]
+    static_assert(6 * LZ_GIANT_CAP <= 2 * LZ_MAX_BLOCK, "wave-replay tables must fit the buffer");
     __shared__ uint32_t s_end;
     const int tid = threadIdx.x;
     const uint32_t count = *sc.giant_count;
@@ -453,9 +456,7 @@ void k_lz_emulate_giant(LzP P, LzScratch sc)
             __syncthreads();
             continue;
         }
-        for (uint32_t i = tid; i < LZ_MAX_BLOCK / 32 + 2; i += 256) s_bm[i] = 0;
-        if (tid < LZ_MAX_BLOCK / 1024 + 2) s_bm1[tid] = 0;
-        if (m <= LZ_GIANT_CAP) {
+        {
             // One WAVE replays the cluster (lz_replay.h: bitmap in registers, the probe walk 64 buckets per step) — a
             // cluster this large is a long run of one word with foreign words inside its bucket range, and every find() of
             // a foreign word walks the run: lane-serial, that was seconds per block.  The entries are first laid out as
@@ -471,52 +472,20 @@ void k_lz_emulate_giant(LzP P, LzScratch sc)
             __threadfence();
             __syncthreads();
             if (tid < 64) {
-                if (anom == ~0u && limit == ~0u) big_replay<LZ_GIANT_CAP, (LZ_GIANT_CAP + 2047) / 2048, true>(s_occ32, s_slot16, (uint32_t)tid, W, m, anom, limit, gp, grs, gid, gc);
-                else big_replay<LZ_GIANT_CAP, (LZ_GIANT_CAP + 2047) / 2048, false>(s_occ32, s_slot16, (uint32_t)tid, W, m, anom, limit, gp, grs, gid, gc);
+                const bool plain = anom == ~0u && limit == ~0u;
+                if (m <= LZ_GIANT_CAP) {
+                    if (plain) big_replay<LZ_GIANT_CAP, (LZ_GIANT_CAP + 2047) / 2048, true>(s_occ32, s_slot16, (uint32_t)tid, W, m, anom, limit, gp, grs, gid, gc);
+                    else big_replay<LZ_GIANT_CAP, (LZ_GIANT_CAP + 2047) / 2048, false>(s_occ32, s_slot16, (uint32_t)tid, W, m, anom, limit, gp, grs, gid, gc);
+                } else {
+                    // posA / posB are free after k_lz_sort_home; every cluster uses its own range [a, a + m)
+                    uint16_t *gslot = sc.posA + (size_t)lb * LZ_MAX_BLOCK + a, *gopos = sc.posB + (size_t)lb * LZ_MAX_BLOCK + a;
+                    if (plain) huge_replay<true>(s_oid16, (uint32_t)tid, W, m, anom, limit, gp, grs, gid, gc, gslot, gopos);
+                    else huge_replay<false>(s_oid16, (uint32_t)tid, W, m, anom, limit, gp, grs, gid, gc, gslot, gopos);
+                }
                 __threadfence();
             }
             __syncthreads();
             for (uint32_t i = tid; i < m; i += 256) { const uint32_t c = gc[i]; if (c != LZ_NONE16) cand[gp[i]] = (uint16_t)c; }
-        } else {
-            // global-memory replay: slot[] and occ[] (u16 each) carved from this block's eB
-            __syncthreads();
-            if (tid == 0) {
-                // (posA / posB are free after k_lz_sort_home; every cluster uses its own range [a, a + m): several giants of
-                //  one block are replayed at the same time by different workgroups, some of them through eB above)
-                uint16_t *slot = sc.posA + (size_t)lb * LZ_MAX_BLOCK + a;
-                uint16_t *occ = sc.posB + (size_t)lb * LZ_MAX_BLOCK + a;
-                uint32_t ev = 0;
-                bool anom_pending = anom != ~0u;
-                for (uint32_t i = 0; i < m; ++i) {
-                    const uint64_t e = E[a + i];
-                    const uint32_t p = (uint32_t)(e >> 16) & 0xFFFFu, r = ((uint32_t)(e >> 32) & 0xFFFFu) - a;
-                    const uint32_t pid = (uint32_t)(e >> 48);
-                    while (ev < i && (((uint32_t)(E[a + ev] >> 16)) & 0xFFFFu) + W < p) {
-                        const uint32_t bb = slot[ev];
-                        s_bm[bb >> 5] &= ~(1u << (bb & 31u));
-                        s_bm1[bb >> 10] &= ~(1u << ((bb >> 5) & 31u));
-                        ++ev;
-                    }
-                    if (anom_pending && p > W - 1u) {
-                        s_bm[anom >> 5] &= ~(1u << (anom & 31u));
-                        s_bm1[anom >> 10] &= ~(1u << ((anom >> 5) & 31u));
-                        anom_pending = false;
-                    }
-                    uint32_t res = LZ_NONE16;
-                    for (uint32_t bb = r;; ++bb) {
-                        if (bb == limit && r < limit) break;
-                        if (!bm_test(s_bm, bb)) break;
-                        const uint64_t oe = E[a + occ[bb]];
-                        if ((uint32_t)(oe >> 48) == pid) { res = (uint32_t)(oe >> 16) & 0xFFFFu; break; }
-                    }
-                    if (res != LZ_NONE16) cand[p] = (uint16_t)res;
-                    const uint32_t bb = bm_next_zero(s_bm, s_bm1, r);
-                    s_bm[bb >> 5] |= 1u << (bb & 31u);
-                    if (s_bm[bb >> 5] == 0xFFFFFFFFu) s_bm1[bb >> 10] |= 1u << ((bb >> 5) & 31u);
-                    occ[bb] = (uint16_t)i;
-                    slot[i] = (uint16_t)bb;
-                }
-            }
         }
         __syncthreads();
     }

@@ -129,3 +129,89 @@ __device__ __forceinline__ void big_replay(uint32_t *s_occ, uint16_t *s_slot, ui
     __builtin_amdgcn_wave_barrier();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same replay for a cluster of up to 65 536 entries (a block that is mostly one byte value, with other data mixed in):
+// LDS only holds the word id of every slot's occupant (2 B x 65 536); the occupants' positions and the entries' slots
+// live in HBM (read past the L1: this wave wrote them), the bitmap in 32 registers per lane.  A find() that hits reads one
+// position from HBM — except on the slot that was last taken as its entry's own home slot (the dominant word's anchor),
+// which is kept in a register pair.
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool PLAIN>
+__device__ __forceinline__ void huge_replay(uint16_t *s_oid, uint32_t lane, uint32_t W, uint32_t n, uint32_t d_anom, uint32_t d_limit,
+                                            const uint16_t *bp, const uint16_t *br, const uint16_t *bi, uint16_t *bc,
+                                            uint16_t *gslot, uint16_t *gopos)
+{
+    constexpr uint32_t CAPS = 65536u;
+    WaveBitmap<32> bm;
+    bm.clear();
+    uint32_t ev = 0;
+    bool anom_pending = !PLAIN && d_anom != ~0u;
+    uint32_t c_pos = 0, c_rs = 0, c_pid = 0, out_acc = 0;
+    uint32_t ev_pos = lane < n ? bp[lane] : 0u;
+    uint32_t pe = RLANE(ev_pos, 0);
+    uint32_t ev_slot = 0, ev_slot_base = ~0u, ev_slot_upto = 0;      // slots of entries [base, base + 64), valid for entries < upto
+    uint32_t an_slot = ~0u, an_pos = 0;                               // cached (slot, position of its occupant)
+    uint32_t n_pos = ev_pos, n_rs = 0, n_pid = 0;
+    if (lane < n) { n_rs = br[lane]; n_pid = bi[lane]; }
+    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+        const uint32_t ii = i0 + lane;
+        c_pos = n_pos; c_rs = n_rs; c_pid = n_pid;
+        if (ii + 64 < n) { n_pos = bp[ii + 64]; n_rs = br[ii + 64]; n_pid = bi[ii + 64]; }
+        const uint32_t lim = (n - i0) < 64u ? (n - i0) : 64u;
+        for (uint32_t t = 0; t < lim; ++t) {
+            const uint32_t i = i0 + t;
+            const uint32_t p = RLANE(c_pos, t), r = RLANE(c_rs, t), id = RLANE(c_pid, t);
+            while (ev < i && pe + W < p) {                          // FIFO retirement (lz77.c:70-76)
+                if ((ev & ~63u) != ev_slot_base || ev >= ev_slot_upto) {
+                    __threadfence();                                // every entry < i has stored its slot
+                    ev_slot_base = ev & ~63u;
+                    const uint32_t q = ev_slot_base + lane;
+                    ev_slot = q < i ? (uint32_t)__builtin_nontemporal_load(gslot + q) : 0u;
+                    ev_slot_upto = i;
+                }
+                const uint32_t sl = RLANE(ev_slot, ev & 63u);
+                bm.clear_bit(sl, lane);                             // clears the bucket, whoever sits there
+                ++ev;
+                if ((ev & 63u) == 0) { const uint32_t q = ev + lane; ev_pos = q < n ? bp[q] : 0u; }
+                pe = RLANE(ev_pos, ev & 63u);
+            }
+            if (!PLAIN && anom_pending && p > W - 1u) { bm.clear_bit(d_anom, lane); anom_pending = false; }
+            uint32_t res = LZ_NONE16;
+            if (PLAIN && ev == 0) {
+                if (id != p) res = id;                              // nothing evicted yet: the first occurrence
+            } else {
+                const uint32_t h = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_oid[r]);
+                if (bm.test(r)) {
+                    uint32_t hit = ~0u;
+                    if (h == id) hit = r;
+                    else {
+                        uint32_t e = bm.first_zero_from(r + 1u, lane);
+                        if (e > CAPS) e = CAPS;
+                        if (!PLAIN && r < d_limit && d_limit < e) e = d_limit;
+                        for (uint32_t b0 = r + 1u; b0 < e; b0 += 64u) {
+                            const uint32_t b = b0 + lane;
+                            const uint64_t mk = __ballot(b < e && (uint32_t)s_oid[b < e ? b : r] == id);
+                            if (mk) { hit = b0 + (uint32_t)__builtin_ctzll(mk); break; }
+                        }
+                    }
+                    if (hit != ~0u) {
+                        if (hit == an_slot) res = an_pos;
+                        else { __threadfence(); res = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)__builtin_nontemporal_load(gopos + hit)); }
+                    }
+                }
+            }
+            const uint32_t b = bm.first_zero_from(r, lane);         // insert: first fit
+            bm.flip(b, lane);
+            if (b < CAPS) {
+                s_oid[b] = (uint16_t)id;
+                if (lane == 0) { __builtin_nontemporal_store((uint16_t)p, gopos + b); __builtin_nontemporal_store((uint16_t)b, gslot + i); }
+            }
+            if (b == r) { an_slot = b; an_pos = p; } else if (b == an_slot) an_slot = ~0u;
+            if (lane == t) out_acc = res;
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (ii < n) bc[ii] = (uint16_t)out_acc;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
