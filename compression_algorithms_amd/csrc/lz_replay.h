@@ -10,36 +10,92 @@
 // occupancy bitmap of one cluster held in registers: slot s = bit (s & 31) of word (s >> 5); word w lives in
 // lane (w & 63), register (w >> 6).  Every index into w[] is a compile-time constant (unrolled), so the
 // array stays in VGPRs; all cross-lane traffic is v_readlane / ballots on wave-uniform indices.
+// a dense switch over a wave-uniform register index: every case names its register by a compile-time constant, so the
+// array stays in VGPRs and only one register is touched (large bitmaps: a select over all 32 registers per operation
+// made every step of huge_replay ~500 instructions)
+#define WB_SWITCH(q, OP) switch (q) { case 0: OP(0); break; case 1: OP(1); break; case 2: OP(2); break; case 3: OP(3); break; case 4: OP(4); break; case 5: OP(5); break; case 6: OP(6); break; case 7: OP(7); break; case 8: OP(8); break; case 9: OP(9); break; case 10: OP(10); break; case 11: OP(11); break; case 12: OP(12); break; case 13: OP(13); break; case 14: OP(14); break; case 15: OP(15); break; case 16: OP(16); break; case 17: OP(17); break; case 18: OP(18); break; case 19: OP(19); break; case 20: OP(20); break; case 21: OP(21); break; case 22: OP(22); break; case 23: OP(23); break; case 24: OP(24); break; case 25: OP(25); break; case 26: OP(26); break; case 27: OP(27); break; case 28: OP(28); break; case 29: OP(29); break; case 30: OP(30); break; case 31: OP(31); break; default: break; }
+
 template <int NW>
 struct WaveBitmap {
     uint32_t w[NW];
+    uint32_t full;                // NW > 4 only: bit q = register q has no zero bit in any lane (wave-uniform)
     __device__ __forceinline__ void clear() {
 #pragma unroll
         for (int q = 0; q < NW; ++q) w[q] = 0;
+        full = 0;
+    }
+    template <int K> __device__ __forceinline__ uint32_t reg_lane(uint32_t ln) const { if constexpr (K < NW) return RLANE(w[K], ln); else return 0u; }
+    template <int K> __device__ __forceinline__ void reg_and(uint32_t keep) { if constexpr (K < NW) w[K] &= keep; }
+    template <int K> __device__ __forceinline__ void reg_set(uint32_t bit) {
+        if constexpr (K < NW) { w[K] |= bit; if (__ballot(w[K] != 0xFFFFFFFFu) == 0ull) full |= 1u << K; }
+    }
+    template <int K> __device__ __forceinline__ uint32_t reg_first_zero(uint32_t rw, uint32_t lowmask, uint32_t lane) const {
+        if constexpr (K < NW) {
+            const uint32_t wi = (uint32_t)K * 64u + lane;
+            uint32_t v = w[K];
+            if (wi < rw) v = 0xFFFFFFFFu; else if (wi == rw) v |= lowmask;
+            const uint64_t nz = __ballot(v != 0xFFFFFFFFu);
+            if (!nz) return ~0u;
+            const uint32_t ln = (uint32_t)__builtin_ctzll(nz);
+            const uint32_t mv = RLANE(v, ln);
+            return (((uint32_t)K * 64u + ln) << 5) + (uint32_t)__builtin_ctz(~mv);
+        } else return ~0u;
     }
     __device__ __forceinline__ uint32_t word(uint32_t wi) const {
         const uint32_t wq = wi >> 6, ln = wi & 63u;
         uint32_t r = 0;
+        if constexpr (NW > 4) {
+#define OP(K) r = reg_lane<K>(ln)
+            WB_SWITCH(wq, OP)
+#undef OP
+        } else {
 #pragma unroll
-        for (int q = 0; q < NW; ++q) { const uint32_t t = RLANE(w[q], ln); if (NW == 1 || (uint32_t)q == wq) r = t; }
+            for (int q = 0; q < NW; ++q) { const uint32_t t = RLANE(w[q], ln); if (NW == 1 || (uint32_t)q == wq) r = t; }
+        }
         return r;
     }
     __device__ __forceinline__ bool test(uint32_t slot) const { return (word(slot >> 5) >> (slot & 31u)) & 1u; }
     __device__ __forceinline__ void clear_bit(uint32_t slot, uint32_t lane) {      // whoever sits there, or nobody
         const uint32_t wi = slot >> 5, wq = wi >> 6;
         const uint32_t keep = (lane == (wi & 63u)) ? ~(1u << (slot & 31u)) : 0xFFFFFFFFu;
+        if constexpr (NW > 4) {
+#define OP(K) reg_and<K>(keep)
+            WB_SWITCH(wq, OP)
+#undef OP
+            full &= ~(1u << wq);
+        } else {
 #pragma unroll
-        for (int q = 0; q < NW; ++q) w[q] &= (NW == 1 || (uint32_t)q == wq) ? keep : 0xFFFFFFFFu;
+            for (int q = 0; q < NW; ++q) w[q] &= (NW == 1 || (uint32_t)q == wq) ? keep : 0xFFFFFFFFu;
+        }
     }
-    __device__ __forceinline__ void flip(uint32_t slot, uint32_t lane) {
+    __device__ __forceinline__ void flip(uint32_t slot, uint32_t lane) {           // SETS the bit of a free slot
         const uint32_t wi = slot >> 5, wq = wi >> 6;
         const uint32_t bit = (lane == (wi & 63u)) ? (1u << (slot & 31u)) : 0u;
+        if constexpr (NW > 4) {
+#define OP(K) reg_set<K>(bit)
+            WB_SWITCH(wq, OP)
+#undef OP
+        } else {
 #pragma unroll
-        for (int q = 0; q < NW; ++q) w[q] ^= (NW == 1 || (uint32_t)q == wq) ? bit : 0u;
+            for (int q = 0; q < NW; ++q) w[q] ^= (NW == 1 || (uint32_t)q == wq) ? bit : 0u;
+        }
     }
     __device__ __forceinline__ uint32_t first_zero_from(uint32_t r, uint32_t lane) const {
         const uint32_t rw = r >> 5, lowmask = (1u << (r & 31u)) - 1u;
         uint32_t res = ~0u;
+        if constexpr (NW > 4) {
+            uint32_t q = rw >> 6;
+            while (q < (uint32_t)NW) {
+#define OP(K) res = reg_first_zero<K>(rw, lowmask, lane)
+                WB_SWITCH(q, OP)
+#undef OP
+                if (res != ~0u) break;
+                const uint32_t rest = (q + 1u < 32u) ? (~full >> (q + 1u)) : 0u;       // next register that is not full
+                if (!rest) break;
+                q = q + 1u + (uint32_t)__builtin_ctz(rest);
+            }
+            return res;
+        }
         bool found = false;
 #pragma unroll
         for (int q = 0; q < NW; ++q) {
@@ -57,6 +113,7 @@ struct WaveBitmap {
         return res;
     }
 };
+
 
 // one cluster, one wave.  PLAIN: the cluster does not cover bucket 0 / T (all but one per block): the spurious clear and
 // the non-wrapping find() drop out of the loop, which is bound by the number of scalar instructions per step.
