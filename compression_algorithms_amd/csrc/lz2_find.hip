@@ -101,7 +101,7 @@ __device__ __forceinline__ void replay_small_reg(const uint16_t *pos, const uint
         uint32_t res = LZ_NONE16;
         if (ev == 0) {                                                  // nothing evicted yet: the first occurrence (see the sweep)
             if (id != p) res = id;
-        } else {
+        } else if (id != p) {                                           // (a word's first occurrence in the block finds nothing, ever)
             for (uint32_t b = rr; (mask >> b) & 1u; ++b) {              // bits >= n are never set: the probe ends inside the cluster
                 const uint32_t o = s + ((ent >> (4u * b)) & 15u);
                 if (pid[o] == id) { res = pos[o]; break; }
@@ -755,7 +755,7 @@ void k_lz2_mid_direct(LzP P, Lz2Scratch sc, int cls)
                 uint32_t res = LZ_NONE16;
                 if (plain && ev == 0) {                    // nothing evicted yet: find() = the word's first occurrence,
                     if (id != p) res = id;                 // which is what the word id is (k_lz2_find, the sweep)
-                } else if ((w0 >> (r & 31u)) & 1u) {
+                } else if (id != p && ((w0 >> (r & 31u)) & 1u)) {       // (a word's first occurrence in the block finds nothing, ever)
                     for (uint32_t b = r;; ++b) {
                         if (b != r) {
                             if (b == d.limit && r < d.limit) break;

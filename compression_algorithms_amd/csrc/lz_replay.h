@@ -152,7 +152,7 @@ __device__ __forceinline__ void big_replay(uint32_t *s_occ, uint16_t *s_slot, ui
             if (PLAIN && ev == 0) {
                 // nothing evicted yet: find() = the word's first occurrence = the word id (k_lz2_find, the sweep)
                 if (id != p) res = id;
-            } else {
+            } else if (id != p) {                                       // (the first occurrence of a word in the block finds nothing, ever)
                 const uint32_t h = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_occ[r]);
                 if (bm.test(r)) {
                     if ((h & 0xFFFFu) == id) res = h >> 16;
@@ -237,7 +237,7 @@ __device__ __forceinline__ void huge_replay(uint16_t *s_oid, uint32_t lane, uint
             uint32_t res = LZ_NONE16;
             if (PLAIN && ev == 0) {
                 if (id != p) res = id;                              // nothing evicted yet: the first occurrence
-            } else {
+            } else if (id != p) {                                       // (the first occurrence of a word in the block finds nothing, ever)
                 const uint32_t h = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_oid[r]);
                 if (bm.test(r)) {
                     uint32_t hit = ~0u;
