@@ -208,7 +208,9 @@ __device__ __forceinline__ void huge_replay(uint16_t *s_oid, uint32_t lane, uint
     uint32_t ev_pos = lane < n ? bp[lane] : 0u;
     uint32_t pe = RLANE(ev_pos, 0);
     uint32_t ev_slot = 0, ev_slot_base = ~0u, ev_slot_upto = 0;      // slots of entries [base, base + 64), valid for entries < upto
-    uint32_t an_slot = ~0u, an_pos = 0;                               // cached (slot, position of its occupant)
+    // two cached (slot, position of its occupant) pairs: the slot last taken as its entry's own home slot, and the slot
+    // last read from HBM — the dominant word's anchor must survive the foreign words' inserts and hits between its uses
+    uint32_t an_slot = ~0u, an_pos = 0, cb_slot = ~0u, cb_pos = 0;
     uint32_t n_pos = ev_pos, n_rs = 0, n_pid = 0;
     if (lane < n) { n_rs = br[lane]; n_pid = bi[lane]; }
     for (uint32_t i0 = 0; i0 < n; i0 += 64) {
@@ -254,7 +256,12 @@ __device__ __forceinline__ void huge_replay(uint16_t *s_oid, uint32_t lane, uint
                     }
                     if (hit != ~0u) {
                         if (hit == an_slot) res = an_pos;
-                        else { __threadfence(); res = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)__builtin_nontemporal_load(gopos + hit)); }
+                        else if (hit == cb_slot) res = cb_pos;
+                        else {
+                            __threadfence();
+                            res = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)__builtin_nontemporal_load(gopos + hit));
+                            cb_slot = hit; cb_pos = res;
+                        }
                     }
                 }
             }
@@ -264,7 +271,9 @@ __device__ __forceinline__ void huge_replay(uint16_t *s_oid, uint32_t lane, uint
                 s_oid[b] = (uint16_t)id;
                 if (lane == 0) { __builtin_nontemporal_store((uint16_t)p, gopos + b); __builtin_nontemporal_store((uint16_t)b, gslot + i); }
             }
-            if (b == r) { an_slot = b; an_pos = p; } else if (b == an_slot) an_slot = ~0u;
+            if (b == cb_slot) cb_pos = p;                           // the cached slots follow their new occupants
+            if (b == r) { if (an_slot != ~0u && an_slot != b && cb_slot == ~0u) { cb_slot = an_slot; cb_pos = an_pos; } an_slot = b; an_pos = p; }
+            else if (b == an_slot) an_pos = p;
             if (lane == t) out_acc = res;
             __builtin_amdgcn_wave_barrier();
         }
