@@ -1,19 +1,31 @@
 #!/usr/bin/env python3
 """bench.py — encode throughput of the MI355X-native block-parallel compressor.
 
-    python bench.py --gpus N --steps K --warmup W [--workload deflate|deflate-h|lz77w16|lz77w14|huffman|fse]
+    python bench.py --gpus N --steps K --warmup W
+                    [--workload deflate-h|deflate|lz77w16|lz77w14|huffman|fse] [--scaling weak|strong] [--bytes B]
 
 N > 1 is launched by the driver as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 one rank per GPU (RCCL).  A "step" is one pass of the hot path over one batch of synthetic
 enwik-shaped input that is already resident in HBM.  Rank 0 prints ONE JSON line.
 
-Workload at N=1 (BASELINE.json metric "encode GB/s on enwik9", config "deflate (LZ77 ...) on
-enwik9, 32 KiB window, 1 MI355X"): 10^9 enwik-shaped bytes cut into 15 259 independent 64 KiB
-blocks, reference tokeniser algorithms/deflate/lz77.c:199-280 per block (fresh table per block),
-byte-exact token stream.  N > 1: every rank encodes its own 10^9-byte shard of independent
-blocks (weak scaling); --gather adds the north star's RCCL gather of the compressed streams
-to rank 0 inside the timed region.
+Default workload = BASELINE.json config 4 as it is worded, "deflate (LZ77 + dynamic Huffman) on enwik9, 32 KiB
+window, 1 MI355X": 10^9 enwik-shaped bytes cut into 15 259 independent 64 KiB blocks; per block the reference
+tokeniser (algorithms/deflate/lz77.c:199-280, fresh table per block, token sequence byte-exact) followed by the
+per-block dynamic Huffman stage the reference leaves as a TODO (lz77.c:279; "mode H", include/mi_codec.h).  The same
+line also carries
+    mode_T        the token-only mode (the reference's own byte-token stream) timed the same way,
+    shard_125MB   config 5's per-GPU shape (1/8 of enwik9 = 1 908 blocks) on this one GPU,
+    ratio_vs_ref  own output size against the reference's shipped compress() output (persistent table,
+                  deflate/deflate.c:47-63) on a sample,
+    roundtrip     decode(encode(x)) == x, checked once outside the timed region,
+    end_to_end    the same step with a pinned-host input and the stream copied back (PCIe inclusive).
+
+N > 1, --scaling weak (default): every rank encodes its own --bytes shard of independent blocks.
+N > 1, --scaling strong: ONE --bytes buffer (enwik9's size by default); rank r encodes the contiguous block range
+sharded.shard_bytes gives it (config 5: 1 908 blocks / 125 MB per GPU at N = 8).
+For N > 1 the north star's RCCL gather of the compressed streams to rank 0 is inside the timed region
+(--no-gather leaves it out).
 """
 import argparse
 import json
@@ -27,77 +39,108 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+BLOCK = 65536
+WORKLOADS = ["deflate-h", "deflate", "lz77w16", "lz77w14", "huffman", "fse"]
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="deflate", choices=["deflate", "deflate-h", "lz77w16", "lz77w14", "huffman", "fse"])
-    ap.add_argument("--bytes", type=int, default=1_000_000_000, help="input bytes per GPU")
-    ap.add_argument("--gather", action="store_true", help="N>1: gather the compressed streams to rank 0 (timed)")
+    ap.add_argument("--workload", default="deflate-h", choices=WORKLOADS)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--bytes", type=int, default=1_000_000_000,
+                    help="input bytes per GPU (weak) or of the whole job (strong)")
+    ap.add_argument("--gather", dest="gather", action="store_true", default=None,
+                    help="N>1: gather the compressed streams to rank 0 inside the timed region (default for N>1)")
+    ap.add_argument("--no-gather", dest="gather", action="store_false")
     ap.add_argument("--cpu-sample-mb", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip mode_T / shard_125MB / end_to_end (A/B runs)")
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 path on a box with fewer GPUs than ranks (ranks share devices)")
     return ap.parse_args()
 
 
-def make_step(workload, x, ctx):
-    """returns (callable doing one encode pass, callable -> compressed bytes of the last pass, dtype, description)"""
-    from compression_algorithms_amd import lz, huffman
-    if workload in ("deflate", "lz77w16", "lz77w14"):
-        p = {"deflate": lz.params("deflate"), "lz77w16": lz.params("lz77", 16), "lz77w14": lz.params("lz77", 14)}[workload]
-        holder = {}
+DESC = {
+    "deflate-h": "deflate (LZ77 W=32 KiB len<=31 + per-block dynamic Huffman over the 286-symbol alphabet, mode H), independent 64 KiB blocks",
+    "deflate": "deflate tokeniser alone (LZ77, W=32 KiB, len<=31, the reference's byte tokens, mode T), independent 64 KiB blocks",
+    "lz77w16": "lz77 (W=64 KiB, len<=15, bit-packed), independent 64 KiB blocks",
+    "lz77w14": "lz77 (W=16 KiB, len<=15, bit-packed), independent 64 KiB blocks",
+    "huffman": "whole-buffer Huffman, one tree",
+    "fse": "FSE/tANS table_log 8, independent 64 KiB blocks x 64 sub-streams",
+}
 
-        def step():
-            holder["st"] = None          # release the previous output first: the caching allocator then reuses its block
-            holder["st"] = lz.compress(x, p, ctx)      # (otherwise the first timed step pays a 2 GB hipMalloc)
 
-        desc = {"deflate": "deflate tokeniser (LZ77, W=32 KiB, len<=31, byte tokens), independent 64 KiB blocks",
-                "lz77w16": "lz77 (W=64 KiB, len<=15, bit-packed), independent 64 KiB blocks",
-                "lz77w14": "lz77 (W=16 KiB, len<=15, bit-packed), independent 64 KiB blocks"}[workload]
-        return step, (lambda: holder["st"].nbytes), (lambda: holder["st"]), "u8", desc
-    if workload == "deflate-h":
-        holder = {}
-        p = lz.params("deflate")
+class Codec:
+    """one workload over the C ABI: encode(x) -> handle, nbytes(handle), decode(handle) -> tensor"""
 
-        def step():
-            holder["st"] = None
-            holder["st"] = lz.compress_h(x, p, ctx)
+    def __init__(self, workload, ctx):
+        from compression_algorithms_amd import fse, huffman, lz
+        self.w, self.ctx = workload, ctx
+        self.lz, self.huffman, self.fse = lz, huffman, fse
+        self.p = {"deflate": lz.params("deflate"), "deflate-h": lz.params("deflate"), "lz77w16": lz.params("lz77", 16),
+                  "lz77w14": lz.params("lz77", 14), "fse": fse.params(), "huffman": None}[workload]
 
-        return step, (lambda: holder["st"].nbytes), (lambda: holder["st"]), "u8", \
-            "deflate tokeniser + per-block dynamic Huffman over the 286-symbol alphabet (mode H), independent 64 KiB blocks"
-    if workload == "huffman":
-        holder = {}
+    def encode(self, x):
+        if self.w == "deflate-h":
+            return self.lz.compress_h(x, self.p, self.ctx)
+        if self.w in ("deflate", "lz77w16", "lz77w14"):
+            return self.lz.compress(x, self.p, self.ctx)
+        if self.w == "huffman":
+            return self.huffman.huffman_compress(x, self.ctx)
+        return self.fse.compress(x, self.p, self.ctx)
 
-        def step():
-            holder["r"] = None
-            holder["r"] = huffman.huffman_compress(x, ctx)
+    def nbytes(self, h):
+        return (h.total_bits + 7) // 8 if self.w == "huffman" else h.nbytes
 
-        return step, (lambda: (holder["r"].total_bits + 7) // 8), (lambda: holder["r"]), "u8", "whole-buffer Huffman, one tree"
-    if workload == "fse":
-        from compression_algorithms_amd import fse
-        holder = {}
-        p = fse.params()
+    def decode(self, h):
+        if self.w == "deflate-h":
+            return self.lz.decompress_h(h, self.ctx)
+        if self.w in ("deflate", "lz77w16", "lz77w14"):
+            return self.lz.decompress(h, self.ctx)
+        if self.w == "huffman":
+            return self.huffman.huffman_decompress(h, ctx=self.ctx)
+        return self.fse.decompress(h, self.ctx)
 
-        def step():
-            holder["r"] = None
-            holder["r"] = fse.compress(x, p, ctx)
+    def stream_and_table(self, h):
+        """(uint8 stream tensor, int64 block table in bits) for the gather; None for the whole-buffer Huffman"""
+        if self.w == "huffman":
+            return None
+        return h.data, (h.block_bits if hasattr(h, "block_bits") else h.offsets)
 
-        return step, (lambda: holder["r"].nbytes), (lambda: holder["r"]), "u8", "FSE/tANS table_log 8, independent 64 KiB blocks x 64 sub-streams"
-    raise ValueError(workload)
+
+def timed_steps(codec, x, steps, warmup, sync, after_step=None):
+    """W untimed + K timed encode passes; the previous output is released first so that the caching allocator reuses
+    its block (otherwise the first timed step pays a multi-GB hipMalloc).  Returns (seconds, last handle)."""
+    holder = {"h": None}
+
+    def step():
+        holder["h"] = None
+        holder["h"] = codec.encode(x)
+        if after_step is not None:
+            after_step(holder["h"])
+
+    for _ in range(warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    return time.perf_counter() - t0, holder["h"]
 
 
 def cpu_baseline(workload, sample, sample_desc):
-    """the reference (oracle/_ref, compiled from /root/reference in the build container) or, where
-    that is absent, the oracle's CPU restatement, timed single-threaded on the host."""
+    """the reference (oracle/_ref, compiled from /root/reference in the build container) or, where the reference has
+    no such code, the oracle's CPU restatement — timed single-threaded on the host.  Checker code, never the product."""
     import numpy as np
     from oracle import orc, ref
     n = len(sample)
     kind = "port"
+    extra = {}
     t0 = time.perf_counter()
     if workload == "deflate":
         if ref.available():
@@ -107,19 +150,33 @@ def cpu_baseline(workload, sample, sample_desc):
             rd.stream(sample, independent=True)
         else:
             t0 = time.perf_counter()
-            orc.deflate_stream(sample, 65536, True)
+            orc.deflate_stream(sample, BLOCK, True)
     elif workload == "deflate-h":
-        # the reference has no entropy stage for this path: the oracle's tokeniser + its mode-H coder
-        d = orc.Deflate(65536)
+        # the reference stops at a TODO where the entropy stage would be (deflate/lz77.c:279): its tokeniser (the real
+        # reference when oracle/_ref is there) + the oracle's restatement of the mode-H coder
+        rd = ref.RefDeflate() if ref.available() else None
+        d = None if rd else orc.Deflate(BLOCK)
+        kind = "reference" if rd else "port"
+        t_tok = 0.0
         t0 = time.perf_counter()
-        for at in range(0, n, 65536):
-            d.fresh()
-            orc.defh_encode_block(d.block_encode(sample[at:at + 65536]))
+        for at in range(0, n, BLOCK):
+            ta = time.perf_counter()
+            if rd:
+                rd.fresh()
+                tok = rd.block(sample[at:at + BLOCK])
+            else:
+                d.fresh()
+                tok = d.block_encode(sample[at:at + BLOCK])
+            t_tok += time.perf_counter() - ta
+            orc.defh_encode_block(tok)
+        extra = {"tokeniser_only_gbs": round(n / t_tok / 1e9, 5),
+                 "note": "tokeniser = " + ("the compiled reference" if rd else "oracle port") +
+                         "; entropy stage = oracle port (the reference has none)"}
     elif workload in ("lz77w16", "lz77w14"):
         wb = 16 if workload == "lz77w16" else 14
         t0 = time.perf_counter()
-        for at in range(0, n, 65536):
-            orc.lz77_encode(sample[at:at + 65536].tobytes(), wb, 4)
+        for at in range(0, n, BLOCK):
+            orc.lz77_encode(sample[at:at + BLOCK].tobytes(), wb, 4)
     elif workload == "huffman":
         if ref.available():
             kind = "reference"
@@ -134,11 +191,35 @@ def cpu_baseline(workload, sample, sample_desc):
             orc.huff_encode(sample)
     elif workload == "fse":
         t0 = time.perf_counter()
-        for at in range(0, n, 65536):
-            orc.fse_encode_block(sample[at:at + 65536], 8, 64, 1)
+        for at in range(0, n, BLOCK):
+            orc.fse_encode_block(sample[at:at + BLOCK], 8, 64, 1)
     dt = time.perf_counter() - t0
-    return {"value": round(n / dt / 1e9, 5), "unit": "GB/s", "cores": 1, "kind": kind,
-            "sample": f"{sample_desc}; {n} bytes in {dt:.2f} s on 1 of {os.cpu_count()} host cores"}
+    out = {"value": round(n / dt / 1e9, 5), "unit": "GB/s", "cores": 1, "kind": kind,
+           "sample": f"{sample_desc}; {n} bytes in {dt:.2f} s on 1 of {os.cpu_count()} host cores"}
+    out.update(extra)
+    return out
+
+
+def reference_output_bytes(workload, sample):
+    """size of what the REFERENCE writes for `sample` (the denominator of ratio_vs_ref), and what it is"""
+    from oracle import orc, ref
+    if workload in ("deflate", "deflate-h"):
+        # the shipped compress(): 64 KiB chunks, ONE table kept across them (deflate/deflate.c:13-14,47-63), raw byte tokens
+        if ref.available():
+            s, _ = ref.RefDeflate().stream(sample, independent=False)
+            return len(s), "reference compress(): persistent-table byte-token stream (deflate/deflate.c:47-63), compiled reference"
+        s, _ = orc.deflate_stream(sample, BLOCK, False)
+        return len(s), "reference compress(): persistent-table byte-token stream (deflate/deflate.c:47-63), oracle port"
+    if workload in ("lz77w16", "lz77w14"):
+        wb = 16 if workload == "lz77w16" else 14
+        if ref.available():
+            s, nb = ref.lz77_compress(sample, wb)
+        else:
+            s, nb = orc.lz77_encode(sample.tobytes(), wb, 4)
+        return (nb + 7) // 8, f"reference lz77_compress over the whole sample as ONE stream, W=2^{wb} (lz77/lz77.c:264-345)"
+    if workload == "huffman":
+        return (orc.huff_encode(sample)["bits"] + 7) // 8, "reference huffman_compress, one tree (identical stream by construction)"
+    return None, "the reference's FSE does not compile: no reference output exists"
 
 
 def main():
@@ -159,15 +240,26 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    from compression_algorithms_amd import synth
+    from compression_algorithms_amd import sharded, synth
     from compression_algorithms_amd.context import Context
     ctx = Context(local)
+    codec = Codec(args.workload, ctx)
+    gather = (world > 1 and args.workload != "huffman") if args.gather is None else (args.gather and world > 1)
 
-    n = args.bytes
-    # every rank owns a different shard of the same enwik-shaped corpus (independent blocks)
-    x = synth.enwik_like(n, seed=args.seed + 1000 * rank, device=dev)
+    if args.scaling == "strong":
+        # ONE corpus of --bytes; rank r owns the contiguous block range of sharded.shard_bytes (config 5's shape)
+        n_job = args.bytes
+        lo, hi = sharded.shard_bytes(n_job, BLOCK, rank, world)
+        whole = synth.enwik_like(n_job, seed=args.seed, device=dev)
+        x = whole[lo:hi].clone()
+        del whole
+        torch.cuda.empty_cache()
+    else:
+        # every rank owns a different shard of the same kind of corpus (independent blocks)
+        n_job = args.bytes * world
+        x = synth.enwik_like(args.bytes, seed=args.seed + 1000 * rank, device=dev)
+    n = x.numel()
     torch.cuda.synchronize()
-    step, out_bytes, last, dtype, desc = make_step(args.workload, x, ctx)
 
     def barrier():
         torch.cuda.synchronize()
@@ -175,41 +267,49 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def gather_streams():
-        """north star: RCCL gather of the per-block compressed streams to rank 0 (sizes and block
-        tables first, then the variable-length streams point to point: sharded.gather_streams)"""
-        from compression_algorithms_amd import sharded
-        st = last()
-        table = st.block_bits if hasattr(st, "block_bits") else st.offsets
-        sharded.gather_streams(st.data, table, dst=0)
+    def gather_streams(h):
+        """north star: RCCL gather of the per-block compressed streams to rank 0 (sizes and block tables first, then the
+        variable-length streams point to point in one group: sharded.gather_streams)"""
+        st = codec.stream_and_table(h)
+        if st is None:
+            return
+        sharded.gather_streams(st[0], st[1], dst=0)
 
+    after = gather_streams if gather else None
     for _ in range(args.warmup):
-        step()
-        if dist is not None and args.gather:
-            gather_streams()
+        h = codec.encode(x)
+        if after:
+            after(h)
+        h = None
     barrier()
     ctx.set_profiling(True)
     ctx.kernel_times()              # reset
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        if dist is not None and args.gather:
-            gather_streams()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt, last = timed_steps(codec, x, args.steps, 0, barrier, after)
     ctx.set_profiling(False)
     ktimes = ctx.kernel_times()
-    c = out_bytes()
+    c = codec.nbytes(last)
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
+    # ---- outside the timed region: round trip of the last output on every rank
+    back = codec.decode(last)
+    rt_ok = bool(torch.equal(back, x))
+    del back
+    if dist is not None:
+        f = torch.tensor([1 if rt_ok else 0], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        rt_ok = bool(int(f.item()))
+    csum = torch.tensor([c], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+    if dist is not None:
+        dist.all_reduce(csum, op=dist.ReduceOp.SUM)
+    c_job = int(csum.item())
+
     if rank == 0:
-        total_bytes = n * world * args.steps
-        value = total_bytes / dt / 1e9
-        # dominant kernel: largest share of the timed region
+        value = n_job * args.steps / dt / 1e9
+        # ---- roofline of the dominant kernel (largest share of the timed region), HIP events on its launch stream
         roof = None
         if ktimes:
             dom = max(ktimes, key=lambda k: k["ms"] * k["launches"])
@@ -224,36 +324,104 @@ def main():
                     traffic = json.load(open(tj)).get(dom["name"])
                 except Exception:
                     traffic = None
-            # the dominant kernel's OWN share of the algorithmic bytes, for orientation (Huffman: the histogram reads n,
-            # the encoder reads n and writes c; the LZ kernels each see the block once)
             own = {"k_huff_hist": n, "k_huff_encode": n + c}.get(dom["name"], (passes * n + c)) / launches_per_step
             roof = {"bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "achieved_own_bytes": round(own / (dom["ms"] * 1e-3) / 1e9, 2),
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "whole_step_frac": round((passes * n + c) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
                     "avg_launch_ms": round(dom["ms"], 4), "launches_per_step": launches_per_step,
                     "kernel_share": round(dom["ms"] * dom["launches"] / (dt * 1e3), 3),
                     "all_kernels_ms_per_step": {k["name"]: round(k["ms"] * k["launches"] / args.steps, 3) for k in ktimes}}
+
+        extras = {}
+        single = world == 1 and not args.no_extras
+        if single and args.workload == "deflate-h":
+            # the token-only mode, timed the same way (what BENCH_r01 carried as its headline)
+            ct = Codec("deflate", ctx)
+            dtt, ht = timed_steps(ct, x, args.steps, 1, torch.cuda.synchronize)
+            extras["mode_T"] = {"value": round(n * args.steps / dtt / 1e9, 3), "unit": "GB/s", "ms_per_step": round(dtt / args.steps * 1e3, 3),
+                                "ratio": round(n / max(ct.nbytes(ht), 1), 4), "what": DESC["deflate"]}
+            del ht
+        if single and args.workload in ("deflate-h", "deflate") and n >= 125_000_000 + BLOCK:
+            # config 5's per-GPU shape on this one GPU: 1/8 of enwik9 = 125 MB = 1 908 blocks
+            xs = x[:125_000_000]
+            k = max(args.steps, 10)
+            dts, hs = timed_steps(codec, xs, k, 2, torch.cuda.synchronize)
+            extras["shard_125MB"] = {"value": round(xs.numel() * k / dts / 1e9, 3), "unit": "GB/s", "ms_per_step": round(dts / k * 1e3, 3),
+                                     "blocks": (xs.numel() + BLOCK - 1) // BLOCK, "steps": k,
+                                     "what": "one GPU's share of config 5 (enwik9 / 8), same workload, single-GPU proxy"}
+            del hs
+        if single:
+            # PCIe-inclusive: pinned host buffer in, stream + block table back to the host (never `value`)
+            try:
+                ne = min(n, 256_000_000)
+                xh = x[:ne].cpu().pin_memory()
+                xd = torch.empty(ne, dtype=torch.uint8, device=dev)
+                outh = None
+                t_e2e = []
+                for it in range(3):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    xd.copy_(xh, non_blocking=True)
+                    he = codec.encode(xd)
+                    nb = codec.nbytes(he)
+                    st = codec.stream_and_table(he)
+                    if st is not None:
+                        if outh is None or outh.numel() < nb:
+                            outh = torch.empty(int(nb * 1.1) + 64, dtype=torch.uint8).pin_memory()
+                        outh[:nb].copy_(st[0][:nb], non_blocking=True)
+                        st[1].cpu()
+                    else:
+                        he.words.cpu()
+                    torch.cuda.synchronize()
+                    t_e2e.append(time.perf_counter() - t0)
+                    he = None
+                extras["end_to_end"] = {"value": round(ne / min(t_e2e[1:]) / 1e9, 3), "unit": "GB/s", "bytes": ne,
+                                        "what": "pinned host input -> H2D -> encode -> D2H of the stream and block table; best of 2 after 1 warm-up"}
+            except Exception as e:       # pinned allocation refused etc.: the column is optional
+                extras["end_to_end"] = {"value": None, "error": repr(e)[:200]}
+
         cpu = None
+        ratio_vs_ref = None
         if not args.no_cpu_baseline:
-            rate = {"deflate": 0.016, "deflate-h": 0.012, "lz77w16": 0.012, "lz77w14": 0.014, "huffman": 0.23, "fse": 0.15}[args.workload]
-            mb = args.cpu_sample_mb if args.cpu_sample_mb else min(n / 1e6, max(4.0, 15.0 * rate * 1e3))
-            nsamp = int(mb * 1e6) // 65536 * 65536 or min(n, 65536)
+            rate = {"deflate": 0.045, "deflate-h": 0.029, "lz77w16": 0.012, "lz77w14": 0.014, "huffman": 0.23, "fse": 0.15}[args.workload]
+            mb = args.cpu_sample_mb if args.cpu_sample_mb else min(n / 1e6, max(4.0, 5.0 * rate * 1e3))
+            nsamp = int(mb * 1e6) // BLOCK * BLOCK or min(n, BLOCK)
             sample = x[:nsamp].cpu().numpy()
             cpu = cpu_baseline(args.workload, sample, f"first {nsamp} bytes of the rank-0 buffer")
+            # ratio vs the reference's own output on (a prefix of) the same sample
+            nr = min(nsamp, 64 * 1024 * 1024)
+            try:
+                ref_bytes, ref_what = reference_output_bytes(args.workload, sample[:nr])
+                own = codec.nbytes(codec.encode(x[:nr]))
+                if ref_bytes:
+                    ratio_vs_ref = {"value": round(ref_bytes / max(own, 1), 4), "own_bytes": int(own), "ref_bytes": int(ref_bytes),
+                                    "sample_bytes": int(nr), "ref": ref_what,
+                                    "meaning": "(input/own) / (input/ref) = ref_bytes / own_bytes; > 1: smaller than the reference's output"}
+                else:
+                    ratio_vs_ref = {"value": None, "ref": ref_what}
+            except Exception as e:
+                ratio_vs_ref = {"value": None, "error": repr(e)[:200]}
         line = {
             "metric": "encode GB/s on enwik9 at 1/2/4/8 MI355X; ratio vs ref; round-trip bit-exact",
             "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": f"{desc}; {n} enwik-shaped bytes per GPU",
-                       "input_bytes_per_gpu": n, "compressed_bytes_rank0": int(c), "ratio": round(n / max(c, 1), 4),
-                       "gather_to_rank0": bool(args.gather and world > 1), "parallelism": f"blocks sharded over {world} GPU(s)"},
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{DESC[args.workload]}; {n_job} enwik-shaped bytes in the job, {n} on rank 0",
+                       "mode": {"deflate-h": "H", "deflate": "T"}.get(args.workload),
+                       "input_bytes_job": n_job, "input_bytes_rank0": n, "compressed_bytes_job": c_job, "compressed_bytes_rank0": int(c),
+                       "ratio": round(n_job / max(c_job, 1), 4), "gather_to_rank0": bool(gather),
+                       "parallelism": f"blocks sharded over {world} GPU(s), {args.scaling} scaling"},
+            "ratio": round(n_job / max(c_job, 1), 4), "ratio_vs_ref": ratio_vs_ref, "roundtrip": rt_ok,
             "roofline": roof, "cpu_baseline": cpu,
         }
+        line.update(extras)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if not rt_ok:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

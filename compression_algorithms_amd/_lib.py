@@ -50,7 +50,7 @@ class KernelTime(C.Structure):
 
 # every symbol include/mi_codec.h declares; tests check that the library exports them all
 EXPORTS = [
-    "mi_ctx_create", "mi_ctx_destroy", "mi_status_str", "mi_last_hip_error", "mi_version", "mi_sync",
+    "mi_ctx_create", "mi_ctx_destroy", "mi_status_str", "mi_last_hip_error", "mi_version", "mi_sync", "mi_validate_block_table",
     "mi_huffman_encode_dev", "mi_huffman_encode", "mi_huffman_encode2", "mi_huffman_decode_dev", "mi_huffman_decode",
     "mi_lz_encode_dev", "mi_lz_encode", "mi_lz_decode_dev", "mi_lz_decode", "mi_lz_find_all_dev",
     "mi_deflate_h_bound_bytes", "mi_deflate_h_encode_dev", "mi_deflate_h_decode_dev", "mi_deflate_h_encode", "mi_deflate_h_decode",
@@ -85,6 +85,7 @@ def lib():
         L.mi_version.restype = C.c_char_p
         L.mi_last_hip_error.argtypes = [vp]
         L.mi_sync.argtypes = [vp, vp]
+        L.mi_validate_block_table.argtypes = [vp, u64, u64, C.c_uint32]
         L.mi_set_profiling.argtypes = [vp, C.c_int]
         L.mi_get_kernel_times.argtypes = [vp, C.POINTER(KernelTime), C.c_int]
         if hasattr(L, "mi_huffman_encode_dev"):
@@ -95,20 +96,22 @@ def lib():
         if hasattr(L, "mi_lz_encode_dev"):
             L.mi_lz_encode_dev.argtypes = [vp, C.POINTER(LzParams), vp, u64, vp, u64, vp, vp]
             L.mi_lz_encode.argtypes = [vp, C.POINTER(LzParams), vp, u64, vp, u64, vp]
-            L.mi_lz_decode_dev.argtypes = [vp, C.POINTER(LzParams), vp, vp, vp, u64, vp]
+            L.mi_lz_decode_dev.argtypes = [vp, C.POINTER(LzParams), vp, u64, vp, vp, u64, vp]
+            L.mi_lz_decode.argtypes = [vp, C.POINTER(LzParams), vp, u64, vp, vp, u64]
             L.mi_lz_find_all_dev.argtypes = [vp, C.POINTER(LzParams), vp, u64, vp, vp]
         if hasattr(L, "mi_deflate_h_encode_dev"):
             L.mi_deflate_h_bound_bytes.restype = u64
-            L.mi_deflate_h_bound_bytes.argtypes = [u64]
+            L.mi_deflate_h_bound_bytes.argtypes = [u64, C.POINTER(LzParams)]
             L.mi_deflate_h_encode_dev.argtypes = [vp, C.POINTER(LzParams), vp, u64, vp, u64, vp, vp]
-            L.mi_deflate_h_decode_dev.argtypes = [vp, C.POINTER(LzParams), vp, vp, vp, u64, vp]
+            L.mi_deflate_h_decode_dev.argtypes = [vp, C.POINTER(LzParams), vp, u64, vp, vp, u64, vp]
             L.mi_deflate_h_encode.argtypes = [vp, C.POINTER(LzParams), vp, u64, vp, u64, vp]
             L.mi_deflate_h_decode.argtypes = [vp, C.POINTER(LzParams), vp, u64, vp, vp, u64]
         if hasattr(L, "mi_fse_encode_dev"):
             L.mi_fse_block_bound.restype = u64
             L.mi_fse_block_bound.argtypes = [C.POINTER(FseParams)]
             L.mi_fse_encode_dev.argtypes = [vp, C.POINTER(FseParams), vp, u64, vp, u64, vp, vp]
-            L.mi_fse_decode_dev.argtypes = [vp, C.POINTER(FseParams), vp, vp, vp, u64, vp]
+            L.mi_fse_decode_dev.argtypes = [vp, C.POINTER(FseParams), vp, u64, vp, vp, u64, vp]
+            L.mi_fse_decode.argtypes = [vp, C.POINTER(FseParams), vp, u64, vp, vp, u64]
             L.mi_fse_normalise_dev.argtypes = [vp, vp, C.c_uint32, vp, vp]
         _lib = L
     return _lib

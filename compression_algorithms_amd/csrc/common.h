@@ -40,6 +40,11 @@ struct mi_ctx {
     // small pinned host staging area for info structs
     void       *h_pinned = nullptr;
     size_t      h_pinned_bytes = 0;
+    // decoder status words: every decode call takes its own (round robin), so calls on different streams of one context
+    // never share one (they used to share ws[0])
+    uint32_t   *d_err = nullptr;
+    uint32_t    err_next = 0;
+#define MI_ERR_SLOTS 256
     std::vector<mi_prof_entry> prof;
     std::vector<hipEvent_t>    event_pool;
 };
@@ -55,6 +60,10 @@ struct mi_ctx {
 
 // grow the context workspace to at least `bytes` (256-byte aligned carve-outs are the caller's job)
 mi_status mi_ws_reserve(mi_ctx *ctx, size_t bytes);
+// a zeroed-on-stream status word for one decode call (never the workspace: two streams may decode at once)
+uint32_t *mi_err_slot(mi_ctx *ctx, hipStream_t s);
+// host check of a block table (exclusive prefix in bits): monotonic, aligned, inside the stream
+extern "C" mi_status mi_validate_block_table(const uint64_t *h_block_bits, uint64_t nblocks, uint64_t stream_bytes, uint32_t align_bits);
 // the context's own stream for the host-buffer entry points, created on first use
 hipStream_t mi_host_stream(mi_ctx *ctx);
 

@@ -61,6 +61,7 @@ mi_status mi_ctx_create(mi_ctx **out, int device)
     if (hipHostMalloc(&c->h_pinned, c->h_pinned_bytes, hipHostMallocDefault) != hipSuccess) {
         mi_ctx_destroy(c); return MI_ERR_NOMEM;
     }
+    if (hipMalloc((void **)&c->d_err, MI_ERR_SLOTS * sizeof(uint32_t)) != hipSuccess) { mi_ctx_destroy(c); return MI_ERR_NOMEM; }
     *out = c;
     return MI_OK;
 }
@@ -74,6 +75,7 @@ void mi_ctx_destroy(mi_ctx *c)
         for (auto &ev : p.pending) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     for (auto e : c->event_pool) hipEventDestroy(e);
     if (c->ws) hipFree(c->ws);
+    if (c->d_err) hipFree(c->d_err);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->side) hipStreamDestroy(c->side);
@@ -135,6 +137,32 @@ int mi_get_kernel_times(mi_ctx *c, mi_kernel_time *out, int cap)
 }
 
 }  // extern "C"
+
+uint32_t *mi_err_slot(mi_ctx *c, hipStream_t s)
+{
+    uint32_t *e = c->d_err + (c->err_next++ % MI_ERR_SLOTS);
+    if (hipMemsetAsync(e, 0, 4, s) != hipSuccess) return nullptr;
+    return e;
+}
+
+// A block table is an exclusive prefix sum of per-block stream lengths in bits.  Decoders index the stream with it, so a
+// table taken from a file or a peer is checked before any kernel sees it: non-decreasing, every entry a multiple of
+// `align_bits` (1 for the bit-packed lz77 flavour, 8 for deflate tokens, 32 for mode-H / FSE records), the last one inside
+// the stream.
+extern "C" mi_status mi_validate_block_table(const uint64_t *t, uint64_t nblocks, uint64_t stream_bytes, uint32_t align_bits)
+{
+    if (!t || !align_bits) return MI_ERR_ARG;
+    if (stream_bytes > (UINT64_MAX >> 3)) return MI_ERR_ARG;
+    const uint64_t limit = stream_bytes * 8;
+    uint64_t prev = t[0];
+    if (prev % align_bits) return MI_ERR_CORRUPT;
+    for (uint64_t i = 1; i <= nblocks; ++i) {
+        const uint64_t v = t[i];
+        if (v < prev || (v % align_bits)) return MI_ERR_CORRUPT;
+        prev = v;
+    }
+    return prev <= limit ? MI_OK : MI_ERR_CORRUPT;
+}
 
 hipStream_t mi_host_stream(mi_ctx *c)
 {

@@ -211,7 +211,7 @@ void defh_launch_encode(const uint32_t *trec, uint32_t *slots, uint64_t *block_b
 // match is spread over the lanes, the output block is staged in LDS like k_lz_decode.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64)
-void k_defh_decode(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ block_bits, LzP P,
+void k_defh_decode(const uint8_t *__restrict__ stream, uint64_t stream_bytes, const uint64_t *__restrict__ block_bits, LzP P,
                    uint8_t *__restrict__ out, uint64_t n_total, uint32_t *__restrict__ err)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_out[LZ_MAX_BLOCK + 256];
@@ -225,7 +225,8 @@ void k_defh_decode(const uint8_t *__restrict__ stream, const uint64_t *__restric
     const uint64_t off = b * (uint64_t)P.block;
     const uint32_t n = (uint32_t)((n_total - off) < P.block ? (n_total - off) : P.block);
     const uint64_t rb = block_bits[b], re = block_bits[b + 1];
-    bool bad = (rb & 31u) || re < rb + DEFH_HDR * 8ull;
+    // the record must lie inside the stream: every later read is bounded by [rb, re)
+    bool bad = (rb & 31u) || (re & 31u) || re < rb + DEFH_HDR * 8ull || re > stream_bytes * 8ull;
     if (bad) { if (lane == 0) atomicOr(err, 1u); return; }
     const uint32_t *rec = reinterpret_cast<const uint32_t *>(stream + (rb >> 3));
     const uint32_t ntok = rec[0];
@@ -297,20 +298,25 @@ void k_defh_decode(const uint8_t *__restrict__ stream, const uint64_t *__restric
     if (o != n) bad = true;
     if (bad && lane == 0) atomicOr(err, 1u);
     __syncthreads();
-    for (uint32_t i = lane; i < n; i += 64) out[off + i] = s_out[i];
+    if (!bad) for (uint32_t i = lane; i < n; i += 64) out[off + i] = s_out[i];
 }
 
 mi_status lz_check_params(const mi_lz_params *p);
 
-extern "C" uint64_t mi_deflate_h_bound_bytes(uint64_t n)
+extern "C" uint64_t mi_deflate_h_bound_bytes(uint64_t n, const mi_lz_params *p)
 {
-    // a block's Huffman code cannot be longer than a fixed 9-bit code over 286 symbols; tokens <= 65536 - 3 * matches,
-    // a match adds <= 19 extra bits: 9 * tokens + 19 * matches <= 9 * 65536 bits.  Plus header and the last partial word.
-    const uint64_t nblocks = (n + LZ_MAX_BLOCK - 1) / LZ_MAX_BLOCK;
-    return nblocks * (DEFH_HDR + (uint64_t)LZ_MAX_BLOCK * 9 / 8 + 8) + 64;
+    // Per block of b bytes: a Huffman code cannot be longer than a fixed 9-bit code over 286 symbols, and a match
+    // (code + <= 15 offset bits + 5 length bits <= 29 bits) replaces >= 4 literals (36 bits) — except the block's last
+    // token, which may be a match that covers ONE real byte and runs into the zero tail: 9 b + 20 bits at most.
+    // Plus the 292-byte header; records are whole words.  Every block pays the header, so the bound depends on p->block.
+    const uint64_t block = (p && p->block) ? p->block : LZ_MAX_BLOCK;
+    const uint64_t nblocks = (n + block - 1) / block;
+    const uint64_t last = n - (nblocks ? (nblocks - 1) * block : 0);
+    auto rec = [](uint64_t b) -> uint64_t { return DEFH_HDR + 4 * ((9 * b + 20 + 31) / 32); };
+    return (nblocks ? (nblocks - 1) * rec(block) + rec(last) : 0) + 64;
 }
 
-extern "C" mi_status mi_deflate_h_decode_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_stream,
+extern "C" mi_status mi_deflate_h_decode_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_stream, uint64_t stream_bytes,
                                              const uint64_t *d_block_bits, uint8_t *d_out, uint64_t n, void *stream)
 {
     if (!ctx || !d_stream || !d_block_bits || (n && !d_out)) return MI_ERR_ARG;
@@ -321,13 +327,11 @@ extern "C" mi_status mi_deflate_h_decode_dev(mi_ctx *ctx, const mi_lz_params *p,
     hipStream_t s = (hipStream_t)stream;
     const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block};
     const uint64_t nblocks = (n + P.block - 1) / P.block;
-    st = mi_ws_reserve(ctx, 4096);
-    if (st) return st;
-    uint32_t *err = reinterpret_cast<uint32_t *>(ctx->ws);
-    MI_HIP(ctx, hipMemsetAsync(err, 0, 4, s));
+    uint32_t *err = mi_err_slot(ctx, s);
+    if (!err) return MI_ERR_HIP;
     {
         mi_prof_scope pr(ctx, "k_defh_decode", s, n);
-        hipLaunchKernelGGL(k_defh_decode, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, d_block_bits, P, d_out, n, err);
+        hipLaunchKernelGGL(k_defh_decode, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, stream_bytes, d_block_bits, P, d_out, n, err);
     }
     uint32_t h_err = 0;
     MI_HIP(ctx, hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, s));

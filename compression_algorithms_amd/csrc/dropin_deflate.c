@@ -31,7 +31,7 @@ StateData compress(const char *input_filename)
     const char *mode = getenv("MI_DEFLATE_MODE");
     const int mode_h = mode && (mode[0] == 'H' || mode[0] == 'h');
     const uint64_t nblocks = mi_lz_num_blocks(n, &p);
-    const uint64_t cap = (mode_h ? mi_deflate_h_bound_bytes(n) : mi_lz_bound_bytes(n, &p)) + 64;
+    const uint64_t cap = (mode_h ? mi_deflate_h_bound_bytes(n, &p) : mi_lz_bound_bytes(n, &p)) + 64;
     uint8_t *out = (uint8_t *)malloc(cap); uint64_t *bits = (uint64_t *)malloc(8 * (nblocks + 1));
     struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
     mi_status st = mode_h ? mi_deflate_h_encode(ctx, &p, (const uint8_t *)in, n, out, cap, bits)
@@ -57,11 +57,21 @@ void decompress(StateData *sd, const char *input_filename)
     const char *name = (sd && sd->compressed_filename) ? sd->compressed_filename : input_filename;
     char *idx = (char *)malloc(strlen(name) + 5); strcpy(idx, name); strcat(idx, ".idx");
     uint64_t isz; char *ib = slurp(idx, &isz);
+    /* the side-car is a file: nothing in it is trusted before it is checked against its own size and the stream's */
+    if (isz < 24) { fprintf(stderr, "decompress: %s is truncated\n", idx); exit(1); }
     const uint64_t *h = (const uint64_t *)ib;
     const uint64_t n = h[0], nblocks = h[2];
-    uint64_t csz; char *cb = slurp(name, &csz);
-    mi_lz_params p = mi_lz_params_deflate(); p.block = (uint32_t)h[1];
+    const uint32_t block = (uint32_t)h[1];
     const int mode_h = (int)((h[1] >> 32) & 1u);
+    if (block < 1 || block > BUFFER_SIZE || (h[1] >> 33) || nblocks != (n + block - 1) / block ||
+        nblocks > (isz - 24) / 8 || isz < 24 + 8 * (nblocks + 1)) {
+        fprintf(stderr, "decompress: %s is corrupt or truncated\n", idx); exit(1);
+    }
+    uint64_t csz; char *cb = slurp(name, &csz);
+    mi_lz_params p = mi_lz_params_deflate(); p.block = block;
+    if (mi_validate_block_table(h + 3, nblocks, csz, mode_h ? 32u : 8u) != MI_OK) {
+        fprintf(stderr, "decompress: the block table of %s does not fit %s\n", idx, name); exit(1);
+    }
     uint8_t *out = (uint8_t *)malloc(n ? n : 1);
     mi_status st = mode_h ? mi_deflate_h_decode(dropin_ctx(), &p, (const uint8_t *)cb, csz, h + 3, out, n)
                           : mi_lz_decode(dropin_ctx(), &p, (const uint8_t *)cb, csz, h + 3, out, n);

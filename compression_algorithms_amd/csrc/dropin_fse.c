@@ -29,9 +29,10 @@ size_t fse_decompress(const uint8_t *input, size_t len, uint8_t *output, size_t 
     if (len < 16) return 0;
     const uint64_t *h = (const uint64_t *)input;
     const uint64_t n = h[0], nb = h[1];
-    if (n > capacity || len < 16 + 8 * (nb + 1)) return 0;
+    if (n > capacity || nb > (len - 16) / 8 || len < 16 + 8 * (nb + 1)) return 0;
     mi_fse_params p = fse_p();
-    mi_status st = mi_fse_decode(dropin_ctx(), &p, input + 16 + 8 * (nb + 1), h + 2, output, n);
+    if (nb != (n + p.block - 1) / p.block) return 0;
+    mi_status st = mi_fse_decode(dropin_ctx(), &p, input + 16 + 8 * (nb + 1), len - (16 + 8 * (nb + 1)), h + 2, output, n);
     if (st != MI_OK) { fprintf(stderr, "fse_decompress: %s\n", mi_status_str(st)); return 0; }
     return n;
 }

@@ -3,8 +3,6 @@
 #include "../../include/mi_huffman.h"
 #include "dropin_common.h"
 
-#define TRAILER_MAGIC 0x4846464D4954494Cull
-
 char *read_input_buffer(const char *filename, uint64_t *size)      /* huffman.c:61-78 */
 {
     FILE *f = fopen(filename, "rb");
@@ -33,13 +31,14 @@ static Node *build_node(const mi_huffman_tree *t, int id)
     return n;
 }
 
-/* buffer layout: [words: 4*(word_idx + (bit_idx>0))][one zero word][pad to 8][magic][n][ntiles][tile_off[ntiles+1]] */
+/* writer->buffer holds the words alone (every word kept, plus one zero word); the encoder's tile offsets — the sync
+ * points the parallel decoder needs — are registered out of band (dropin_common.h) under the buffer pointer. */
 Node huffman_compress(char *buffer, uint64_t size, BitWriter *writer)
 {
     mi_ctx *ctx = dropin_ctx();
     const uint64_t cap = mi_huffman_bound_words(size);
     const uint64_t ntiles = (size + MI_HUFFMAN_TILE - 1) / MI_HUFFMAN_TILE;
-    uint32_t *words = (uint32_t *)calloc(cap + 4 + 2 * (4 + ntiles + 1), 4);
+    uint32_t *words = (uint32_t *)calloc(cap + 4, 4);
     uint64_t *toff = (uint64_t *)malloc(8 * (ntiles + 1));
     mi_huffman_info info; mi_huffman_tree tree;
     if (!words || !toff) { fprintf(stderr, "huffman_compress: out of memory\n"); exit(1); }
@@ -49,11 +48,9 @@ Node huffman_compress(char *buffer, uint64_t size, BitWriter *writer)
     if (st != MI_OK) { fprintf(stderr, "huffman_compress: %s\n", mi_status_str(st)); exit(1); }
     writer->word_idx = info.word_idx; writer->bit_idx = info.bit_idx; writer->buffer_size = info.buffer_size;
     const uint64_t nw = info.word_idx + (info.bit_idx > 0);
-    uint64_t at = ((nw + 1) * 4 + 7) & ~7ull;
-    uint64_t *t = (uint64_t *)((uint8_t *)words + at);
-    t[0] = TRAILER_MAGIC; t[1] = size; t[2] = ntiles;
-    memcpy(t + 3, toff, 8 * (ntiles + 1));
-    writer->buffer = (uint32_t *)realloc(words, at + 8 * (3 + ntiles + 1));
+    writer->buffer = (uint32_t *)realloc(words, (nw + 1) * 4);
+    if (!writer->buffer) { fprintf(stderr, "huffman_compress: out of memory\n"); exit(1); }
+    dropin_side_put(writer->buffer, info.total_bits, size, ntiles, toff, ntiles + 1);
     free(toff);
     Node *root = build_node(&tree, (int)info.n_nodes - 1);
     Node r = *root;
@@ -84,10 +81,8 @@ void huffman_decompress(BitWriter *writer, Node *root, char *output, uint64_t *o
     memcpy(tree.code, codes, sizeof codes); memcpy(tree.length, lens, sizeof lens);
     const uint64_t n = *output_size;                            /* the original length (huffman/main.c:69) */
     const uint64_t bits = writer->word_idx * 32 + writer->bit_idx;
-    const uint64_t nw = writer->word_idx + (writer->bit_idx > 0);
-    const uint64_t at = ((nw + 1) * 4 + 7) & ~7ull;
-    const uint64_t *t = (const uint64_t *)((const uint8_t *)writer->buffer + at);
-    const uint64_t *toff = (t[0] == TRAILER_MAGIC && t[1] == n) ? t + 3 : NULL;   /* foreign stream: single-lane decode */
+    const dropin_side *e = dropin_side_get(writer->buffer, bits, n);
+    const uint64_t *toff = (e && e->count == (n + MI_HUFFMAN_TILE - 1) / MI_HUFFMAN_TILE + 1) ? e->table : NULL;   /* foreign stream: single-lane decode */
     mi_status st = mi_huffman_decode(ctx, writer->buffer, bits, &tree, (uint32_t)next, toff, (uint8_t *)output, n);
     if (st != MI_OK) { fprintf(stderr, "huffman_decompress: %s\n", mi_status_str(st)); exit(1); }
     *output_size = n;

@@ -3,8 +3,6 @@
 #include "../../include/mi_lz77.h"
 #include "dropin_common.h"
 
-#define TRAILER_MAGIC 0x4C5A37374D49424Bull   /* "KBIM77ZL" */
-
 static uint32_t g_wbits = WINDOW_BITS;
 void mi_lz77_set_window_bits(uint32_t w) { g_wbits = w; }
 static uint32_t cur_wbits(void)
@@ -35,7 +33,8 @@ bool check_buffer_equivalence(const char *a, const char *b, uint64_t size)     /
     return diff == 0;
 }
 
-/* data layout: [stream: bit_index/8+1 bytes][pad to 8][magic][wbits][block][nblocks][bits[nblocks+1]] */
+/* `data` holds the stream alone (bit_index/8 + 1 bytes, like lz77.c:341-342); the per-block bit offsets a parallel
+ * decoder needs are registered out of band (dropin_common.h) under the data pointer. */
 BitStream *lz77_compress(const char *buffer, uint64_t size)
 {
     mi_ctx *ctx = dropin_ctx();
@@ -43,19 +42,16 @@ BitStream *lz77_compress(const char *buffer, uint64_t size)
     p.block = MI_LZ77_BLOCK;
     const uint64_t nblocks = mi_lz_num_blocks(size, &p);
     const uint64_t cap = mi_lz_bound_bytes(size, &p) + 64;
-    const uint64_t trailer = 8 * (4 + nblocks + 1);
-    uint8_t *data = (uint8_t *)calloc(1, cap + 8 + trailer);
+    uint8_t *data = (uint8_t *)calloc(1, cap + 8);
     uint64_t *bits = (uint64_t *)malloc(8 * (nblocks + 1));
     BitStream *s = (BitStream *)malloc(sizeof *s);
     if (!data || !bits || !s) { fprintf(stderr, "lz77_compress: out of memory\n"); exit(1); }
     mi_status st = mi_lz_encode(ctx, &p, (const uint8_t *)buffer, size, data, cap, bits);
     if (st != MI_OK) { fprintf(stderr, "lz77_compress: %s\n", mi_status_str(st)); exit(1); }
     s->bit_index = bits[nblocks];
-    uint64_t at = (s->bit_index / 8 + 1 + 7) & ~7ull;
-    uint64_t *t = (uint64_t *)(data + at);
-    t[0] = TRAILER_MAGIC; t[1] = p.wbits; t[2] = p.block; t[3] = nblocks;
-    memcpy(t + 4, bits, 8 * (nblocks + 1));
-    s->data = (uint8_t *)realloc(data, at + trailer);          /* lz77.c:341-342 shrinks too */
+    s->data = (uint8_t *)realloc(data, s->bit_index / 8 + 1);  /* lz77.c:341-342 */
+    if (!s->data) { fprintf(stderr, "lz77_compress: out of memory\n"); exit(1); }
+    dropin_side_put(s->data, s->bit_index, size, ((uint64_t)p.wbits << 32) | p.block, bits, nblocks + 1);
     free(bits);
     return s;
 }
@@ -66,17 +62,17 @@ char *lz77_decompress(BitStream *cs, uint64_t size, uint64_t *decompressed_size)
     const uint64_t total = cs->bit_index;
     cs->bit_index = 0;                                          /* lz77.c:355-356 */
     char *out = (char *)malloc(size ? size : 1);
-    uint64_t at = (total / 8 + 1 + 7) & ~7ull;
-    const uint64_t *t = (const uint64_t *)(cs->data + at);
     mi_lz_params p = mi_lz_params_lz77(cur_wbits());
     p.block = MI_LZ77_BLOCK;
     uint64_t one[2] = {0, total};
     const uint64_t *bits = one;
     if (size > p.block) {
-        /* more than one block: the offsets must be the ones lz77_compress stored behind the stream */
-        if (t[0] != TRAILER_MAGIC) { fprintf(stderr, "lz77_decompress: stream carries no block table\n"); exit(1); }
-        p.wbits = (uint32_t)t[1]; p.tbits = p.wbits + 6; p.block = (uint32_t)t[2];
-        bits = t + 4;
+        /* more than one block: the offsets are the ones lz77_compress registered for this buffer */
+        const dropin_side *e = dropin_side_get(cs->data, total, size);
+        if (!e) { fprintf(stderr, "lz77_decompress: stream carries no block table (not produced by this library's lz77_compress)\n"); exit(1); }
+        p.wbits = (uint32_t)(e->aux >> 32); p.tbits = p.wbits + 6; p.block = (uint32_t)e->aux;
+        if (e->count != mi_lz_num_blocks(size, &p) + 1) { fprintf(stderr, "lz77_decompress: block table does not match the size\n"); exit(1); }
+        bits = e->table;
     }
     mi_status st = mi_lz_decode(ctx, &p, cs->data, total / 8 + 1, bits, (uint8_t *)out, size);
     if (st != MI_OK) { fprintf(stderr, "lz77_decompress: %s\n", mi_status_str(st)); exit(1); }

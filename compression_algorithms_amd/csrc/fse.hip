@@ -282,7 +282,7 @@ void k_fse_encode(const uint8_t *__restrict__ in, uint64_t n_total, FseP P, uint
 
 // one wave per block: lane i decodes sub-stream i forwards, reading its bits backwards
 __global__ __launch_bounds__(64)
-void k_fse_decode(const uint8_t *__restrict__ packed, const uint64_t *__restrict__ offsets, FseP P,
+void k_fse_decode(const uint8_t *__restrict__ packed, uint64_t packed_bytes, const uint64_t *__restrict__ offsets, FseP P,
                   uint8_t *__restrict__ out, uint64_t n_total, uint32_t *__restrict__ err)
 {
     __shared__ uint32_t s_cnt[256], s_cum[256], s_fill[256];
@@ -295,7 +295,15 @@ void k_fse_decode(const uint8_t *__restrict__ packed, const uint64_t *__restrict
     const uint64_t off = b * (uint64_t)P.block;
     const uint32_t n = (uint32_t)((n_total - off) < P.block ? (n_total - off) : P.block);
     const uint32_t L = P.L, N = 1u << L, S = P.S;
-    const uint8_t *rec = packed + (offsets[b] >> 3);
+    // the record [rb, re) must lie inside the packed buffer and hold at least the fixed part of a header; every field
+    // read below is checked against re before it is used (records come from files / peers)
+    const uint64_t rb = offsets[b], re = offsets[b + 1];
+    if ((rb & 31u) || (re & 31u) || re < rb || re > packed_bytes * 8ull || (re - rb) < 8ull * (32u + 4u)) {
+        if (n && lane == 0) atomicOr(err, 1u);
+        return;
+    }
+    const uint32_t rec_bytes = (uint32_t)(((re - rb) >> 3) > 0xFFFFFFFFull ? 0xFFFFFFFFull : ((re - rb) >> 3));
+    const uint8_t *rec = packed + (rb >> 3);
     // header: bitmap + counts
     uint32_t pres[4], t = 0;
 #pragma unroll
@@ -308,7 +316,7 @@ void k_fse_decode(const uint8_t *__restrict__ packed, const uint64_t *__restrict
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         uint32_t c = 0;
-        if (pres[k]) { c = rec[32 + 2 * r] | ((uint32_t)rec[32 + 2 * r + 1] << 8); ++r; }
+        if (pres[k]) { if (32u + 2u * r + 2u <= rec_bytes) c = rec[32 + 2 * r] | ((uint32_t)rec[32 + 2 * r + 1] << 8); ++r; }
         s_cnt[lane * 4 + k] = c; sum += c;
     }
 #pragma unroll
@@ -329,6 +337,9 @@ void k_fse_decode(const uint8_t *__restrict__ packed, const uint64_t *__restrict
     }
     __builtin_amdgcn_wave_barrier();
     const uint32_t hdr = 32u + 2u * (nsym + (nsym & 1u));
+    const uint32_t fixed = hdr + 2u * (S + (S & 1u)) + 4u * S;                 // bytes before the payload words
+    if (fixed > rec_bytes) { if (lane == 0) atomicOr(err, 1u); return; }
+    const uint32_t payload_words = (rec_bytes - fixed) >> 2;
     const uint8_t *states = rec + hdr;
     const uint8_t *lens = states + 2u * (S + (S & 1u));
     const uint32_t *payload = reinterpret_cast<const uint32_t *>(lens + 4u * S);
@@ -340,10 +351,14 @@ void k_fse_decode(const uint8_t *__restrict__ packed, const uint64_t *__restrict
         nbits = lens[4 * lane] | ((uint32_t)lens[4 * lane + 1] << 8) | ((uint32_t)lens[4 * lane + 2] << 16) | ((uint32_t)lens[4 * lane + 3] << 24);
         tstate = states[2 * lane] | ((uint32_t)states[2 * lane + 1] << 8);
     }
+    // a sub-stream of m symbols holds at most m * L bits: a length above that is corrupt (and would index past the record)
+    if (nbits > m * L) { bad = true; nbits = 0; }
     const uint32_t nwords = (nbits + 31u) >> 5;
     uint32_t winc = nwords;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(winc, o); if (lane >= (uint32_t)o) winc += v; }
+    if (__shfl(winc, 63) > payload_words) bad = true;                          // the sub-streams must fit the record
+    if (__ballot(bad) != 0ull) { if (lane == 0) atomicOr(err, 1u); return; }
     const uint32_t *w = payload + (winc - nwords);
     uint32_t pos = nbits;
     uint8_t *dst = out + off + a;
@@ -476,23 +491,21 @@ extern "C" mi_status mi_fse_encode_dev(mi_ctx *ctx, const mi_fse_params *p, cons
     return MI_OK;
 }
 
-extern "C" mi_status mi_fse_decode_dev(mi_ctx *ctx, const mi_fse_params *p, const uint8_t *d_packed,
+extern "C" mi_status mi_fse_decode_dev(mi_ctx *ctx, const mi_fse_params *p, const uint8_t *d_packed, uint64_t packed_bytes,
                                        const uint64_t *d_offsets, uint8_t *d_out, uint64_t n, void *stream)
 {
-    if (!ctx || !d_packed || !d_offsets || (n && !d_out)) return MI_ERR_ARG;
+    if (!ctx || !d_packed || !d_offsets || (n && !d_out) || ((uintptr_t)d_packed & 3u)) return MI_ERR_ARG;
     mi_status st = fse_check(p);
     if (st) return st;
     if (n == 0) return MI_OK;
     hipStream_t s = (hipStream_t)stream;
     const FseP P{p->table_log, p->streams, p->spread, p->block};
     const uint64_t nblocks = (n + P.block - 1) / P.block;
-    st = mi_ws_reserve(ctx, 4096);
-    if (st) return st;
-    uint32_t *err = reinterpret_cast<uint32_t *>(ctx->ws);
-    MI_HIP(ctx, hipMemsetAsync(err, 0, 4, s));
+    uint32_t *err = mi_err_slot(ctx, s);
+    if (!err) return MI_ERR_HIP;
     {
         mi_prof_scope pr(ctx, "k_fse_decode", s, n);
-        hipLaunchKernelGGL(k_fse_decode, dim3((unsigned)nblocks), dim3(64), 5u << P.L, s, d_packed, d_offsets, P, d_out, n, err);
+        hipLaunchKernelGGL(k_fse_decode, dim3((unsigned)nblocks), dim3(64), 5u << P.L, s, d_packed, packed_bytes, d_offsets, P, d_out, n, err);
     }
     uint32_t h_err = 0;
     MI_HIP(ctx, hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, s));

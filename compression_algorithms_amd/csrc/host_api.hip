@@ -43,6 +43,11 @@ extern "C" mi_status mi_huffman_decode(mi_ctx *ctx, const uint32_t *h_words, uin
     if (n == 0) return MI_OK;
     hipStream_t s = mi_host_stream(ctx);
     const uint64_t nw = (total_bits + 31) >> 5, ntiles = (n + MI_HUFFMAN_TILE - 1) / MI_HUFFMAN_TILE;
+    if (h_tile_off) {                                   // tile offsets index the words: monotonic and inside the stream
+        mi_status vt = mi_validate_block_table(h_tile_off, ntiles, nw * 4, 1u);
+        if (vt) return vt;
+        if (h_tile_off[ntiles] > total_bits) return MI_ERR_CORRUPT;
+    }
     DevBuf words, tree, toff, out;
     if (!words.alloc((nw + 2) * 4) || !tree.alloc(sizeof(mi_huffman_tree)) || !toff.alloc((ntiles + 1) * 8) || !out.alloc(n + 16))
         return MI_ERR_NOMEM;
@@ -64,12 +69,15 @@ extern "C" mi_status mi_lz_decode(mi_ctx *ctx, const mi_lz_params *p, const uint
     if (n == 0) return MI_OK;
     hipStream_t s = mi_host_stream(ctx);
     const uint64_t nblocks = (n + p->block - 1) / p->block;
+    // the table indexes the stream: check it before anything is copied or launched
+    mi_status st = mi_validate_block_table(h_block_bits, nblocks, stream_bytes, p->deflate ? 8u : 1u);
+    if (st) return st;
     DevBuf st_, bits, out;
     if (!st_.alloc(stream_bytes + 64) || !bits.alloc((nblocks + 1) * 8) || !out.alloc(n + 16)) return MI_ERR_NOMEM;
     MI_HIP(ctx, hipMemsetAsync(st_.as<uint8_t>() + stream_bytes, 0, 64, s));
     MI_HIP(ctx, hipMemcpyAsync(st_.p, h_stream, stream_bytes, hipMemcpyHostToDevice, s));
     MI_HIP(ctx, hipMemcpyAsync(bits.p, h_block_bits, (nblocks + 1) * 8, hipMemcpyHostToDevice, s));
-    mi_status st = mi_lz_decode_dev(ctx, p, st_.as<uint8_t>(), bits.as<uint64_t>(), out.as<uint8_t>(), n, s);
+    st = mi_lz_decode_dev(ctx, p, st_.as<uint8_t>(), stream_bytes, bits.as<uint64_t>(), out.as<uint8_t>(), n, s);
     if (st) return st;
     MI_HIP(ctx, hipMemcpy(h_out, out.p, n, hipMemcpyDeviceToHost));
     return MI_OK;
@@ -80,7 +88,7 @@ extern "C" mi_status mi_deflate_h_encode(mi_ctx *ctx, const mi_lz_params *p, con
 {
     if (!ctx || !p || !h_out || !h_block_bits || (n && !h_in) || !p->block) return MI_ERR_ARG;
     hipStream_t s = mi_host_stream(ctx);
-    const uint64_t nblocks = (n + p->block - 1) / p->block, bound = mi_deflate_h_bound_bytes(n);
+    const uint64_t nblocks = (n + p->block - 1) / p->block, bound = mi_deflate_h_bound_bytes(n, p);
     DevBuf in, out, bits;
     if (!in.alloc(n + 64) || !out.alloc(bound + 64) || !bits.alloc((nblocks + 1) * 8)) return MI_ERR_NOMEM;
     if (n) MI_HIP(ctx, hipMemcpyAsync(in.p, h_in, n, hipMemcpyHostToDevice, s));
@@ -101,13 +109,14 @@ extern "C" mi_status mi_deflate_h_decode(mi_ctx *ctx, const mi_lz_params *p, con
     if (n == 0) return MI_OK;
     hipStream_t s = mi_host_stream(ctx);
     const uint64_t nblocks = (n + p->block - 1) / p->block;
-    if (h_block_bits[nblocks] / 8 > stream_bytes) return MI_ERR_CORRUPT;
+    mi_status st = mi_validate_block_table(h_block_bits, nblocks, stream_bytes, 32u);
+    if (st) return st;
     DevBuf st_, bits, out;
     if (!st_.alloc(stream_bytes + 64) || !bits.alloc((nblocks + 1) * 8) || !out.alloc(n + 16)) return MI_ERR_NOMEM;
     MI_HIP(ctx, hipMemsetAsync(st_.as<uint8_t>() + stream_bytes, 0, 64, s));
     MI_HIP(ctx, hipMemcpyAsync(st_.p, h_stream, stream_bytes, hipMemcpyHostToDevice, s));
     MI_HIP(ctx, hipMemcpyAsync(bits.p, h_block_bits, (nblocks + 1) * 8, hipMemcpyHostToDevice, s));
-    mi_status st = mi_deflate_h_decode_dev(ctx, p, st_.as<uint8_t>(), bits.as<uint64_t>(), out.as<uint8_t>(), n, s);
+    st = mi_deflate_h_decode_dev(ctx, p, st_.as<uint8_t>(), stream_bytes, bits.as<uint64_t>(), out.as<uint8_t>(), n, s);
     if (st) return st;
     MI_HIP(ctx, hipMemcpy(h_out, out.p, n, hipMemcpyDeviceToHost));
     return MI_OK;
@@ -132,18 +141,21 @@ extern "C" mi_status mi_fse_encode(mi_ctx *ctx, const mi_fse_params *p, const ui
     return MI_OK;
 }
 
-extern "C" mi_status mi_fse_decode(mi_ctx *ctx, const mi_fse_params *p, const uint8_t *h_packed, const uint64_t *h_offsets,
-                                   uint8_t *h_out, uint64_t n)
+extern "C" mi_status mi_fse_decode(mi_ctx *ctx, const mi_fse_params *p, const uint8_t *h_packed, uint64_t packed_bytes,
+                                   const uint64_t *h_offsets, uint8_t *h_out, uint64_t n)
 {
     if (!ctx || !p || !h_packed || !h_offsets || (n && !h_out) || !p->block) return MI_ERR_ARG;
     if (n == 0) return MI_OK;
     hipStream_t s = mi_host_stream(ctx);
-    const uint64_t nblocks = (n + p->block - 1) / p->block, bytes = h_offsets[nblocks] / 8;
+    const uint64_t nblocks = (n + p->block - 1) / p->block;
+    mi_status st = mi_validate_block_table(h_offsets, nblocks, packed_bytes, 32u);
+    if (st) return st;
+    const uint64_t bytes = h_offsets[nblocks] / 8;
     DevBuf in, offs, out;
     if (!in.alloc(bytes + 16) || !offs.alloc((nblocks + 1) * 8) || !out.alloc(n + 16)) return MI_ERR_NOMEM;
     MI_HIP(ctx, hipMemcpyAsync(in.p, h_packed, bytes, hipMemcpyHostToDevice, s));
     MI_HIP(ctx, hipMemcpyAsync(offs.p, h_offsets, (nblocks + 1) * 8, hipMemcpyHostToDevice, s));
-    mi_status st = mi_fse_decode_dev(ctx, p, in.as<uint8_t>(), offs.as<uint64_t>(), out.as<uint8_t>(), n, s);
+    st = mi_fse_decode_dev(ctx, p, in.as<uint8_t>(), bytes, offs.as<uint64_t>(), out.as<uint8_t>(), n, s);
     if (st) return st;
     MI_HIP(ctx, hipMemcpy(h_out, out.p, n, hipMemcpyDeviceToHost));
     return MI_OK;

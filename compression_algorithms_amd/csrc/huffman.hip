@@ -430,27 +430,37 @@ void k_huff_decode(const uint32_t *__restrict__ words, uint64_t total_bits, cons
     __shared__ uint8_t  s_val[511];
     const uint32_t lane = threadIdx.x;
     for (uint32_t i = lane; i < (1u << HUFF_LUT_BITS); i += 64) s_lut[i] = 0;
-    for (uint32_t i = lane; i < 511; i += 64) { s_left[i] = tree->left[i]; s_right[i] = tree->right[i]; s_val[i] = tree->value[i]; }
+    // the tree arrays come from the caller (a file, a peer): children must be node ids or -1, codes must fit their length
+    bool bad = false;
+    for (uint32_t i = lane; i < 511; i += 64) {
+        const int l = tree->left[i], r = tree->right[i];
+        if (l < -1 || l > 510 || r < -1 || r > 510 || ((l < 0) != (r < 0))) bad = true;
+        s_left[i] = (int16_t)l; s_right[i] = (int16_t)r; s_val[i] = tree->value[i];
+    }
     __syncthreads();
     for (uint32_t s = lane; s < 256; s += 64) {
         const uint32_t l = tree->length[s], c = tree->code[s];
-        if (l && l <= HUFF_LUT_BITS) {
+        if (l && l <= HUFF_LUT_BITS && (c >> l) != 0) bad = true;
+        else if (l && l <= HUFF_LUT_BITS) {
             const uint32_t lo = c << (HUFF_LUT_BITS - l), cnt = 1u << (HUFF_LUT_BITS - l);
             for (uint32_t k = 0; k < cnt; ++k) s_lut[lo + k] = (uint16_t)((l << 8) | s);
         }
     }
+    __syncthreads();
+    if (__ballot(bad) != 0ull) { if (lane == 0) atomicOr(err, 1u); return; }
     __syncthreads();
     const uint64_t t = (uint64_t)blockIdx.x * 64 + lane;
     if (t >= ntiles) return;
     const uint64_t o0 = t * tile_bytes, o1 = (o0 + tile_bytes < n) ? o0 + tile_bytes : n;
     uint64_t bit = tile_off ? tile_off[t] : 0;
     const int root = (int)n_nodes - 1;
+    const uint64_t nwords = (total_bits + 31) >> 5;              // words past the stream read as zero
     uint32_t pack = 0;
-    bool bad = false;
+    if (bit > total_bits) { atomicOr(err, 1u); return; }
     for (uint64_t o = o0; o < o1; ++o) {
         // next 32 stream bits, MSB first: bit j of the stream is bit 31 - j%32 of word j/32
         const uint64_t wi = bit >> 5; const uint32_t sh = (uint32_t)(bit & 31u);
-        const uint64_t two = ((uint64_t)words[wi] << 32) | words[wi + 1];
+        const uint64_t two = ((uint64_t)(wi < nwords ? words[wi] : 0u) << 32) | (wi + 1 < nwords ? words[wi + 1] : 0u);
         const uint32_t peek = (uint32_t)((two << sh) >> 32);
         const uint32_t e = s_lut[peek >> (32 - HUFF_LUT_BITS)];
         uint32_t sym, len;
@@ -477,17 +487,18 @@ extern "C" mi_status mi_huffman_decode_dev(mi_ctx *ctx, const uint32_t *d_words,
     if (!ctx || !d_words || !d_tree || (n && !d_out) || n_nodes < 3 || n_nodes > 511) return MI_ERR_ARG;
     if (n == 0) return MI_OK;
     if (((uintptr_t)d_out & 3u) != 0) return MI_ERR_ARG;
+    // without tile offsets one lane walks the whole stream with a 32-bit tile length: refuse what it cannot cover
+    // instead of decoding a prefix
+    if (!d_tile_off && n > 0xFFFFFFFFull) return MI_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    mi_status st = mi_ws_reserve(ctx, 4096);
-    if (st) return st;
-    uint32_t *err = reinterpret_cast<uint32_t *>(ctx->ws);
-    MI_HIP(ctx, hipMemsetAsync(err, 0, 4, s));
+    uint32_t *err = mi_err_slot(ctx, s);
+    if (!err) return MI_ERR_HIP;
     const uint64_t ntiles = d_tile_off ? huff_ntiles(n) : 1;
     const uint32_t tile_bytes = d_tile_off ? HUFF_TILE : 0xFFFFFFFFu;
     {
         mi_prof_scope p(ctx, "k_huff_decode", s, n);
         hipLaunchKernelGGL(k_huff_decode, dim3((unsigned)((ntiles + 63) / 64)), dim3(64), 0, s, d_words, total_bits, d_tree,
-                           n_nodes, d_tile_off, ntiles, tile_bytes, d_out, d_tile_off ? n : (n < 0xFFFFFFFFull ? n : 0xFFFFFFFFull), err);
+                           n_nodes, d_tile_off, ntiles, tile_bytes, d_out, n, err);
     }
     uint32_t h_err = 0;
     MI_HIP(ctx, hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, s));

@@ -357,8 +357,8 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
 // exclusive offsets (base + local) to the caller's array
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024)
-void k_lz_scan_blocks(const uint64_t *__restrict__ bits, uint32_t nb, const uint64_t *__restrict__ base_bits,
-                      uint64_t *__restrict__ excl_local, uint64_t *__restrict__ excl_global)
+void k_lz_scan_blocks(const uint64_t *bits, uint32_t nb, const uint64_t *__restrict__ base_bits,
+                      uint64_t *excl_local /* may alias `bits`: scanned in place */, uint64_t *__restrict__ excl_global)
 {
     __shared__ uint64_t s_tmp[18];
     const uint64_t v = threadIdx.x < nb ? bits[threadIdx.x] : 0;       // nb <= 1024 per batch
@@ -388,10 +388,12 @@ __device__ __forceinline__ uint32_t extract_bits(const uint32_t *w, uint64_t lo,
 // one thread per output dword of the batch's bit range [base, base + total)
 __global__ __launch_bounds__(256)
 void k_lz_concat(const uint32_t *__restrict__ slots, const uint64_t *__restrict__ excl_local, uint32_t nb,
-                 const uint64_t *__restrict__ base_bits, uint32_t *__restrict__ out)
+                 const uint64_t *__restrict__ base_bits, uint32_t *__restrict__ out, uint64_t cap_words)
 {
     const uint64_t base = *base_bits, total = excl_local[nb];
-    const uint64_t wfirst = base >> 5, wlast = (base + total + 31) >> 5;       // [wfirst, wlast)
+    const uint64_t wfirst = base >> 5;
+    uint64_t wlast = (base + total + 31) >> 5;                                 // [wfirst, wlast)
+    if (wlast > cap_words) wlast = cap_words;       // never past the caller's buffer (the host checked cap against the bound)
     // grid-stride: the grid is sized for a typical stream, the loop covers the worst case
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + wfirst; j < wlast; j += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t g0 = j << 5, g1 = g0 + 32;
@@ -421,17 +423,19 @@ void k_lz_concat(const uint32_t *__restrict__ slots, const uint64_t *__restrict_
 // decode: one wave per block, output staged in LDS.  A block stops at its original length: the
 // last match may overshoot (the encoder compares into the zero tail), SURVEY.md A.3.4.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t stream_bits(const uint8_t *s, uint64_t pos, uint32_t k)   // k <= 25
+// k <= 25 stream bits from bit `pos`; bytes at or past `nbytes` read as zero (the table and the stream come from a file
+// or a peer: nothing is read outside the buffer the caller described)
+__device__ __forceinline__ uint32_t stream_bits(const uint8_t *s, uint64_t nbytes, uint64_t pos, uint32_t k)
 {
     const uint64_t byte = pos >> 3;
     uint64_t v = 0;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) v |= (uint64_t)s[byte + i] << (8 * i);
+    for (int i = 0; i < 5; ++i) if (byte + i < nbytes) v |= (uint64_t)s[byte + i] << (8 * i);
     return (uint32_t)(v >> (pos & 7u)) & ((1u << k) - 1u);
 }
 
 __global__ __launch_bounds__(64)
-void k_lz_decode(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ block_bits, LzP P,
+void k_lz_decode(const uint8_t *__restrict__ stream, uint64_t stream_bytes, const uint64_t *__restrict__ block_bits, LzP P,
                  uint8_t *__restrict__ out, uint64_t n_total, uint32_t *__restrict__ err)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_out[LZ_MAX_BLOCK + 256];
@@ -442,19 +446,22 @@ void k_lz_decode(const uint8_t *__restrict__ stream, const uint64_t *__restrict_
     uint64_t pos = block_bits[b];
     const uint64_t end = block_bits[b + 1];
     uint32_t o = 0;
-    bool bad = false;
-    while (o < n && pos < end) {
+    // the block's bit range must lie inside the stream (an untrusted table must not steer reads anywhere else)
+    bool bad = end < pos || end > stream_bytes * 8ull;
+    const uint32_t MB = P.deflate ? 32u : 1u + P.wbits + P.lbits;
+    while (!bad && o < n && pos < end) {
         uint32_t flag, d = 0, len = 0, lit = 0;
         if (P.deflate) {
-            const uint32_t t0 = stream_bits(stream, pos, 16);
+            const uint32_t t0 = stream_bits(stream, stream_bytes, pos, 16);
             flag = t0 & 0xFFu;
+            if (flag > 1 || pos + (flag ? 32u : 16u) > end) { bad = true; break; }
             if (flag == 0) { lit = t0 >> 8; pos += 16; }
-            else { const uint32_t t1 = stream_bits(stream, pos + 16, 16); d = (t0 >> 8) | ((t1 & 0xFFu) << 8); len = t1 >> 8; pos += 32; }
-            if (flag > 1) { bad = true; break; }
+            else { const uint32_t t1 = stream_bits(stream, stream_bytes, pos + 16, 16); d = (t0 >> 8) | ((t1 & 0xFFu) << 8); len = t1 >> 8; pos += 32; }
         } else {
-            flag = stream_bits(stream, pos, 1);
-            if (!flag) { lit = stream_bits(stream, pos + 1, 8); pos += 9; }
-            else { d = stream_bits(stream, pos + 1, P.wbits); len = stream_bits(stream, pos + 1 + P.wbits, P.lbits); pos += 1 + P.wbits + P.lbits; }
+            flag = stream_bits(stream, stream_bytes, pos, 1);
+            if (pos + (flag ? MB : 9u) > end) { bad = true; break; }
+            if (!flag) { lit = stream_bits(stream, stream_bytes, pos + 1, 8); pos += 9; }
+            else { d = stream_bits(stream, stream_bytes, pos + 1, P.wbits); len = stream_bits(stream, stream_bytes, pos + 1 + P.wbits, P.lbits); pos += MB; }
         }
         if (!flag) {
             if (lane == 0) s_out[o] = (uint8_t)lit;
@@ -470,7 +477,7 @@ void k_lz_decode(const uint8_t *__restrict__ stream, const uint64_t *__restrict_
     if (o != n) bad = true;
     if (bad && lane == 0) atomicOr(err, 1u);
     __syncthreads();
-    for (uint32_t i = lane; i < n; i += 64) out[off + i] = s_out[i];
+    if (!bad) for (uint32_t i = lane; i < n; i += 64) out[off + i] = s_out[i];
 }
 
 // =============================================================================================
@@ -490,7 +497,7 @@ mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t
 uint32_t lz_batch_blocks(uint64_t nblocks);
 
 void defh_launch_encode(const uint32_t *trec, uint32_t *slots, uint64_t *block_bits, uint32_t nb, hipStream_t s);
-extern "C" uint64_t mi_deflate_h_bound_bytes(uint64_t n);
+extern "C" uint64_t mi_deflate_h_bound_bytes(uint64_t n, const mi_lz_params *p);
 
 // mode_h = 0: the reference's token stream.  mode_h = 1: the same tokens, entropy coded per block (defh.hip); the
 // per-block records are word aligned, so the same scan / concatenate kernels place them.
@@ -502,7 +509,7 @@ static mi_status lz_encode_impl(mi_ctx *ctx, const mi_lz_params *p, const uint8_
     if (st) return st;
     if (((uintptr_t)d_out & 3u) != 0) return MI_ERR_ARG;
     if (mode_h && (!p->deflate || p->lbits > 5 || p->wbits > 16)) return MI_ERR_ARG;
-    if (cap_bytes < (mode_h ? mi_deflate_h_bound_bytes(n) : mi_lz_bound_bytes(n, p))) return MI_ERR_CAPACITY;
+    if (cap_bytes < (mode_h ? mi_deflate_h_bound_bytes(n, p) : mi_lz_bound_bytes(n, p))) return MI_ERR_CAPACITY;
     hipStream_t s = (hipStream_t)stream;
     const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block};
     const uint64_t nblocks = (n + P.block - 1) / P.block;
@@ -542,7 +549,7 @@ static mi_status lz_encode_impl(mi_ctx *ctx, const mi_lz_params *p, const uint8_
             mi_prof_scope pr(ctx, "k_lz_concat", sp, (uint64_t)nb * P.block);
             const uint64_t typw = (uint64_t)nb * (P.block / 4 + 64);   // about one output byte per input byte; the kernel strides
             hipLaunchKernelGGL(k_lz_concat, dim3((unsigned)((typw + 255) / 256)), dim3(256), 0, sp, sc[k].slot, excl_local, nb,
-                               base_bits, reinterpret_cast<uint32_t *>(d_out));
+                               base_bits, reinterpret_cast<uint32_t *>(d_out), cap_bytes / 4);
         }
         hipLaunchKernelGGL(k_lz_advance, dim3(1), dim3(1), 0, sp, base_bits, excl_local, nb);
         if (overlap) MI_HIP(ctx, hipEventRecord(ctx->ev_done[k], sp));
@@ -620,7 +627,7 @@ extern "C" mi_status mi_lz_encode(mi_ctx *ctx, const mi_lz_params *p, const uint
     return st;
 }
 
-extern "C" mi_status mi_lz_decode_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_stream,
+extern "C" mi_status mi_lz_decode_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_stream, uint64_t stream_bytes,
                                       const uint64_t *d_block_bits, uint8_t *d_out, uint64_t n, void *stream)
 {
     if (!ctx || !d_stream || !d_block_bits || (n && !d_out)) return MI_ERR_ARG;
@@ -630,13 +637,11 @@ extern "C" mi_status mi_lz_decode_dev(mi_ctx *ctx, const mi_lz_params *p, const 
     hipStream_t s = (hipStream_t)stream;
     const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block};
     const uint64_t nblocks = (n + P.block - 1) / P.block;
-    st = mi_ws_reserve(ctx, 4096);
-    if (st) return st;
-    uint32_t *err = reinterpret_cast<uint32_t *>(ctx->ws);
-    MI_HIP(ctx, hipMemsetAsync(err, 0, 4, s));
+    uint32_t *err = mi_err_slot(ctx, s);
+    if (!err) return MI_ERR_HIP;
     {
         mi_prof_scope pr(ctx, "k_lz_decode", s, n);
-        hipLaunchKernelGGL(k_lz_decode, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, d_block_bits, P, d_out, n, err);
+        hipLaunchKernelGGL(k_lz_decode, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, stream_bytes, d_block_bits, P, d_out, n, err);
     }
     uint32_t h_err = 0;
     MI_HIP(ctx, hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, s));

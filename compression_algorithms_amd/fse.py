@@ -52,7 +52,7 @@ def compress(data, p=None, ctx=None):
 def decompress(stream, ctx=None):
     ctx = ctx or default_context()
     out = torch.empty(max(stream.n, 1), dtype=torch.uint8, device=ctx.device)
-    st = ctx.L.mi_fse_decode_dev(ctx.h, C.byref(stream.p), C.c_void_p(stream.data.data_ptr()),
+    st = ctx.L.mi_fse_decode_dev(ctx.h, C.byref(stream.p), C.c_void_p(stream.data.data_ptr()), stream.data.numel(),
                                  C.c_void_p(stream.offsets.data_ptr()), C.c_void_p(out.data_ptr()), stream.n, ctx.stream_ptr())
     _lib.check(st, "mi_fse_decode_dev")
     return out[: stream.n]

@@ -59,7 +59,11 @@ class LzStream:
 
 
 def bound_bytes(n, p):
-    return 2 * n + 8 if p.deflate else (9 * n + 7) // 8 + 16
+    """mi_lz_bound_bytes of include/mi_codec.h (a static inline there)"""
+    nblocks = (n + p.block - 1) // p.block
+    if p.deflate:
+        return 2 * n + 2 * nblocks + 8
+    return (9 * n + nblocks * (p.wbits + p.lbits - 8) + 7) // 8 + 16
 
 
 def compress(data, p, ctx=None):
@@ -80,7 +84,7 @@ def compress(data, p, ctx=None):
 def decompress(stream, ctx=None):
     ctx = ctx or default_context()
     out = torch.empty(max(stream.n, 1), dtype=torch.uint8, device=ctx.device)
-    st = ctx.L.mi_lz_decode_dev(ctx.h, C.byref(stream.p), C.c_void_p(stream.data.data_ptr()),
+    st = ctx.L.mi_lz_decode_dev(ctx.h, C.byref(stream.p), C.c_void_p(stream.data.data_ptr()), stream.data.numel(),
                                 C.c_void_p(stream.block_bits.data_ptr()), C.c_void_p(out.data_ptr()), stream.n, ctx.stream_ptr())
     _lib.check(st, "mi_lz_decode_dev")
     return out[: stream.n]
@@ -96,7 +100,7 @@ def compress_h(data, p=None, ctx=None):
     d_in = as_device_bytes(data, ctx.device)
     n = d_in.numel()
     nblocks = (n + p.block - 1) // p.block
-    cap = int(ctx.L.mi_deflate_h_bound_bytes(n)) + 64
+    cap = int(ctx.L.mi_deflate_h_bound_bytes(n, C.byref(p))) + 64
     out = torch.empty(cap, dtype=torch.uint8, device=ctx.device)
     bits = torch.zeros(nblocks + 1, dtype=torch.int64, device=ctx.device)
     st = ctx.L.mi_deflate_h_encode_dev(ctx.h, C.byref(p), C.c_void_p(d_in.data_ptr() if n else 0), n, C.c_void_p(out.data_ptr()),
@@ -108,7 +112,7 @@ def compress_h(data, p=None, ctx=None):
 def decompress_h(stream, ctx=None):
     ctx = ctx or default_context()
     out = torch.empty(max(stream.n, 1), dtype=torch.uint8, device=ctx.device)
-    st = ctx.L.mi_deflate_h_decode_dev(ctx.h, C.byref(stream.p), C.c_void_p(stream.data.data_ptr()),
+    st = ctx.L.mi_deflate_h_decode_dev(ctx.h, C.byref(stream.p), C.c_void_p(stream.data.data_ptr()), stream.data.numel(),
                                        C.c_void_p(stream.block_bits.data_ptr()), C.c_void_p(out.data_ptr()), stream.n,
                                        ctx.stream_ptr())
     _lib.check(st, "mi_deflate_h_decode_dev")

@@ -29,8 +29,13 @@ def shard_bytes(n, block, rank, world):
 def gather_streams(data, block_bits, dst=0, group=None):
     """data: uint8 tensor (this rank's stream, byte aligned); block_bits: int64 [nb+1] exclusive
     prefix in bits.  Returns on `dst`: (stream uint8 tensor, global int64 block table), else (None, None).
-    Streams are byte-concatenated: use with byte-aligned flavours (deflate tokens, FSE records);
-    for the bit-packed lz77 flavour keep the per-rank streams separate or pad each to a byte."""
+    Streams are byte-concatenated: use with byte-aligned flavours (deflate tokens, mode-H / FSE records);
+    for the bit-packed lz77 flavour keep the per-rank streams separate or pad each to a byte.
+
+    Exchange: one all_gather of {bytes, blocks} per rank (16 B each), then ONE group of point-to-point
+    transfers (ncclGroupStart .. ncclSend/ncclRecv x (world-1) .. ncclGroupEnd under RCCL): every peer owns a direct
+    xGMI link into `dst`, so the variable-length gather is not ring-bound.  Two host reads: this rank's stream length
+    and the gathered sizes (the receive buffers have to be sized on the host)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = data.device
@@ -38,12 +43,13 @@ def gather_streams(data, block_bits, dst=0, group=None):
     meta = torch.tensor([nbytes, block_bits.numel() - 1], dtype=torch.int64, device=dev)
     metas = [torch.zeros_like(meta) for _ in range(world)]
     dist.all_gather(metas, meta, group=group)
+    metas = torch.stack(metas).cpu().tolist()
     sizes = [int(m[0]) for m in metas]
     nbs = [int(m[1]) for m in metas]
     if rank == dst:
         streams = [None] * world
         tables = [None] * world
-        reqs = []
+        ops = []
         for r in range(world):
             if r == rank:
                 streams[r], tables[r] = data[:nbytes], block_bits
@@ -51,10 +57,11 @@ def gather_streams(data, block_bits, dst=0, group=None):
                 streams[r] = torch.empty(sizes[r], dtype=torch.uint8, device=dev)
                 tables[r] = torch.empty(nbs[r] + 1, dtype=torch.int64, device=dev)
                 if sizes[r]:
-                    reqs.append(dist.irecv(streams[r], src=r, group=group))
-                reqs.append(dist.irecv(tables[r], src=r, group=group))
-        for q in reqs:
-            q.wait()
+                    ops.append(dist.P2POp(dist.irecv, streams[r], r, group))
+                ops.append(dist.P2POp(dist.irecv, tables[r], r, group))
+        if ops:
+            for q in dist.batch_isend_irecv(ops):
+                q.wait()
         out = torch.cat(streams)
         base, parts = 0, []
         for r in range(world):
@@ -62,7 +69,10 @@ def gather_streams(data, block_bits, dst=0, group=None):
             base += sizes[r] * 8
         parts.append(torch.tensor([base], dtype=torch.int64, device=dev))
         return out, torch.cat(parts)
+    ops = []
     if nbytes:
-        dist.send(data[:nbytes].contiguous(), dst=dst, group=group)
-    dist.send(block_bits.contiguous(), dst=dst, group=group)
+        ops.append(dist.P2POp(dist.isend, data[:nbytes].contiguous(), dst, group))
+    ops.append(dist.P2POp(dist.isend, block_bits.contiguous(), dst, group))
+    for q in dist.batch_isend_irecv(ops):
+        q.wait()
     return None, None

@@ -51,6 +51,11 @@ int         mi_last_hip_error(const mi_ctx *ctx);
 const char *mi_version(void);
 /* blocks until everything queued on `stream` has finished */
 mi_status   mi_sync(mi_ctx *ctx, void *stream);
+/* Host-side check of a block table (exclusive prefix of per-block stream lengths in BITS, nblocks+1 entries) that came
+ * from a file or a peer: non-decreasing, every entry a multiple of align_bits (1: bit-packed lz77; 8: deflate tokens;
+ * 32: mode-H and FSE records), last entry <= 8 * stream_bytes.  MI_OK or MI_ERR_CORRUPT.  The host-buffer decoders call
+ * it themselves; callers of the *_dev decoders that hold the table on the host should. */
+mi_status   mi_validate_block_table(const uint64_t *h_block_bits, uint64_t nblocks, uint64_t stream_bytes, uint32_t align_bits);
 
 /* ------------------------------------------------------------------------------------
  * Huffman, whole buffer, one tree        replaces algorithms/huffman/huffman.c:288-328
@@ -134,10 +139,15 @@ static inline mi_lz_params mi_lz_params_deflate(void) { mi_lz_params p = {15, 5,
 static inline mi_lz_params mi_lz_params_lz77(uint32_t wbits) { mi_lz_params p = {wbits, 4, wbits + 6, 0, 65536}; return p; }
 
 static inline uint64_t mi_lz_num_blocks(uint64_t n, const mi_lz_params *p) { return (n + p->block - 1) / p->block; }
-/* bound on the concatenated stream, in bytes */
+/* bound on the concatenated stream, in bytes.  Per block: every byte a literal (2 bytes / 9 bits), except that the
+ * block's LAST token may be a match that covers a single real byte and runs on into the zero tail the reference
+ * reads past `size`: that match costs 4 bytes (deflate) or 1+wbits+lbits bits (lz77) instead of
+ * one literal — +2 bytes / +(wbits+lbits-8) bits per block. */
 static inline uint64_t mi_lz_bound_bytes(uint64_t n, const mi_lz_params *p)
 {
-    return p->deflate ? 2 * n + 8 : (9 * n + 7) / 8 + 16;
+    const uint64_t nblocks = p->block ? (n + p->block - 1) / p->block : 0;
+    if (p->deflate) return 2 * n + 2 * nblocks + 8;
+    return (9 * n + nblocks * (uint64_t)(p->wbits + p->lbits - 8) + 7) / 8 + 16;
 }
 
 /*
@@ -152,8 +162,11 @@ mi_status mi_lz_encode_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_
                            uint8_t *d_out, uint64_t cap_bytes, uint64_t *d_block_bits, void *stream);
 mi_status mi_lz_encode(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *h_in, uint64_t n,
                        uint8_t *h_out, uint64_t cap_bytes, uint64_t *h_block_bits);
-/* decode; every block is truncated at its original length (an overshooting last match, A.3.4) */
-mi_status mi_lz_decode_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_stream,
+/* decode; every block is truncated at its original length (an overshooting last match, A.3.4).
+ * stream_bytes = readable bytes at d_stream: the kernel never reads outside [d_stream, d_stream + stream_bytes) and
+ * never outside a block's own bit range, whatever the table says.  Like every decoder of this ABI it synchronises
+ * `stream` before returning (MI_ERR_CORRUPT is decided on the device). */
+mi_status mi_lz_decode_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_stream, uint64_t stream_bytes,
                            const uint64_t *d_block_bits, uint8_t *d_out, uint64_t n, void *stream);
 
 mi_status mi_lz_decode(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *h_stream, uint64_t stream_bytes,
@@ -180,10 +193,12 @@ mi_status mi_lz_find_all_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *
  * d_block_bits u64[nblocks+1]: exclusive prefix of record lengths in BITS (multiples of 32).
  * p must be a deflate-flavour parameter set with lbits <= 5 and wbits <= 16.
  * ------------------------------------------------------------------------------------ */
-uint64_t  mi_deflate_h_bound_bytes(uint64_t n);
+/* worst case of the concatenated records: per block the 292-byte header plus 9 bits per byte (a Huffman code is never
+ * longer than the fixed 9-bit code over 286 symbols) plus one overshooting last match (<= 20 extra bits), word aligned */
+uint64_t  mi_deflate_h_bound_bytes(uint64_t n, const mi_lz_params *p);
 mi_status mi_deflate_h_encode_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_in, uint64_t n,
                                   uint8_t *d_out, uint64_t cap_bytes, uint64_t *d_block_bits, void *stream);
-mi_status mi_deflate_h_decode_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_stream,
+mi_status mi_deflate_h_decode_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_stream, uint64_t stream_bytes,
                                   const uint64_t *d_block_bits, uint8_t *d_out, uint64_t n, void *stream);
 mi_status mi_deflate_h_encode(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *h_in, uint64_t n,
                               uint8_t *h_out, uint64_t cap_bytes, uint64_t *h_block_bits);
@@ -207,13 +222,13 @@ uint64_t  mi_fse_block_bound(const mi_fse_params *p);        /* bytes per block 
  * d_packed (optional, may be NULL): the records concatenated; d_offsets u64[nblocks+1]. */
 mi_status mi_fse_encode_dev(mi_ctx *ctx, const mi_fse_params *p, const uint8_t *d_in, uint64_t n,
                             uint8_t *d_packed, uint64_t cap_bytes, uint64_t *d_offsets, void *stream);
-mi_status mi_fse_decode_dev(mi_ctx *ctx, const mi_fse_params *p, const uint8_t *d_packed,
+mi_status mi_fse_decode_dev(mi_ctx *ctx, const mi_fse_params *p, const uint8_t *d_packed, uint64_t packed_bytes,
                             const uint64_t *d_offsets, uint8_t *d_out, uint64_t n, void *stream);
 /* host-buffer versions.  h_packed needs mi_fse_block_bound() * nblocks bytes; h_offsets u64[nblocks+1] (bits). */
 mi_status mi_fse_encode(mi_ctx *ctx, const mi_fse_params *p, const uint8_t *h_in, uint64_t n,
                         uint8_t *h_packed, uint64_t cap_bytes, uint64_t *h_offsets);
-mi_status mi_fse_decode(mi_ctx *ctx, const mi_fse_params *p, const uint8_t *h_packed, const uint64_t *h_offsets,
-                        uint8_t *h_out, uint64_t n);
+mi_status mi_fse_decode(mi_ctx *ctx, const mi_fse_params *p, const uint8_t *h_packed, uint64_t packed_bytes,
+                        const uint64_t *h_offsets, uint8_t *h_out, uint64_t n);
 /* the normalisation step alone (main.zig:106-149), for parity tests: d_freq u64[256] -> d_cnt u32[256] */
 mi_status mi_fse_normalise_dev(mi_ctx *ctx, const uint64_t *d_freq, uint32_t table_log, uint32_t *d_cnt, void *stream);
 

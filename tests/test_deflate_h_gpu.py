@@ -129,7 +129,7 @@ def test_host_entry_points():
     data = synth.enwik_like(150_000, seed=4).numpy()
     p = lz.params("deflate")
     nblocks = (len(data) + p.block - 1) // p.block
-    cap = int(ctx.L.mi_deflate_h_bound_bytes(len(data)))
+    cap = int(ctx.L.mi_deflate_h_bound_bytes(len(data), C.byref(p)))
     out = np.zeros(cap, np.uint8)
     bits = np.zeros(nblocks + 1, np.uint64)
     _lib.check(ctx.L.mi_deflate_h_encode(ctx.h, C.byref(p), data.ctypes.data, len(data), out.ctypes.data, cap, bits.ctypes.data), "enc")
@@ -140,3 +140,30 @@ def test_host_entry_points():
     back = np.zeros(len(data), np.uint8)
     _lib.check(ctx.L.mi_deflate_h_decode(ctx.h, C.byref(p), out.ctypes.data, nbytes, bits.ctypes.data, back.ctypes.data, len(data)), "dec")
     assert np.array_equal(back, data)
+
+
+def test_small_blocks_stay_inside_the_bound():
+    """every block pays the 292-byte header, so the bound depends on p.block — random bytes at
+    block 1024 / 256 produce more than the old 64 KiB-block bound; the stream must equal the oracle's and fit."""
+    from compression_algorithms_amd import lz
+    from compression_algorithms_amd.context import default_context
+    import ctypes as C
+    ctx = default_context()
+    rng = np.random.default_rng(1)
+    data = rng.integers(0, 256, 65536, dtype=np.uint8)
+    for block in (1024, 256):
+        st = _check(data, block)
+        p = lz.params("deflate", None, block)
+        assert st.nbytes <= int(ctx.L.mi_deflate_h_bound_bytes(len(data), C.byref(p)))
+
+
+def test_overshooting_last_match_every_block():
+    """block = 8, every block ends in a match that covers ONE real byte and runs into the zero tail"""
+    from compression_algorithms_amd import lz
+    from compression_algorithms_amd.context import default_context
+    import ctypes as C
+    unit = np.array([0x41, 0, 0, 0, 0x61, 0x62, 0x63, 0x41], np.uint8)
+    data = np.tile(unit, 1000)
+    st = _check(data, 8)
+    p = lz.params("deflate", None, 8)
+    assert st.nbytes <= int(default_context().L.mi_deflate_h_bound_bytes(len(data), C.byref(p)))
