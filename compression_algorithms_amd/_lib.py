@@ -52,6 +52,7 @@ class KernelTime(C.Structure):
 EXPORTS = [
     "mi_ctx_create", "mi_ctx_destroy", "mi_status_str", "mi_last_hip_error", "mi_version", "mi_sync", "mi_validate_block_table",
     "mi_huffman_encode_dev", "mi_huffman_encode", "mi_huffman_encode2", "mi_huffman_decode_dev", "mi_huffman_decode",
+    "mi_huffman_num_tiles", "mi_huffman_hist_dev", "mi_huffman_build_dev", "mi_huffman_encode_with_tree_dev",
     "mi_lz_encode_dev", "mi_lz_encode", "mi_lz_decode_dev", "mi_lz_decode", "mi_lz_find_all_dev",
     "mi_deflate_h_bound_bytes", "mi_deflate_h_encode_dev", "mi_deflate_h_decode_dev", "mi_deflate_h_encode", "mi_deflate_h_decode",
     "mi_fse_block_bound", "mi_fse_encode_dev", "mi_fse_decode_dev", "mi_fse_encode", "mi_fse_decode", "mi_fse_normalise_dev",
@@ -91,6 +92,12 @@ def lib():
         if hasattr(L, "mi_huffman_encode_dev"):
             L.mi_huffman_encode_dev.argtypes = [vp, vp, u64, vp, u64, vp, vp, vp, vp]
             L.mi_huffman_encode.argtypes = [vp, vp, u64, vp, u64, C.POINTER(HuffmanInfo), C.POINTER(HuffmanTree)]
+        if hasattr(L, "mi_huffman_hist_dev"):
+            L.mi_huffman_num_tiles.restype = u64
+            L.mi_huffman_num_tiles.argtypes = [u64]
+            L.mi_huffman_hist_dev.argtypes = [vp, vp, u64, vp, vp, vp]
+            L.mi_huffman_build_dev.argtypes = [vp, vp, vp, vp, vp]
+            L.mi_huffman_encode_with_tree_dev.argtypes = [vp, vp, u64, vp, vp, C.c_uint32, vp, u64, vp, vp, vp]
         if hasattr(L, "mi_huffman_decode_dev"):
             L.mi_huffman_decode_dev.argtypes = [vp, vp, u64, vp, C.c_uint32, vp, vp, u64, vp]
         if hasattr(L, "mi_lz_encode_dev"):

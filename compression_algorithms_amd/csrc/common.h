@@ -42,6 +42,7 @@ struct mi_ctx {
     size_t      h_pinned_bytes = 0;
     // decoder status words: every decode call takes its own (round robin), so calls on different streams of one context
     // never share one (they used to share ws[0])
+    uint64_t   *lz_dbg = nullptr;      // phase counters of the LZ pipeline (MI_LZ_DEBUG=1), inside the workspace
     uint32_t   *d_err = nullptr;
     uint32_t    err_next = 0;
 #define MI_ERR_SLOTS 256

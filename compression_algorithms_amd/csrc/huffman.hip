@@ -12,6 +12,7 @@
 // HUFF_TILE input bytes = one workgroup; per-tile histograms (1 KiB each, 3 % of n) turn the
 // bit-offset computation into a dot product with the code lengths instead of a third pass.
 #include "common.h"
+#include <stddef.h>
 
 #define HUFF_TILE      32768u          // input bytes per workgroup
 #define HUFF_THREADS   256
@@ -23,7 +24,7 @@
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(HUFF_THREADS)
 void k_huff_hist(const uint8_t *__restrict__ in, uint64_t n, uint32_t *__restrict__ tile_hist,
-                 uint32_t *__restrict__ hist)
+                 uint32_t *__restrict__ hist, unsigned long long *__restrict__ hist64)
 {
     __shared__ uint32_t sh[HUFF_THREADS / MI_WAVE][256];
     const int tid = threadIdx.x, wave = tid >> 6;
@@ -52,7 +53,14 @@ void k_huff_hist(const uint8_t *__restrict__ in, uint64_t n, uint32_t *__restric
 #pragma unroll
     for (int w = 0; w < HUFF_THREADS / MI_WAVE; ++w) c += sh[w][tid];
     tile_hist[(uint64_t)blockIdx.x * 256 + tid] = c;
-    if (c) atomicAdd(&hist[tid], c);
+    if (c && hist) atomicAdd(&hist[tid], c);
+    if (c && hist64) atomicAdd(&hist64[tid], (unsigned long long)c);      // shard histograms are summed across GPUs in 64 bits
+}
+
+// u64 histogram (the all-reduced one of a sharded job) -> the reference's u32 counters, wrapping like huffman.c:184-187
+__global__ void k_huff_hist_narrow(const uint64_t *__restrict__ h64, uint32_t *__restrict__ h32)
+{
+    h32[threadIdx.x] = (uint32_t)h64[threadIdx.x];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -174,13 +182,16 @@ void k_huff_build(const uint32_t *__restrict__ hist, mi_huffman_tree *__restrict
 // bits of one tile = dot(tile histogram, code lengths); one wave per tile
 __global__ __launch_bounds__(256)
 void k_huff_tile_bits(const uint32_t *__restrict__ tile_hist, const uint8_t *__restrict__ len,
-                      uint64_t ntiles, uint64_t *__restrict__ tile_bits)
+                      uint64_t ntiles, uint64_t *__restrict__ tile_bits, uint32_t *__restrict__ uncovered)
 {
     const uint64_t tile = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (tile >= ntiles) return;
     const uint4 c = *reinterpret_cast<const uint4 *>(tile_hist + tile * 256 + lane * 4);
     const uint32_t l4 = *reinterpret_cast<const uint32_t *>(len + lane * 4);
+    // a byte that occurs but has no code: the tree was built for other data (only possible with a caller-supplied tree)
+    if (uncovered && ((c.x && !(l4 & 0xFF)) || (c.y && !((l4 >> 8) & 0xFF)) || (c.z && !((l4 >> 16) & 0xFF)) || (c.w && !(l4 >> 24))))
+        atomicOr(uncovered, 1u);
     uint64_t s = (uint64_t)c.x * (l4 & 0xFF) + (uint64_t)c.y * ((l4 >> 8) & 0xFF) +
                  (uint64_t)c.z * ((l4 >> 16) & 0xFF) + (uint64_t)c.w * (l4 >> 24);
 #pragma unroll
@@ -215,7 +226,7 @@ __device__ inline uint64_t block_exclusive_scan_u64(uint64_t v, uint64_t *total,
 }
 
 __global__ __launch_bounds__(1024)
-void k_scan_u64(const uint64_t *__restrict__ in, uint64_t n, uint64_t *__restrict__ out)
+void k_scan_u64(const uint64_t *__restrict__ in, uint64_t n, uint64_t *__restrict__ out, uint64_t base)
 {
     __shared__ uint64_t s_tmp[17];
     const uint64_t per = (n + 1023) / 1024;
@@ -223,15 +234,15 @@ void k_scan_u64(const uint64_t *__restrict__ in, uint64_t n, uint64_t *__restric
     uint64_t s = 0;
     for (uint64_t i = a; i < b; ++i) s += in[i];
     uint64_t total;
-    uint64_t run = block_exclusive_scan_u64(s, &total, s_tmp);
+    uint64_t run = base + block_exclusive_scan_u64(s, &total, s_tmp);
     for (uint64_t i = a; i < b; ++i) { uint64_t v = in[i]; out[i] = run; run += v; }
-    if (threadIdx.x == 0) out[n] = total;
+    if (threadIdx.x == 0) out[n] = base + total;
 }
 
 // finish the info struct and zero the words that neighbouring tiles share (they are OR-merged)
 __global__ __launch_bounds__(256)
 void k_huff_finish_info(const uint64_t *__restrict__ tile_off, uint64_t ntiles, uint32_t *__restrict__ words,
-                        uint64_t cap_words, mi_huffman_info *__restrict__ info)
+                        uint64_t cap_words, mi_huffman_info *__restrict__ info, const uint32_t *__restrict__ uncovered)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t total = tile_off[ntiles];
@@ -241,6 +252,7 @@ void k_huff_finish_info(const uint64_t *__restrict__ tile_off, uint64_t ntiles, 
         info->word_idx = total >> 5;
         info->bit_idx = total & 31;
         info->buffer_size = (total >> 5) * 4 + (total & 31) / 8 + (((total & 31) % 8) > 0);   // huffman.c:318-320
+        if (info->status == MI_OK && uncovered && *uncovered) info->status = MI_ERR_ARG;
         if (info->status == MI_OK && !fits) info->status = MI_ERR_CAPACITY;
     }
     if (i <= ntiles && fits) words[tile_off[i] >> 5] = 0;
@@ -357,7 +369,7 @@ extern "C" mi_status mi_huffman_encode_dev(mi_ctx *ctx, const uint8_t *d_in, uin
     MI_HIP(ctx, hipMemsetAsync(hist, 0, 256 * 4, s));
     if (ntiles) {
         mi_prof_scope p(ctx, "k_huff_hist", s, n);
-        hipLaunchKernelGGL(k_huff_hist, dim3((unsigned)ntiles), dim3(HUFF_THREADS), 0, s, d_in, n, tile_hist, hist);
+        hipLaunchKernelGGL(k_huff_hist, dim3((unsigned)ntiles), dim3(HUFF_THREADS), 0, s, d_in, n, tile_hist, hist, (unsigned long long *)nullptr);
     }
     {
         mi_prof_scope p(ctx, "k_huff_build", s, 1024);
@@ -365,12 +377,97 @@ extern "C" mi_status mi_huffman_encode_dev(mi_ctx *ctx, const uint8_t *d_in, uin
     }
     if (ntiles) {
         mi_prof_scope p(ctx, "k_huff_tile_bits", s, ntiles * 1024);
-        hipLaunchKernelGGL(k_huff_tile_bits, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, s, tile_hist, len, ntiles, tile_bits);
+        hipLaunchKernelGGL(k_huff_tile_bits, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, s, tile_hist, len, ntiles, tile_bits, (uint32_t *)nullptr);
     }
-    hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, s, tile_bits, ntiles, tile_off);
+    hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, s, tile_bits, ntiles, tile_off, (uint64_t)0);
     if (d_tile_off) MI_HIP(ctx, hipMemcpyAsync(d_tile_off, tile_off, (ntiles + 1) * 8, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(k_huff_finish_info, dim3((unsigned)((ntiles + 1 + 255) / 256)), dim3(256), 0, s,
-                       tile_off, ntiles, d_words, cap_words, d_info);
+                       tile_off, ntiles, d_words, cap_words, d_info, (const uint32_t *)nullptr);
+    if (ntiles) {
+        mi_prof_scope p(ctx, "k_huff_encode", s, n + (n * 5) / 8);
+        hipLaunchKernelGGL(k_huff_encode, dim3((unsigned)ntiles), dim3(HUFF_THREADS), 0, s, d_in, n, code, len, tile_off,
+                           d_words, d_info);
+    }
+    MI_HIP(ctx, hipGetLastError());
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same encoder in three steps, for ONE tree over a buffer that is spread over several GPUs (SURVEY.md 8e,
+// "whole-buffer Huffman": huffman.c:179-215 builds one tree over the whole buffer, :267-328 packs with it):
+//   mi_huffman_hist_dev              shard -> u64[256] histogram (+ per-tile histograms the caller keeps)
+//   [the caller sums the histograms of all shards: one all-reduce of 2 KiB]
+//   mi_huffman_build_dev             summed histogram -> the reference's tree and codes (identical on every GPU)
+//   [bits of a shard = dot(its histogram, lengths); an all-gather of those gives every shard its global bit offset]
+//   mi_huffman_encode_with_tree_dev  shard -> words, the stream starting `bit_offset` (0..31) bits into d_words[0]
+// The shards' word ranges overlap by at most one word at each seam; OR-ing them there gives the single-GPU stream.
+// ---------------------------------------------------------------------------------------------
+extern "C" uint64_t mi_huffman_num_tiles(uint64_t n) { return huff_ntiles(n); }
+
+extern "C" mi_status mi_huffman_hist_dev(mi_ctx *ctx, const uint8_t *d_in, uint64_t n, uint64_t *d_hist,
+                                         uint32_t *d_tile_hist, void *stream)
+{
+    if (!ctx || !d_hist || (n && (!d_in || !d_tile_hist))) return MI_ERR_ARG;
+    if (((uintptr_t)d_in & 15) != 0 || ((uintptr_t)d_tile_hist & 15) != 0) return MI_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    MI_HIP(ctx, hipMemsetAsync(d_hist, 0, 256 * 8, s));
+    const uint64_t ntiles = huff_ntiles(n);
+    if (ntiles) {
+        mi_prof_scope p(ctx, "k_huff_hist", s, n);
+        hipLaunchKernelGGL(k_huff_hist, dim3((unsigned)ntiles), dim3(HUFF_THREADS), 0, s, d_in, n, d_tile_hist,
+                           (uint32_t *)nullptr, reinterpret_cast<unsigned long long *>(d_hist));
+    }
+    MI_HIP(ctx, hipGetLastError());
+    return MI_OK;
+}
+
+extern "C" mi_status mi_huffman_build_dev(mi_ctx *ctx, const uint64_t *d_hist, mi_huffman_info *d_info,
+                                          mi_huffman_tree *d_tree, void *stream)
+{
+    if (!ctx || !d_hist || !d_info || !d_tree) return MI_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    size_t need = 256 * 4 + 256 * 4 + 256 + 4096;
+    if (need > ctx->ws_bytes) { mi_status st = mi_ws_reserve(ctx, need); if (st) return st; }
+    mi_carver cv(ctx->ws);
+    uint32_t *hist = cv.take<uint32_t>(256);
+    uint32_t *code = cv.take<uint32_t>(256);
+    uint8_t  *len = cv.take<uint8_t>(256);
+    hipLaunchKernelGGL(k_huff_hist_narrow, dim3(1), dim3(256), 0, s, d_hist, hist);
+    {
+        mi_prof_scope p(ctx, "k_huff_build", s, 1024);
+        hipLaunchKernelGGL(k_huff_build, dim3(1), dim3(256), 0, s, hist, d_tree, d_info, code, len);
+    }
+    MI_HIP(ctx, hipGetLastError());
+    return MI_OK;
+}
+
+extern "C" mi_status mi_huffman_encode_with_tree_dev(mi_ctx *ctx, const uint8_t *d_in, uint64_t n, const mi_huffman_tree *d_tree,
+                                                     const uint32_t *d_tile_hist, uint32_t bit_offset, uint32_t *d_words,
+                                                     uint64_t cap_words, mi_huffman_info *d_info, uint64_t *d_tile_off, void *stream)
+{
+    if (!ctx || !d_words || !d_info || !d_tree || (n && (!d_in || !d_tile_hist)) || cap_words < 2 || bit_offset > 31) return MI_ERR_ARG;
+    if (((uintptr_t)d_in & 15) != 0 || ((uintptr_t)d_tile_hist & 15) != 0) return MI_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const uint64_t ntiles = huff_ntiles(n);
+    size_t need = (ntiles + 1) * 8 * 2 + 4096;
+    if (need > ctx->ws_bytes) { mi_status st = mi_ws_reserve(ctx, need); if (st) return st; }
+    mi_carver cv(ctx->ws);
+    uint64_t *tile_bits = cv.take<uint64_t>(ntiles + 1);
+    uint64_t *tile_off = cv.take<uint64_t>(ntiles + 2);
+    uint32_t *uncovered = cv.take<uint32_t>(4);
+    const uint32_t *code = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(d_tree) + offsetof(mi_huffman_tree, code));
+    const uint8_t *len = reinterpret_cast<const uint8_t *>(d_tree) + offsetof(mi_huffman_tree, length);
+    // the caller's info is rewritten for THIS shard: status OK, sizes of bit_offset + shard bits
+    MI_HIP(ctx, hipMemsetAsync(d_info, 0, sizeof(mi_huffman_info), s));
+    MI_HIP(ctx, hipMemsetAsync(uncovered, 0, 4, s));
+    if (ntiles) {
+        mi_prof_scope p(ctx, "k_huff_tile_bits", s, ntiles * 1024);
+        hipLaunchKernelGGL(k_huff_tile_bits, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, s, d_tile_hist, len, ntiles, tile_bits, uncovered);
+    }
+    hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, s, tile_bits, ntiles, tile_off, (uint64_t)bit_offset);
+    if (d_tile_off) MI_HIP(ctx, hipMemcpyAsync(d_tile_off, tile_off, (ntiles + 1) * 8, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_huff_finish_info, dim3((unsigned)((ntiles + 1 + 255) / 256)), dim3(256), 0, s,
+                       tile_off, ntiles, d_words, cap_words, d_info, uncovered);
     if (ntiles) {
         mi_prof_scope p(ctx, "k_huff_encode", s, n + (n * 5) / 8);
         hipLaunchKernelGGL(k_huff_encode, dim3((unsigned)ntiles), dim3(HUFF_THREADS), 0, s, d_in, n, code, len, tile_off,

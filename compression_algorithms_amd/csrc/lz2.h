@@ -31,10 +31,8 @@ static_assert(LZ2_CAP % LZ2_THREADS == 0, "entries per thread must be whole");
 #define LZ2_NCLASS    8u                    // class 7: 8..15 entries (a lane per cluster)
 #define LZ2_BIG_SMALL 1024u                 // boundary between the two wave-replay classes (1 vs 4 bitmap dwords per lane)
 // wave_min: clusters of at least this many entries are replayed by a whole wave (128, 256 or 512)
-// row_mode (default): 3: 128..255, 4: 256..511, 5: 512..1024 go to the quarter-wave replay k_lz2_row, 6 to k_lz2_big
-__host__ __device__ __forceinline__ uint32_t lz2_class_of(uint32_t cnt, uint32_t wave_min, uint32_t row_mode)
+__host__ __device__ __forceinline__ uint32_t lz2_class_of(uint32_t cnt, uint32_t wave_min)
 {
-    if (row_mode && cnt >= 128u) return cnt < 256u ? 3u : cnt < 512u ? 4u : cnt <= LZ2_BIG_SMALL ? 5u : 6u;
     // wave replay: 4 = 512..1024 entries and 5 = wave_min..511 share one launch that starts the long chains first
     if (cnt >= wave_min) return cnt > LZ2_BIG_SMALL ? 6u : cnt >= 512u ? 4u : 5u;
     return cnt < 16 ? 7u : cnt < 32 ? 0u : cnt < 64 ? 1u : cnt < 128 ? 2u : cnt < 256 ? 3u : 4u;
@@ -72,5 +70,4 @@ struct Lz2Scratch {
     uint32_t     *big_count;                         // [LZ2_NCLASS]
     uint64_t     *dbg;                               // phase cycle counters (MI_LZ_DEBUG=1), else NULL
     uint32_t      wave_min;                          // see lz2_class_of
-    uint32_t      row_mode;
 };

@@ -13,7 +13,6 @@
 //                     eight entries per load.
 //   k_lz2_big         one WAVE per exported cluster of >= 128 entries: occupancy bitmap in registers, first fit by
 //                     ballot + v_readlane, 6 bytes of LDS per entry; bound by scalar-instruction issue.
-//   k_lz2_row         the same by a 16-lane DPP row per cluster (opt-in, measured slower: lz2_carve).
 //   k_lz2_scatter     lists -> by-position array (test hook and fallback boundary).
 //
 // Replaces the same reference functions as lz_find.hip (hash / insert_hash_table / find,
@@ -141,7 +140,12 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     static_assert(3 * LZ2_MAXBIG * 4 + 2 * LZ2_MAXBIG * 2 <= sizeof(uint32_t) * LZ2_NWAVES * 256, "export lists must fit the radix counters");
 
     const int tid = threadIdx.x;
-    if (blockIdx.x >= *sc.work_count) return;           // the grid covers the worst case; the listed parts come first
+    // The grid covers the worst case (32 parts per block) and the listed parts come first; a surplus workgroup reads the
+    // count and leaves.  Measured (round 2, same box, 10^9 bytes): a persistent grid of 2 workgroups per CU pulling parts
+    // off a cursor made this kernel 30.3 -> 51 ms per GB on its own — the loop keeps every scratch pointer live across
+    // the whole body: 84 -> 176 VGPRs, one workgroup per CU instead of two (forced back to 128 VGPRs it spills) — and the
+    // hardware dispatcher already IS a dynamic scheduler: ~13 k empty workgroups per batch cost nothing measurable.
+    if (blockIdx.x >= *sc.work_count) return;
     const uint32_t item = sc.work[blockIdx.x];
     const uint32_t lb = item & 0xFFFFu, part = item >> 16;
     Lz2BlockMeta *mt = sc.meta + lb;
@@ -442,7 +446,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
             uint32_t it = 0;
             for (uint32_t q = tid; q < nbig; q += LZ2_THREADS, ++it) {
                 const uint32_t cnt = s_big[3 * q + 1] - s_big[3 * q];
-                const uint32_t cls = lz2_class_of(cnt, sc.wave_min, sc.row_mode);
+                const uint32_t cls = lz2_class_of(cnt, sc.wave_min);
                 my_rank[it] = atomicAdd(&s_cls[cls], 1u);
                 my_dst[it] = atomicAdd(&s_ent, LZ2_ALIGN8(cnt));        // every cluster starts on an 8-entry boundary
             }
@@ -472,7 +476,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
         uint32_t it = 0;
         for (uint32_t q = tid; q < nbig; q += LZ2_THREADS, ++it) {
             const uint32_t s = s_big[3 * q], e = s_big[3 * q + 1], cnt = e - s;
-            const uint32_t cls = lz2_class_of(cnt, sc.wave_min, sc.row_mode);
+            const uint32_t cls = lz2_class_of(cnt, sc.wave_min);
             const uint32_t dst = s_entbase + my_dst[it];
             s_big[3 * q + 2] = dst;
             Lz2BigDesc d;
@@ -538,143 +542,6 @@ void k_lz2_big(LzP P, Lz2Scratch sc, int large)
 }
 
 // =============================================================================================
-// quarter-wave-per-cluster replay (128 .. 1024 entries), opt-in with MI_LZ_ROW=1 (see lz2_carve for the numbers).
-// k_lz2_big spends a whole wave on one cluster and nearly all of its instructions are wave-uniform, i.e. SALU work —
-// and a CU issues ONE scalar instruction per cycle for all resident waves: ~90 CU-cycles per replayed entry.  Here a 16-lane DPP row owns a cluster: the
-// occupancy bitmap is spread over the row's registers (word q*16+l in register q of lane l), first-fit is a row
-// minimum by four row-rotate DPP steps, the current entry is broadcast inside the row by ds_bpermute.  Everything
-// is VALU / LDS work issued per SIMD, four clusters per wave advance in lockstep, and the scalar loop control is
-// shared by the four.
-// =============================================================================================
-__device__ __forceinline__ uint32_t row_min_u32(uint32_t v)
-{
-    // dpp_ctrl 0x120 + n = row_ror:n (rotate right inside each 16-lane row); after 8,4,2,1 every lane holds the row minimum
-    uint32_t t;
-    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xF, 0xF, false); v = t < v ? t : v;
-    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xF, 0xF, false); v = t < v ? t : v;
-    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x122, 0xF, 0xF, false); v = t < v ? t : v;
-    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x121, 0xF, 0xF, false); v = t < v ? t : v;
-    return v;
-}
-
-#define LZ2_ROW_ENTRIES 1024
-__global__ __launch_bounds__(64)
-void k_lz2_row(LzP P, Lz2Scratch sc)
-{
-    constexpr int LDS_ENTRIES = LZ2_ROW_ENTRIES;
-    constexpr int NWR = (LDS_ENTRIES + 511) / 512;        // bitmap registers per lane (16 lanes x 32 bits each)
-    __shared__ uint32_t s_occ[4][LDS_ENTRIES];            // slot -> word id | position << 16 of its occupant
-    __shared__ uint16_t s_slot[4][LDS_ENTRIES];           // entry -> slot (for its eviction)
-    const uint32_t lane = threadIdx.x, row = lane >> 4, lr = lane & 15u;
-    // ONE launch for the three size classes, longest chains first: a launch lasts as long as its longest cluster, and
-    // three launches in a row would add those tails up.  Workgroup -> (class, four clusters of that class).
-    const uint32_t n5 = sc.big_count[5], n4 = sc.big_count[4], n3 = sc.big_count[3];
-    const uint32_t g5 = (n5 + 3u) >> 2, g4 = (n4 + 3u) >> 2, g3 = (n3 + 3u) >> 2;
-    uint32_t wg = blockIdx.x, cls, ncl;
-    if (wg < g5) { cls = 5; ncl = n5; }
-    else if (wg < g5 + g4) { cls = 4; ncl = n4; wg -= g5; }
-    else if (wg < g5 + g4 + g3) { cls = 3; ncl = n3; wg -= g5 + g4; }
-    else return;
-    const uint32_t ci = wg * 4u + row;
-    Lz2BigDesc d;
-    d.block = 0; d.start = 0; d.count = 0; d.anom = ~0u; d.limit = ~0u;
-    if (ci < ncl) d = sc.desc[cls][ci];
-    const uint32_t n = d.count <= (uint32_t)LDS_ENTRIES ? d.count : 0u, W = 1u << P.wbits;
-    const uint16_t *bp = sc.bigpos + (size_t)d.block * LZ2_BIG_STRIDE + d.start;
-    const uint16_t *br = sc.bigrs + (size_t)d.block * LZ2_BIG_STRIDE + d.start;
-    const uint16_t *bi = sc.bigpid + (size_t)d.block * LZ2_BIG_STRIDE + d.start;
-    uint16_t *bc = sc.bigcand + (size_t)d.block * LZ2_BIG_STRIDE + d.start;
-    uint32_t *occ = s_occ[row];
-    uint16_t *slot = s_slot[row];
-    uint32_t w[NWR];
-#pragma unroll
-    for (int q = 0; q < NWR; ++q) w[q] = 0;
-    auto bitword = [&](uint32_t wi) -> uint32_t {         // bitmap word wi of this row (wi is row-uniform)
-        uint32_t sel = w[0];
-#pragma unroll
-        for (int q = 1; q < NWR; ++q) sel = ((wi >> 4) == (uint32_t)q) ? w[q] : sel;
-        return (uint32_t)__shfl((int)sel, (int)(wi & 15u), 16);
-    };
-    auto clear_slot = [&](uint32_t sl) {
-        const uint32_t wi = sl >> 5;
-        const uint32_t keep = ((wi & 15u) == lr) ? ~(1u << (sl & 31u)) : 0xFFFFFFFFu;
-#pragma unroll
-        for (int q = 0; q < NWR; ++q) w[q] &= ((wi >> 4) == (uint32_t)q) ? keep : 0xFFFFFFFFu;
-    };
-    // the oldest entry still in the table: its position is kept at hand so that the common "nothing to evict" test
-    // costs a compare, not an LDS round trip
-    uint32_t ev = 0, ev_pos = 0, ev_base = 0, out_acc = 0;
-    { const uint32_t q = lr; ev_pos = q < n ? bp[q] : 0u; }
-    uint32_t pe = (uint32_t)__shfl((int)ev_pos, 0, 16);
-    bool anom_pending = d.anom != ~0u;
-    const bool plain = d.anom == ~0u && d.limit == ~0u;     // not the cluster that covers bucket 0 / T
-    for (uint32_t i0 = 0; i0 < (uint32_t)LDS_ENTRIES; i0 += 16) {
-        if (__ballot(i0 < n) == 0ull) break;                // every cluster of this wave is done
-        const uint32_t ii = i0 + lr;
-        uint32_t c_a = 0, c_id = 0;
-        if (ii < n) { c_a = (uint32_t)bp[ii] | ((uint32_t)br[ii] << 16); c_id = bi[ii]; }
-        // the entry of step t + 1 is broadcast inside the row while step t runs (ds_bpermute latency off the chain)
-        uint32_t a_nx = (uint32_t)__shfl((int)c_a, 0, 16), id_nx = (uint32_t)__shfl((int)c_id, 0, 16);
-        for (uint32_t t = 0; t < 16; ++t) {
-            const uint32_t i = i0 + t;
-            if (__ballot(i < n) == 0ull) break;
-            const uint32_t a = a_nx, id = id_nx;
-            a_nx = (uint32_t)__shfl((int)c_a, (int)((t + 1u) & 15u), 16); id_nx = (uint32_t)__shfl((int)c_id, (int)((t + 1u) & 15u), 16);
-            if (i < n) {                                    // row-uniform from here on
-                const uint32_t p = a & 0xFFFFu, r = a >> 16;
-                while (ev < i && pe + W < p) {              // FIFO retirement (lz77.c:70-76)
-                    clear_slot(slot[ev]);                   // clears the bucket, whoever sits there
-                    ++ev;
-                    if ((ev & ~15u) != ev_base) { ev_base = ev & ~15u; const uint32_t q = ev_base + lr; ev_pos = q < n ? bp[q] : 0u; }
-                    pe = (uint32_t)__shfl((int)ev_pos, (int)(ev & 15u), 16);
-                }
-                if (anom_pending && p > W - 1u) { clear_slot(d.anom); anom_pending = false; }
-                uint32_t res = LZ_NONE16;
-                if (plain && ev == 0) {
-                    // nothing evicted yet: find() = the word's first occurrence = the word id (k_lz2_find, the sweep)
-                    if (id != p) res = id;
-                } else {
-                    const uint32_t h = occ[r];
-                    if ((bitword(r >> 5) >> (r & 31u)) & 1u) {
-                        if ((h & 0xFFFFu) == id) res = h >> 16;
-                        else {
-                            for (uint32_t b = r + 1;; ++b) {    // rare: the home holds another word
-                                if (b == d.limit && r < d.limit) break;
-                                if (!((bitword(b >> 5) >> (b & 31u)) & 1u)) break;
-                                const uint32_t o = occ[b];
-                                if ((o & 0xFFFFu) == id) { res = o >> 16; break; }
-                            }
-                        }
-                    }
-                }
-                // insert: first fit = row minimum over every lane's first zero at or after r (inside the cluster by the parking bound)
-                const uint32_t rw = r >> 5, lowmask = (1u << (r & 31u)) - 1u;
-                uint32_t best = 0xFFFFFFFFu;
-#pragma unroll
-                for (int q = 0; q < NWR; ++q) {
-                    const uint32_t wi = (uint32_t)q * 16u + lr;
-                    uint32_t v = w[q];
-                    if (wi < rw) v = 0xFFFFFFFFu; else if (wi == rw) v |= lowmask;
-                    const uint32_t c = (v != 0xFFFFFFFFu) ? (wi << 5) + (uint32_t)__builtin_ctz(~v) : 0xFFFFFFFFu;
-                    best = c < best ? c : best;
-                }
-                const uint32_t b = row_min_u32(best);
-                {
-                    const uint32_t wi = b >> 5;
-                    const uint32_t bit = ((wi & 15u) == lr) ? (1u << (b & 31u)) : 0u;
-#pragma unroll
-                    for (int q = 0; q < NWR; ++q) w[q] |= ((wi >> 4) == (uint32_t)q) ? bit : 0u;
-                }
-                if (lr == 0 && b < (uint32_t)LDS_ENTRIES) { occ[b] = id | (p << 16); slot[i] = (uint16_t)b; }
-                if (lr == t) out_acc = res;
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (ii < n) bc[ii] = (uint16_t)out_acc;
-    }
-}
-
-// =============================================================================================
 // lane-per-cluster replay of exported clusters of one size class [16,32) / [32,64) / [64,128):
 // 64 clusters per wave, every lane owns a private LDS region (slot -> word id, slot -> position,
 // entry -> slot, occupancy bits).  All lanes of a wave step through clusters of similar size.
@@ -706,8 +573,10 @@ void k_lz2_mid_direct(LzP P, Lz2Scratch sc, int cls)
     __shared__ uint32_t s_bits[LANES * (CMAX / 32 + 1)];
     const uint32_t lane = threadIdx.x;
     const uint32_t ncl = sc.big_count[cls];
-    const uint32_t ci = blockIdx.x * (uint32_t)LANES + lane;
-    if (blockIdx.x * (uint32_t)LANES >= ncl) return;
+    // persistent grid: a wave takes LANES clusters at a time until the class is done (a worst-case grid was 131 k
+    // workgroups for the 8..15 class, nearly all of them empty)
+    for (uint32_t wg = blockIdx.x; wg * (uint32_t)LANES < ncl; wg += gridDim.x) {
+    const uint32_t ci = wg * (uint32_t)LANES + lane;
     const bool active = ci < ncl && lane < (uint32_t)LANES;
     struct { uint32_t block, start, count, anom, limit; } d = {0u, 0u, 0u, ~0u, ~0u};
     if (active) { const Lz2BigDesc *dp = &sc.desc[cls][ci]; d.block = dp->block; d.start = dp->start; d.count = dp->count; d.anom = dp->anom; d.limit = dp->limit; }
@@ -775,6 +644,8 @@ void k_lz2_mid_direct(LzP P, Lz2Scratch sc, int cls)
         }
         if (i0 < n) vc[i0 >> 3] = make_uint4(o0, o1, o2, o3);      // pads of the last group: 0 (= skipped, lz2.h)
     }
+    __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // lists -> by-position array (test hook mi_lz_find_all_dev and the fallback boundary)
@@ -834,19 +705,22 @@ void lz2_carve(mi_carver &cv, uint32_t nb, Lz2Scratch *sc)
     sc->work = cv.take<uint32_t>((size_t)nb * LZ2_MAXPARTS);
     sc->dbg = getenv("MI_LZ_DEBUG") ? cv.take<uint64_t>(32) : nullptr;
     sc->wave_min = LZ2_WAVE;
-    // quarter-wave replay of 128..1024-entry clusters (k_lz2_row) is OPT-IN: alone it is no faster than k_lz2_big
-    // (19.6 vs 16.7 ms / GB: 24 KiB of LDS per wave leaves 6 waves per CU and every instruction of a wave costs >= 4
-    // cycles of latency), and beside k_lz2_find — which needs all of a CU's LDS for its two workgroups — that LDS
-    // footprint costs the pipeline 4 % (10.74 vs 11.24 GB/s, same box).  Kept for the measurement.
-    sc->row_mode = getenv("MI_LZ_ROW") ? 1u : 0u;
 }
 
-static uint64_t *g_dbg_ptr = nullptr;
-extern "C" int mi_lz_debug_counters(uint64_t *out32)
+static uint32_t lz2_env_u32(const char *name, uint32_t dflt)
 {
-    if (!g_dbg_ptr) return 0;
+    const char *e = getenv(name);
+    if (!e) return dflt;
+    const long v = atol(e);
+    return v >= 0 ? (uint32_t)v : dflt;
+}
+
+// phase cycle counters of the last LZ call of this context (MI_LZ_DEBUG=1; a development hook, not in the public header)
+extern "C" int mi_lz_debug_counters(mi_ctx *ctx, uint64_t *out32)
+{
+    if (!ctx || !ctx->lz_dbg) return 0;
     (void)hipDeviceSynchronize();
-    return hipMemcpy(out32, g_dbg_ptr, 32 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 1 : 0;
+    return hipMemcpy(out32, ctx->lz_dbg, 32 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 1 : 0;
 }
 
 void lz2_launch_partition(const uint8_t *d_in, uint64_t n, const LzP &P, const Lz2Scratch &sc, uint64_t block0, uint32_t nb, hipStream_t s);
@@ -856,7 +730,7 @@ mi_status lz2_stage_partition(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, ui
                               const Lz2Scratch &sc, hipStream_t s)
 {
     MI_HIP(ctx, hipMemsetAsync(sc.fallback_count, 0, 256, s));      // fallback_count and big_count[]
-    if (sc.dbg && g_dbg_ptr != sc.dbg) { g_dbg_ptr = sc.dbg; MI_HIP(ctx, hipMemsetAsync(sc.dbg, 0, 256, s)); }
+    if (sc.dbg && ctx->lz_dbg != sc.dbg) { ctx->lz_dbg = sc.dbg; MI_HIP(ctx, hipMemsetAsync(sc.dbg, 0, 256, s)); }
     mi_prof_scope p(ctx, "k_lz2_partition", s, (uint64_t)nb * P.block);
     lz2_launch_partition(d_in, n, P, sc, block0, nb, s);
     MI_HIP(ctx, hipGetLastError());
@@ -878,26 +752,30 @@ mi_status lz2_stage_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_
 // stage B: replay of the exported clusters (almost no LDS: runs beside the next batch's stage A)
 mi_status lz2_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &sc, hipStream_t s)
 {
-    // lane-per-cluster classes; grids cover the worst case, surplus workgroups read the class count and leave
+    // Replay grids cover the worst case and the kernels stride, so any grid is correct.  MI_LZ_REPLAY_WAVES=k caps them at
+    // k workgroups per CU (0 / unset = worst case).  Measured (round 2, same box): persistent grids sized by LDS (16 / 12 /
+    // 7 / 5 / 16 waves per CU) left the lane classes unchanged and made the wave replay 10.9 -> 15.8 ms per GB — a static
+    // stride deals a wave whatever chain lengths it draws, the hardware dispatcher hands the next cluster to the first
+    // wave that is free.
+    const uint32_t ncu = (uint32_t)ctx->num_cu;
+    auto grid_of = [&](uint64_t worst) -> uint32_t {
+        const uint64_t g = (uint64_t)ncu * lz2_env_u32("MI_LZ_REPLAY_WAVES", 0);             // 0 = the worst-case grid
+        return (uint32_t)((g == 0 || worst < g) ? (worst ? worst : 1) : g);
+    };
     { mi_prof_scope p(ctx, "k_lz2_mid<16>", s, (uint64_t)nb * P.block);
-      hipLaunchKernelGGL((k_lz2_mid_direct<16, 64>), dim3(nb * lz2_class_cap(7) / 64 + 1), dim3(64), 0, s, P, sc, 7); }
+      hipLaunchKernelGGL((k_lz2_mid_direct<16, 64>), dim3(grid_of((uint64_t)nb * lz2_class_cap(7) / 64 + 1)), dim3(64), 0, s, P, sc, 7); }
     { mi_prof_scope p(ctx, "k_lz2_mid<32>", s, (uint64_t)nb * P.block);
-      hipLaunchKernelGGL((k_lz2_mid_direct<32, 64>), dim3(nb * lz2_class_cap(0) / 64 + 1), dim3(64), 0, s, P, sc, 0); }
+      hipLaunchKernelGGL((k_lz2_mid_direct<32, 64>), dim3(grid_of((uint64_t)nb * lz2_class_cap(0) / 64 + 1)), dim3(64), 0, s, P, sc, 0); }
     { mi_prof_scope p(ctx, "k_lz2_mid<64>", s, (uint64_t)nb * P.block);
-      hipLaunchKernelGGL((k_lz2_mid_direct<64, 64>), dim3(nb * lz2_class_cap(1) / 64 + 1), dim3(64), 0, s, P, sc, 1); }
+      hipLaunchKernelGGL((k_lz2_mid_direct<64, 64>), dim3(grid_of((uint64_t)nb * lz2_class_cap(1) / 64 + 1)), dim3(64), 0, s, P, sc, 1); }
     { mi_prof_scope p(ctx, "k_lz2_mid<128>", s, (uint64_t)nb * P.block);
       // 48 clusters per wave: 31 KiB of LDS instead of 42, five waves per CU instead of three (240 replaying lanes, not 192)
-      hipLaunchKernelGGL((k_lz2_mid_direct<128, 48>), dim3(nb * lz2_class_cap(2) / 48 + 1), dim3(64), 0, s, P, sc, 2); }
-    if (sc.row_mode) {
-        mi_prof_scope p(ctx, "k_lz2_row", s, (uint64_t)nb * P.block);
-        hipLaunchKernelGGL(k_lz2_row, dim3(nb * (lz2_class_cap(5) + lz2_class_cap(4) + lz2_class_cap(3)) / 4 + 3), dim3(64), 0, s, P, sc);
-        hipLaunchKernelGGL((k_lz2_big<LZ2_CAP, 4>), dim3(nb * lz2_class_cap(6) < 4096 ? nb * lz2_class_cap(6) : 4096), dim3(64), 0, s, P, sc, 1);
-    } else {
-        { mi_prof_scope p(ctx, "k_lz2_big", s, (uint64_t)nb * P.block);
-          hipLaunchKernelGGL((k_lz2_big<LZ2_BIG_SMALL, 1>), dim3(nb * (lz2_class_cap(4) + lz2_class_cap(5))), dim3(64), 0, s, P, sc, 0); }
-        { mi_prof_scope p(ctx, "k_lz2_big<4096>", s, (uint64_t)nb * P.block);
-          hipLaunchKernelGGL((k_lz2_big<LZ2_CAP, 4>), dim3(nb * lz2_class_cap(6) < 4096 ? nb * lz2_class_cap(6) : 4096), dim3(64), 0, s, P, sc, 1); }
-    }
+      hipLaunchKernelGGL((k_lz2_mid_direct<128, 48>), dim3(grid_of((uint64_t)nb * lz2_class_cap(2) / 48 + 1)), dim3(64), 0, s, P, sc, 2); }
+    { mi_prof_scope p(ctx, "k_lz2_big", s, (uint64_t)nb * P.block);
+      // the kernel strides over the two wave classes (long chains first); 6 KiB per wave
+      hipLaunchKernelGGL((k_lz2_big<LZ2_BIG_SMALL, 1>), dim3(grid_of((uint64_t)nb * (lz2_class_cap(4) + lz2_class_cap(5)))), dim3(64), 0, s, P, sc, 0); }
+    { mi_prof_scope p(ctx, "k_lz2_big<4096>", s, (uint64_t)nb * P.block);
+      hipLaunchKernelGGL((k_lz2_big<LZ2_CAP, 4>), dim3(grid_of((uint64_t)nb * lz2_class_cap(6) < 4096 ? (uint64_t)nb * lz2_class_cap(6) : 4096)), dim3(64), 0, s, P, sc, 1); }   // 24 KiB each, normally none: a small striding grid
     MI_HIP(ctx, hipGetLastError());
     return MI_OK;
 }

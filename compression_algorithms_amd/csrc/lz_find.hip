@@ -547,9 +547,14 @@ mi_status lz_find_stage_a(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64
     if (!lz_use_v2()) return lz_find_batch(ctx, P, d_in, n, block0, nb, sc, s, nullptr, nullptr);
     mi_status st = lz2_stage_partition(ctx, P, d_in, n, block0, nb, sc2, s);
     if (st) return st;
-    if (sf != s) { MI_HIP(ctx, hipEventRecord(ev_part, s)); MI_HIP(ctx, hipStreamWaitEvent(sf, ev_part, 0)); }
-    st = lz_find_batch(ctx, P, d_in, n, block0, nb, sc, sf, sc2.fallback_list, sc2.fallback_count);
-    if (st) return st;
+    // MI_LZ_UNSAFE_NO_FALLBACK=1 (measurement only: wrong output for any block the partition hands back) leaves the
+    // fallback chain out, to price its normally empty launches
+    static const bool no_fb = getenv("MI_LZ_UNSAFE_NO_FALLBACK") != nullptr;
+    if (!no_fb) {
+        if (sf != s) { MI_HIP(ctx, hipEventRecord(ev_part, s)); MI_HIP(ctx, hipStreamWaitEvent(sf, ev_part, 0)); }
+        st = lz_find_batch(ctx, P, d_in, n, block0, nb, sc, sf, sc2.fallback_list, sc2.fallback_count);
+        if (st) return st;
+    }
     if (sf != s) MI_HIP(ctx, hipEventRecord(ev_fb, sf));
     return lz2_stage_find(ctx, P, d_in, n, block0, nb, sc2, s);
 }

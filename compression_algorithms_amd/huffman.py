@@ -84,3 +84,62 @@ def huffman_decompress(result, use_tiles=True, ctx=None):
                                      C.c_void_p(out.data_ptr()), result.n, ctx.stream_ptr())
     _lib.check(st, "mi_huffman_decode_dev")
     return out[: result.n]
+
+
+class HipShardEngine:
+    """The three-step encoder of include/mi_codec.h (mi_huffman_hist_dev / _build_dev / _encode_with_tree_dev) as the
+    per-rank engine of sharded.huffman_compress: one tree over a buffer spread over several GPUs
+    (algorithms/huffman/huffman.c:179-215 builds it over the WHOLE buffer, :267-328 packs with it)."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or default_context()
+
+    def hist(self, shard):
+        """-> (int64[256] device tensor, state for encode())"""
+        ctx = self.ctx
+        d_in = as_device_bytes(shard, ctx.device)
+        n = d_in.numel()
+        ntiles = int(ctx.L.mi_huffman_num_tiles(n))
+        h = torch.zeros(256, dtype=torch.int64, device=ctx.device)
+        tile_hist = torch.empty(max(ntiles, 1) * 256, dtype=torch.int32, device=ctx.device)
+        st = ctx.L.mi_huffman_hist_dev(ctx.h, C.c_void_p(d_in.data_ptr() if n else 0), n, C.c_void_p(h.data_ptr()),
+                                       C.c_void_p(tile_hist.data_ptr()), ctx.stream_ptr())
+        _lib.check(st, "mi_huffman_hist_dev")
+        return h, dict(d_in=d_in, n=n, ntiles=ntiles, tile_hist=tile_hist)
+
+    def build(self, hist):
+        """summed histogram -> dict(d_tree, info, tree, lengths int64 device tensor); raises MiError like huffman_compress"""
+        ctx = self.ctx
+        d_info = torch.zeros(C.sizeof(_lib.HuffmanInfo), dtype=torch.uint8, device=ctx.device)
+        d_tree = torch.zeros(C.sizeof(_lib.HuffmanTree), dtype=torch.uint8, device=ctx.device)
+        st = ctx.L.mi_huffman_build_dev(ctx.h, C.c_void_p(hist.data_ptr()), C.c_void_p(d_info.data_ptr()),
+                                        C.c_void_p(d_tree.data_ptr()), ctx.stream_ptr())
+        _lib.check(st, "mi_huffman_build_dev")
+        info = _lib.HuffmanInfo.from_buffer_copy(d_info.cpu().numpy().tobytes())
+        if info.status != _lib.MI_OK:
+            raise _lib.MiError(info.status, "huffman_compress (sharded)")
+        tree = _lib.HuffmanTree.from_buffer_copy(d_tree.cpu().numpy().tobytes())
+        off = _lib.HuffmanTree.length.offset
+        lengths = d_tree[off:off + 256].to(torch.int64)
+        return dict(d_tree=d_tree, info=info, tree=tree, lengths=lengths)
+
+    def shard_bits(self, hist, tree):
+        return int((hist * tree["lengths"]).sum().item())
+
+    def encode(self, state, tree, bit_offset, nbits):
+        """-> (int32 device tensor of ceil((bit_offset + nbits) / 32) words, int64 tile offsets relative to word 0)"""
+        ctx = self.ctx
+        nw = (bit_offset + nbits + 31) // 32
+        words = torch.zeros(nw + 2, dtype=torch.int32, device=ctx.device)
+        d_info = torch.zeros(C.sizeof(_lib.HuffmanInfo), dtype=torch.uint8, device=ctx.device)
+        tile_off = torch.zeros(state["ntiles"] + 1, dtype=torch.int64, device=ctx.device)
+        st = ctx.L.mi_huffman_encode_with_tree_dev(ctx.h, C.c_void_p(state["d_in"].data_ptr() if state["n"] else 0), state["n"],
+                                                   C.c_void_p(tree["d_tree"].data_ptr()), C.c_void_p(state["tile_hist"].data_ptr()),
+                                                   bit_offset, C.c_void_p(words.data_ptr()), nw + 2, C.c_void_p(d_info.data_ptr()),
+                                                   C.c_void_p(tile_off.data_ptr()), ctx.stream_ptr())
+        _lib.check(st, "mi_huffman_encode_with_tree_dev")
+        info = _lib.HuffmanInfo.from_buffer_copy(d_info.cpu().numpy().tobytes())
+        if info.status != _lib.MI_OK:
+            raise _lib.MiError(info.status, "mi_huffman_encode_with_tree_dev")
+        assert info.total_bits == bit_offset + nbits, (info.total_bits, bit_offset, nbits)
+        return words[:nw], tile_off

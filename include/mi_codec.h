@@ -118,6 +118,25 @@ mi_status mi_huffman_decode(mi_ctx *ctx, const uint32_t *h_words, uint64_t total
 mi_status mi_huffman_encode2(mi_ctx *ctx, const uint8_t *h_in, uint64_t n, uint32_t *h_words, uint64_t cap_words,
                              mi_huffman_info *h_info, mi_huffman_tree *h_tree, uint64_t *h_tile_off);
 
+/* The same encoder in three steps, for ONE tree over a buffer spread over several GPUs (whole-buffer parity across
+ * ranks: huffman.c:179-215 builds one tree over the whole buffer, :267-328 packs with it).  Per rank:
+ *   mi_huffman_hist_dev   shard -> d_hist u64[256] (+ d_tile_hist u32[mi_huffman_num_tiles(n)][256], kept by the caller)
+ *   -- all-reduce (sum) of d_hist over the ranks: 2 KiB --
+ *   mi_huffman_build_dev  summed histogram (taken modulo 2^32 like the reference's u32 counters) -> tree, codes, status
+ *   -- bits of a shard = sum(hist[s] * length[s]); an all-gather of those gives every shard its global bit offset --
+ *   mi_huffman_encode_with_tree_dev  shard -> words; the stream starts bit_offset (= global offset mod 32) bits into
+ *                         d_words[0]; d_info->total_bits = bit_offset + the shard's bits; d_tile_off (optional)
+ *                         are offsets relative to d_words[0].  MI_ERR_ARG in d_info->status if the shard holds a
+ *                         byte the tree has no code for.
+ * Shard word ranges overlap by one word at a seam; OR-ing them there yields the single-GPU stream bit for bit
+ * (compression_algorithms_amd/sharded.py does the exchange over torch.distributed / RCCL). */
+uint64_t  mi_huffman_num_tiles(uint64_t n);
+mi_status mi_huffman_hist_dev(mi_ctx *ctx, const uint8_t *d_in, uint64_t n, uint64_t *d_hist, uint32_t *d_tile_hist, void *stream);
+mi_status mi_huffman_build_dev(mi_ctx *ctx, const uint64_t *d_hist, mi_huffman_info *d_info, mi_huffman_tree *d_tree, void *stream);
+mi_status mi_huffman_encode_with_tree_dev(mi_ctx *ctx, const uint8_t *d_in, uint64_t n, const mi_huffman_tree *d_tree,
+                                          const uint32_t *d_tile_hist, uint32_t bit_offset, uint32_t *d_words, uint64_t cap_words,
+                                          mi_huffman_info *d_info, uint64_t *d_tile_off, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * LZ77 greedy tokenisers, block-parallel.
  *   deflate flavour: algorithms/deflate/lz77.c:199-280 per block of `block` bytes with a

@@ -61,6 +61,10 @@ def lib():
         L.orc_huff_buffer_size.argtypes = [C.c_uint64]
         L.orc_huff_decode.restype = C.c_uint64
         L.orc_huff_decode.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
+        L.orc_huff_codes_from_freq.restype = C.c_int
+        L.orc_huff_codes_from_freq.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_huff_pack.restype = C.c_uint64
+        L.orc_huff_pack.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.orc_huff_preorder.restype = C.c_int
         L.orc_huff_preorder.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_fse_normalise.restype = C.c_int
@@ -225,6 +229,26 @@ def huff_encode(data):
     nw = (bits + 31) // 32
     return dict(words=words[:nw].copy(), bits=int(bits), word_idx=int(bits // 32), bit_idx=int(bits % 32),
                 buffer_size=int(lib().orc_huff_buffer_size(bits)), codes=codes, lens=lens)
+
+
+def huff_codes_from_freq(freq):
+    """codes/lengths the reference derives from a histogram (u32, wrapping) -> (codes u32[256], lens u8[256]) or None"""
+    f = np.ascontiguousarray(np.asarray(freq, dtype=np.uint64) & 0xFFFFFFFF, dtype=np.uint32)
+    codes = np.zeros(256, dtype=np.uint32)
+    lens = np.zeros(256, dtype=np.uint8)
+    if lib().orc_huff_codes_from_freq(_p(f), _p(codes), _p(lens)) < 0:
+        return None
+    return codes, lens
+
+
+def huff_pack(data, codes, lens, bit_offset=0):
+    """pack `data` with given codes, the stream starting bit_offset bits into word 0 -> (words u32[], end bit)"""
+    src = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8)) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data)
+    bits = int(np.asarray(lens, np.uint64)[src].sum())
+    words = np.zeros((bit_offset + bits + 31) // 32 + 1, dtype=np.uint32)
+    end = lib().orc_huff_pack(_p(src), len(src), _p(np.ascontiguousarray(codes, np.uint32)),
+                              _p(np.ascontiguousarray(lens, np.uint8)), bit_offset, _p(words))
+    return words[: (end + 31) // 32].copy(), int(end)
 
 
 def huff_decode(words, bits, freq, n):

@@ -183,3 +183,29 @@ int orc_huff_preorder(const uint32_t freq[256], uint8_t *kinds, uint8_t *values,
     }
     return k;
 }
+
+/* ---- pieces of the same coder, for the sharded (multi-GPU) parity tests: codes from a given histogram
+ * (huffman.c:189-250 on the SUMMED counts) and packing a shard with given codes from a bit offset
+ * (huffman.c:18-48 continued mid-word). */
+int orc_huff_codes_from_freq(const uint32_t freq[256], uint32_t codes[256], uint8_t lens[256])
+{
+    orc_huff_tree t;
+    uint64_t code[256];
+    int nsym = orc_huff_build(freq, &t);
+    int maxlen = orc_huff_codes(&t, code, lens);
+    for (int s = 0; s < 256; ++s) codes[s] = (uint32_t)code[s];
+    return (nsym < 2 || maxlen > 32) ? -1 : maxlen;
+}
+
+/* words: zeroed, >= ceil((bit_offset + bits)/32) + 1 entries; returns bit_offset + bits */
+uint64_t orc_huff_pack(const uint8_t *in, uint64_t n, const uint32_t codes[256], const uint8_t lens[256],
+                       uint64_t bit_offset, uint32_t *words)
+{
+    uint64_t bit = bit_offset;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t c = codes[in[i]]; unsigned l = lens[in[i]];
+        for (unsigned k = 0; k < l; ++k, ++bit)
+            if ((c >> (l - 1 - k)) & 1) words[bit >> 5] |= 1u << (31 - (bit & 31));
+    }
+    return bit;
+}

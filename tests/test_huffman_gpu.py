@@ -93,3 +93,57 @@ def test_full_size_properties(hf):
     w = r1.words[: (8 * 1_000_000) // 32 + 64].cpu().numpy().view(np.uint32)
     head = orc.huff_decode(w, len(w) * 32, hist.astype(np.uint32), 1_000_000)
     assert np.array_equal(head, x[:1_000_000].cpu().numpy())
+
+
+@pytest.mark.parametrize("cuts", [(0, 65536 * 2, 65536 * 3 + 32768), (0, 32768), (0,)])
+def test_three_step_encoder_equals_one_pass(cuts):
+    """mi_huffman_hist_dev / _build_dev / _encode_with_tree_dev (the per-rank engine of sharded.huffman_compress): shards of
+    one buffer, histograms summed, one tree, every shard packed from its global bit offset, seam words OR-merged — must
+    equal the single-call encoder and the oracle's whole-buffer stream, and decode with the merged tile table."""
+    import torch
+    from oracle import orc
+    from compression_algorithms_amd import huffman
+    from compression_algorithms_amd.context import default_context
+    ctx = default_context()
+    data = synth.enwik_like(300_000, seed=21).numpy()
+    bounds = list(cuts) + [len(data)]
+    eng = huffman.HipShardEngine(ctx)
+    hs, states = [], []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        h, st = eng.hist(data[a:b])
+        assert np.array_equal(h.cpu().numpy(), np.bincount(data[a:b], minlength=256))
+        hs.append(h); states.append(st)
+    tree = eng.build(torch.stack(hs).sum(0))
+    want = orc.huff_encode(data)
+    assert np.array_equal(np.ctypeslib.as_array(tree["tree"].code), want["codes"])
+    assert np.array_equal(np.ctypeslib.as_array(tree["tree"].length), want["lens"])
+    start, out = 0, torch.zeros((want["bits"] + 31) // 32 + 1, dtype=torch.int32, device=ctx.device)
+    tiles = []
+    for h, st in zip(hs, states):
+        nb = eng.shard_bits(h, tree)
+        w, toff = eng.encode(st, tree, start % 32, nb)
+        out[start // 32: start // 32 + w.numel()] |= w
+        tiles.append(toff[:-1] + (start // 32) * 32)
+        start += nb
+    assert start == want["bits"]
+    assert np.array_equal(out[:-1].cpu().numpy().view(np.uint32), want["words"])
+    one = huffman.huffman_compress(data)
+    assert one.total_bits == start and np.array_equal(one.words.cpu().numpy(), out[:-1].cpu().numpy())
+    tile_table = torch.cat(tiles + [torch.tensor([start], dtype=torch.int64, device=ctx.device)])
+    assert np.array_equal(tile_table.cpu().numpy(), one.tile_off.cpu().numpy())
+    one._words_padded, one.tile_off = out, tile_table
+    assert np.array_equal(huffman.huffman_decompress(one).cpu().numpy(), data)
+
+
+def test_encode_with_foreign_tree_is_refused():
+    """a shard that holds a byte the tree has no code for: status MI_ERR_ARG, not a silently short stream"""
+    from compression_algorithms_amd import huffman, _lib
+    eng = huffman.HipShardEngine()
+    a = np.frombuffer(b"abababbbabab" * 4000, dtype=np.uint8)
+    b = np.frombuffer(b"abcabc" * 8000, dtype=np.uint8)
+    ha, _ = eng.hist(a)
+    tree = eng.build(ha)
+    hb, stb = eng.hist(b)
+    with pytest.raises(_lib.MiError) as e:
+        eng.encode(stb, tree, 0, eng.shard_bits(hb, tree))
+    assert e.value.status == 1
