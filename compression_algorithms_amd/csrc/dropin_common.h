@@ -28,7 +28,7 @@ typedef struct { const void *key; uint64_t bits, n, aux, count; uint64_t *table;
 static dropin_side g_side[DROPIN_SIDE_SLOTS];
 static unsigned g_side_next;
 
-static void dropin_side_put(const void *key, uint64_t bits, uint64_t n, uint64_t aux, const uint64_t *table, uint64_t count)
+__attribute__((unused)) static void dropin_side_put(const void *key, uint64_t bits, uint64_t n, uint64_t aux, const uint64_t *table, uint64_t count)
 {
     dropin_side *e = NULL;
     for (unsigned i = 0; i < DROPIN_SIDE_SLOTS; ++i) if (g_side[i].key == key) { e = &g_side[i]; break; }
@@ -40,7 +40,7 @@ static void dropin_side_put(const void *key, uint64_t bits, uint64_t n, uint64_t
     e->key = key; e->bits = bits; e->n = n; e->aux = aux; e->count = count;
 }
 
-static const dropin_side *dropin_side_get(const void *key, uint64_t bits, uint64_t n)
+__attribute__((unused)) static const dropin_side *dropin_side_get(const void *key, uint64_t bits, uint64_t n)
 {
     for (unsigned i = 0; i < DROPIN_SIDE_SLOTS; ++i)
         if (g_side[i].key == key && g_side[i].table && g_side[i].bits == bits && g_side[i].n == n) return &g_side[i];

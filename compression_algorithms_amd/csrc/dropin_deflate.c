@@ -2,6 +2,7 @@
 #include <string.h>
 #include <time.h>
 #include "../../include/mi_deflate.h"
+#include "../../include/mi_frame.h"
 #include "dropin_common.h"
 
 static const char *extension = ".deflate";                      /* deflate.h:10 */
@@ -15,6 +16,38 @@ static char *slurp(const char *name, uint64_t *size)
     if (fread(b, 1, *size, f) != *size) { fprintf(stderr, "Error: short read on %s\n", name); exit(1); }
     fclose(f);
     return b;
+}
+
+uint64_t min(uint64_t a, uint64_t b) { return a < b ? a : b; }
+uint64_t max(uint64_t a, uint64_t b) { return a > b ? a : b; }
+
+uint32_t hash(uint32_t pattern)                                     /* deflate/lz77.c:14-42 */
+{
+    uint32_t k = pattern * 0xcc9e2d51u;
+    k = (k << 15) | (k >> 17);
+    k *= 0x1b873593u;
+    uint32_t h = (k << 13) | (k >> 19);
+    h = h * 5u + 0xe6546b64u;
+    h ^= h >> 16; h *= 0x85ebca6bu;
+    h ^= h >> 13; h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h % TABLE_SIZE;
+}
+
+void init_hash_table(HashTableArray *table)                         /* deflate/lz77.c:44-67 */
+{
+    table->buckets.patterns = (uint32_t *)calloc(TABLE_SIZE, sizeof(uint32_t));
+    table->buckets.indices = (uint64_t *)calloc(TABLE_SIZE, sizeof(uint64_t));
+    table->buckets.is_set = (bool *)calloc(TABLE_SIZE, sizeof(bool));
+    memset(table->bucket_indices, 0, sizeof table->bucket_indices);
+    table->current_idx = 0;
+    table->is_full = false;
+}
+
+void write_literal(char *buffer, char c, uint64_t *at) { buffer[(*at)++] = 0; buffer[(*at)++] = c; }          /* deflate/lz77.c:176-184 */
+void write_length_distance(char *buffer, uint8_t length, uint16_t distance, uint64_t *at)              /* deflate/lz77.c:186-197 */
+{
+    buffer[(*at)++] = 1; buffer[(*at)++] = (char)(distance & 0xFF); buffer[(*at)++] = (char)(distance >> 8); buffer[(*at)++] = (char)length;
 }
 
 StateData compress(const char *input_filename)
@@ -38,14 +71,30 @@ StateData compress(const char *input_filename)
                           : mi_lz_encode(ctx, &p, (const uint8_t *)in, n, out, cap, bits);
     clock_gettime(CLOCK_MONOTONIC, &t1);
     if (st != MI_OK) { fprintf(stderr, "compress: %s\n", mi_status_str(st)); exit(1); }
+    /* Mode T keeps the reference's file byte for byte (the bare token concatenation of deflate.c:56) and puts what a
+     * decoder needs into a side-car.  Mode H is this build's own stream, so it is written self-describing (mi_frame.h:
+     * {last_block, size} + record per block) with no side-car; MI_DEFLATE_FRAMED=1 frames mode T the same way. */
+    const char *fr = getenv("MI_DEFLATE_FRAMED");
+    const int framed = mode_h || (fr && fr[0] == '1');
     FILE *f = fopen(sd.compressed_filename, "wb");
     if (!f) { fprintf(stderr, "Error: could not open file %s\n", sd.compressed_filename); exit(1); }   /* deflate.c:30-34 */
-    fwrite(out, 1, bits[nblocks] / 8, f); fclose(f);
     char *idx = (char *)malloc(strlen(sd.compressed_filename) + 5);
     strcpy(idx, sd.compressed_filename); strcat(idx, ".idx");
-    f = fopen(idx, "wb");
-    /* side-car: original size, block size | mode H flag << 32, block count, then the per-block bit offsets */
-    if (f) { uint64_t hdr[3] = { n, p.block | ((uint64_t)mode_h << 32), nblocks }; fwrite(hdr, 8, 3, f); fwrite(bits, 8, nblocks + 1, f); fclose(f); }
+    if (framed) {
+        const uint64_t fcap = mi_frame_bound_blocks(nblocks, bits[nblocks] / 8);
+        uint8_t *frame = (uint8_t *)malloc(fcap); uint64_t fn = 0;
+        if (!frame) { fprintf(stderr, "compress: out of memory\n"); exit(1); }
+        st = mi_frame_pack_blocks(mode_h ? MI_FRAME_DEFLATE_H : MI_FRAME_DEFLATE_T, p.block, p.wbits, p.lbits, n, out, bits, nblocks, frame, fcap, &fn);
+        if (st != MI_OK) { fprintf(stderr, "compress: %s\n", mi_status_str(st)); exit(1); }
+        fwrite(frame, 1, fn, f); fclose(f);
+        free(frame);
+        remove(idx);                                            /* a stale side-car of an earlier mode-T run must not shadow the frame */
+    } else {
+        fwrite(out, 1, bits[nblocks] / 8, f); fclose(f);
+        f = fopen(idx, "wb");
+        /* side-car: original size, block size | mode H flag << 32, block count, then the per-block bit offsets */
+        if (f) { uint64_t hdr[3] = { n, p.block | ((uint64_t)mode_h << 32), nblocks }; fwrite(hdr, 8, 3, f); fwrite(bits, 8, nblocks + 1, f); fclose(f); }
+    }
     const double sec = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
     printf("MB/s: %f\n", (double)n / (1024 * 1024) / sec);     /* deflate.c:65 */
     free(idx); free(in); free(out); free(bits);
@@ -55,33 +104,51 @@ StateData compress(const char *input_filename)
 void decompress(StateData *sd, const char *input_filename)
 {
     const char *name = (sd && sd->compressed_filename) ? sd->compressed_filename : input_filename;
+    uint64_t csz; char *cb = slurp(name, &csz);
+    uint8_t *out = NULL; uint64_t n = 0;
+    mi_status st;
+    if (csz >= 4 && memcmp(cb, MI_FRAME_MAGIC, 4) == 0) {
+        /* a framed, self-describing file (mode H, or MI_DEFLATE_FRAMED=1): no side-car */
+        mi_frame_info fi;
+        st = mi_frame_parse((const uint8_t *)cb, csz, &fi);
+        if (st != MI_OK || (fi.codec != MI_FRAME_DEFLATE_H && fi.codec != MI_FRAME_DEFLATE_T)) { fprintf(stderr, "decompress: %s is not a deflate frame\n", name); exit(1); }
+        uint8_t *stream = (uint8_t *)malloc(fi.stream_bytes + 8); uint64_t *t = (uint64_t *)malloc(8 * (fi.nblocks + 1));
+        n = fi.original_size; out = (uint8_t *)malloc(n ? n : 1);
+        if (!stream || !t || !out) { fprintf(stderr, "decompress: out of memory\n"); exit(1); }
+        st = mi_frame_unpack_blocks((const uint8_t *)cb, csz, stream, fi.stream_bytes + 8, t, fi.nblocks + 1);
+        mi_lz_params p = mi_lz_params_deflate(); p.block = fi.block; p.wbits = fi.p0; p.lbits = fi.p1;
+        if (st == MI_OK) st = fi.codec == MI_FRAME_DEFLATE_H ? mi_deflate_h_decode(dropin_ctx(), &p, stream, fi.stream_bytes, t, out, n)
+                                                             : mi_lz_decode(dropin_ctx(), &p, stream, fi.stream_bytes, t, out, n);
+        free(stream); free(t);
+    } else {
     char *idx = (char *)malloc(strlen(name) + 5); strcpy(idx, name); strcat(idx, ".idx");
     uint64_t isz; char *ib = slurp(idx, &isz);
     /* the side-car is a file: nothing in it is trusted before it is checked against its own size and the stream's */
     if (isz < 24) { fprintf(stderr, "decompress: %s is truncated\n", idx); exit(1); }
     const uint64_t *h = (const uint64_t *)ib;
-    const uint64_t n = h[0], nblocks = h[2];
+    const uint64_t nblocks = h[2];
+    n = h[0];
     const uint32_t block = (uint32_t)h[1];
     const int mode_h = (int)((h[1] >> 32) & 1u);
     if (block < 1 || block > BUFFER_SIZE || (h[1] >> 33) || nblocks != (n + block - 1) / block ||
         nblocks > (isz - 24) / 8 || isz < 24 + 8 * (nblocks + 1)) {
         fprintf(stderr, "decompress: %s is corrupt or truncated\n", idx); exit(1);
     }
-    uint64_t csz; char *cb = slurp(name, &csz);
     mi_lz_params p = mi_lz_params_deflate(); p.block = block;
     if (mi_validate_block_table(h + 3, nblocks, csz, mode_h ? 32u : 8u) != MI_OK) {
         fprintf(stderr, "decompress: the block table of %s does not fit %s\n", idx, name); exit(1);
     }
-    uint8_t *out = (uint8_t *)malloc(n ? n : 1);
-    mi_status st = mode_h ? mi_deflate_h_decode(dropin_ctx(), &p, (const uint8_t *)cb, csz, h + 3, out, n)
-                          : mi_lz_decode(dropin_ctx(), &p, (const uint8_t *)cb, csz, h + 3, out, n);
+    out = (uint8_t *)malloc(n ? n : 1);
+    st = mode_h ? mi_deflate_h_decode(dropin_ctx(), &p, (const uint8_t *)cb, csz, h + 3, out, n)
+                : mi_lz_decode(dropin_ctx(), &p, (const uint8_t *)cb, csz, h + 3, out, n);
+    free(ib); free(idx);
+    }
     if (st != MI_OK) { fprintf(stderr, "decompress: %s\n", mi_status_str(st)); exit(1); }
     char *on = (char *)malloc(strlen(name) + 6); strcpy(on, name); strcat(on, ".orig");
     FILE *f = fopen(on, "wb");
     if (!f) { fprintf(stderr, "Error: could not open file %s\n", on); exit(1); }
     fwrite(out, 1, n, f); fclose(f);
-    (void)nblocks;
-    free(on); free(out); free(cb); free(ib); free(idx);
+    free(on); free(out); free(cb);
 }
 
 void lz77_compress(const char *in, uint64_t n, char *out, uint64_t *out_n, HashTableArray *table)
@@ -91,6 +158,7 @@ void lz77_compress(const char *in, uint64_t n, char *out, uint64_t *out_n, HashT
     if (n > p.block) { fprintf(stderr, "lz77_compress: a block is at most %u bytes\n", p.block); exit(1); }
     uint64_t bits[2];
     uint8_t *tmp = (uint8_t *)malloc(2 * n + 128);
+    if (!tmp) { fprintf(stderr, "lz77_compress: out of memory\n"); exit(1); }
     mi_status st = mi_lz_encode(dropin_ctx(), &p, (const uint8_t *)in, n, tmp, 2 * n + 128, bits);
     if (st != MI_OK) { fprintf(stderr, "lz77_compress: %s\n", mi_status_str(st)); exit(1); }
     *out_n = bits[n ? 1 : 0] / 8;

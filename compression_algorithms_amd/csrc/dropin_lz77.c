@@ -14,6 +14,64 @@ static uint32_t cur_wbits(void)
 uint64_t min(uint64_t a, uint64_t b) { return a < b ? a : b; }
 uint64_t max(uint64_t a, uint64_t b) { return a > b ? a : b; }
 
+uint32_t hash(uint32_t pattern)                                     /* lz77.c:13-41: murmur3-style mix, % TABLE_SIZE */
+{
+    uint32_t k = pattern * 0xcc9e2d51u;
+    k = (k << 15) | (k >> 17);
+    k *= 0x1b873593u;
+    uint32_t h = (k << 13) | (k >> 19);
+    h = h * 5u + 0xe6546b64u;
+    h ^= h >> 16; h *= 0x85ebca6bu;
+    h ^= h >> 13; h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h % (1u << (cur_wbits() + 6));
+}
+
+void init_hash_table(HashTableArray *table)                         /* lz77.c:43-53 */
+{
+    table->buckets = (ArrayNode *)calloc((size_t)TABLE_SIZE, sizeof(ArrayNode));
+    if (!table->buckets) { fprintf(stderr, "Error: could not allocate memory for hash table\n"); exit(1); }
+    memset(table->bucket_indices, 0, sizeof table->bucket_indices);
+    table->current_idx = 0;
+    table->is_full = false;
+}
+
+void init_bitstream(BitStream *stream, uint8_t *buffer) { stream->data = buffer; stream->bit_index = 0; }   /* lz77.c:139-142 */
+
+void write_bit(BitStream *stream, bool bit)                         /* lz77.c:144-156: sets OR clears (the buffer need not be zeroed) */
+{
+    const uint64_t byte = stream->bit_index / 8, off = stream->bit_index % 8;
+    if (bit) stream->data[byte] |= (uint8_t)(1u << off); else stream->data[byte] &= (uint8_t)~(1u << off);
+    ++stream->bit_index;
+}
+
+bool read_bit(BitStream *stream)                                    /* lz77.c:159-167 */
+{
+    const bool b = (stream->data[stream->bit_index / 8] >> (stream->bit_index % 8)) & 1u;
+    ++stream->bit_index;
+    return b;
+}
+
+void write_bits(BitStream *stream, uint64_t value, uint64_t num_bits)   /* lz77.c:169-174: LSB first */
+{
+    for (uint64_t b = 0; b < num_bits; ++b) write_bit(stream, b < 64 && ((value >> b) & 1u));
+}
+
+uint64_t read_bits(BitStream *stream, uint64_t num_bits)            /* lz77.c:176-184 */
+{
+    uint64_t v = 0;
+    for (uint64_t b = 0; b < num_bits; ++b) if (read_bit(stream) && b < 64) v |= 1ull << b;
+    return v;
+}
+
+void print_bit_string(const char *buffer, uint64_t size)            /* lz77.c:110-119 */
+{
+    for (uint64_t i = 0; i < size; ++i) {
+        for (int bit = 7; bit >= 0; --bit) printf("%d", (buffer[i] >> bit) & 1);
+    }
+    printf("\n");
+}
+
 char *read_input_buffer(const char *filename, uint64_t *size)      /* lz77.c:121-137 */
 {
     FILE *f = fopen(filename, "rb");

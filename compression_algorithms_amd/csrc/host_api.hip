@@ -62,6 +62,57 @@ extern "C" mi_status mi_huffman_decode(mi_ctx *ctx, const uint32_t *h_words, uin
     return MI_OK;
 }
 
+// histogram + tree build alone, host buffer in (the drop-in's build_huffman_tree, huffman.c:179-215)
+extern "C" mi_status mi_huffman_build(mi_ctx *ctx, const uint8_t *h_in, uint64_t n, mi_huffman_info *h_info, mi_huffman_tree *h_tree)
+{
+    if (!ctx || !h_info || !h_tree || (n && !h_in)) return MI_ERR_ARG;
+    hipStream_t s = mi_host_stream(ctx);
+    const uint64_t ntiles = mi_huffman_num_tiles(n);
+    DevBuf in, hist, thist, info, tree;
+    if (!in.alloc(n + 16) || !hist.alloc(256 * 8) || !thist.alloc((ntiles + 1) * 1024) || !info.alloc(sizeof(mi_huffman_info)) ||
+        !tree.alloc(sizeof(mi_huffman_tree))) return MI_ERR_NOMEM;
+    if (n) MI_HIP(ctx, hipMemcpyAsync(in.p, h_in, n, hipMemcpyHostToDevice, s));
+    mi_status st = mi_huffman_hist_dev(ctx, in.as<uint8_t>(), n, hist.as<uint64_t>(), thist.as<uint32_t>(), s);
+    if (st) return st;
+    st = mi_huffman_build_dev(ctx, hist.as<uint64_t>(), info.as<mi_huffman_info>(), tree.as<mi_huffman_tree>(), s);
+    if (st) return st;
+    MI_HIP(ctx, hipMemcpyAsync(h_info, info.p, sizeof(*h_info), hipMemcpyDeviceToHost, s));
+    MI_HIP(ctx, hipMemcpyAsync(h_tree, tree.p, sizeof(*h_tree), hipMemcpyDeviceToHost, s));
+    MI_HIP(ctx, hipStreamSynchronize(s));
+    return (mi_status)h_info->status;
+}
+
+// pack with GIVEN codes from a bit offset (the drop-in's _huffman_compress, huffman.c:267-285, which appends to a
+// BitWriter wherever it stands).  h_words[0] holds the stream from bit `bit_offset` on (its first bit_offset bits are 0).
+extern "C" mi_status mi_huffman_encode_with_codes(mi_ctx *ctx, const uint8_t *h_in, uint64_t n, const uint32_t *h_codes,
+                                                  const uint8_t *h_lengths, uint32_t bit_offset, uint32_t *h_words,
+                                                  uint64_t cap_words, mi_huffman_info *h_info)
+{
+    if (!ctx || !h_codes || !h_lengths || !h_words || !h_info || (n && !h_in) || bit_offset > 31 || cap_words < 2) return MI_ERR_ARG;
+    hipStream_t s = mi_host_stream(ctx);
+    const uint64_t ntiles = mi_huffman_num_tiles(n);
+    mi_huffman_tree t;
+    memset(&t, 0, sizeof t);
+    memcpy(t.code, h_codes, sizeof t.code); memcpy(t.length, h_lengths, sizeof t.length);
+    DevBuf in, hist, thist, info, tree, words;
+    if (!in.alloc(n + 16) || !hist.alloc(256 * 8) || !thist.alloc((ntiles + 1) * 1024) || !info.alloc(sizeof(mi_huffman_info)) ||
+        !tree.alloc(sizeof(mi_huffman_tree)) || !words.alloc(cap_words * 4)) return MI_ERR_NOMEM;
+    if (n) MI_HIP(ctx, hipMemcpyAsync(in.p, h_in, n, hipMemcpyHostToDevice, s));
+    MI_HIP(ctx, hipMemcpyAsync(tree.p, &t, sizeof t, hipMemcpyHostToDevice, s));
+    mi_status st = mi_huffman_hist_dev(ctx, in.as<uint8_t>(), n, hist.as<uint64_t>(), thist.as<uint32_t>(), s);
+    if (st) return st;
+    st = mi_huffman_encode_with_tree_dev(ctx, in.as<uint8_t>(), n, tree.as<mi_huffman_tree>(), thist.as<uint32_t>(), bit_offset,
+                                         words.as<uint32_t>(), cap_words, info.as<mi_huffman_info>(), nullptr, s);
+    if (st) return st;
+    MI_HIP(ctx, hipMemcpyAsync(h_info, info.p, sizeof(*h_info), hipMemcpyDeviceToHost, s));
+    MI_HIP(ctx, hipStreamSynchronize(s));
+    if (h_info->status != MI_OK) return (mi_status)h_info->status;
+    const uint64_t nw = (h_info->total_bits + 31) >> 5;
+    if (nw > cap_words) return MI_ERR_CAPACITY;
+    if (nw) MI_HIP(ctx, hipMemcpy(h_words, words.p, nw * 4, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
 extern "C" mi_status mi_lz_decode(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *h_stream, uint64_t stream_bytes,
                                   const uint64_t *h_block_bits, uint8_t *h_out, uint64_t n)
 {

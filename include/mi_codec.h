@@ -137,6 +137,12 @@ mi_status mi_huffman_encode_with_tree_dev(mi_ctx *ctx, const uint8_t *d_in, uint
                                           const uint32_t *d_tile_hist, uint32_t bit_offset, uint32_t *d_words, uint64_t cap_words,
                                           mi_huffman_info *d_info, uint64_t *d_tile_off, void *stream);
 
+/* host-buffer forms of the steps (the drop-in's build_huffman_tree and _huffman_compress, huffman.c:179-215, :267-285) */
+mi_status mi_huffman_build(mi_ctx *ctx, const uint8_t *h_in, uint64_t n, mi_huffman_info *h_info, mi_huffman_tree *h_tree);
+mi_status mi_huffman_encode_with_codes(mi_ctx *ctx, const uint8_t *h_in, uint64_t n, const uint32_t *h_codes,
+                                       const uint8_t *h_lengths, uint32_t bit_offset, uint32_t *h_words, uint64_t cap_words,
+                                       mi_huffman_info *h_info);
+
 /* ------------------------------------------------------------------------------------
  * LZ77 greedy tokenisers, block-parallel.
  *   deflate flavour: algorithms/deflate/lz77.c:199-280 per block of `block` bytes with a

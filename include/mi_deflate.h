@@ -30,8 +30,38 @@
 extern "C" {
 #endif
 
-typedef struct HashTableArray HashTableArray;     /* opaque: the GPU path never materialises the table */
-typedef struct HuffmanNode HuffmanNode;
+#define WINDOW_SIZE (1 << MAX_WINDOW_BITS)
+#define TABLE_SIZE  (1 << (MAX_WINDOW_BITS + 5))
+
+/* algorithms/deflate/lz77.h:10-28, same layouts: a caller written like deflate.c:13-14 (`HashTableArray table;
+ * init_hash_table(&table);`) compiles and runs.  The GPU path never materialises the table: lz77_compress
+ * accepts it and neither reads nor updates it — every call encodes its block against a FRESH table. */
+typedef struct ArrayNode {
+    uint32_t pattern;
+    uint64_t index;
+    bool     is_set;
+} ArrayNode;
+
+typedef struct Buckets {
+    uint32_t *patterns;
+    uint64_t *indices;
+    bool     *is_set;
+} Buckets;
+
+typedef struct {
+    Buckets  buckets;
+    uint32_t bucket_indices[1 << MAX_WINDOW_BITS];
+    uint32_t current_idx;
+    bool     is_full;
+} HashTableArray;
+
+/* algorithms/deflate/deflate.h:12-17 */
+typedef struct HuffmanNode {
+    struct HuffmanNode *left;
+    struct HuffmanNode *right;
+    uint16_t value;
+    uint64_t frequency;
+} HuffmanNode;
 
 typedef struct StateData {
     HashTableArray *table;              /* always NULL (the reference returns a dangling pointer here) */
@@ -41,6 +71,16 @@ typedef struct StateData {
 
 StateData compress(const char *input_filename);
 void      decompress(StateData *state_data, const char *input_filename);
+
+uint64_t min(uint64_t a, uint64_t b);
+uint64_t max(uint64_t a, uint64_t b);
+uint32_t hash(uint32_t pattern);                                  /* deflate/lz77.c:14-42 */
+void     init_hash_table(HashTableArray *table);                  /* deflate/lz77.c:44-67: allocates and zeroes, as the reference */
+/* NOT exported: insert_hash_table, find (deflate/lz77.h:32-33): per-entry operations on a host table the GPU path does
+ * not have (mi_lz_find_all_dev gives find() for every position of a buffer); lz77_decompress (deflate/lz77.h:54-59): the
+ * reference's body discards its output (deflate/lz77.c:282-311) — use decompress() or mi_lz_decode. */
+void write_literal(char *buffer, char c, uint64_t *buffer_index);                                   /* deflate/lz77.c:176-184 */
+void write_length_distance(char *buffer, uint8_t length, uint16_t distance, uint64_t *buffer_index);   /* deflate/lz77.c:186-197 */
 
 /* one block (<= 65 536 bytes), fresh table; `table` is accepted for source compatibility and ignored */
 void lz77_compress(const char *input_buffer, uint64_t input_buffer_size, char *compressed_buffer,

@@ -11,7 +11,8 @@
  * reference builds (huffman_decompress walks it), and fills the BitWriter like the reference:
  * buffer (malloc'd), word_idx, bit_idx, buffer_size per huffman.c:318-320.  Unlike the
  * reference's realloc (which can cut live bytes of the last partial word) the
- * buffer keeps every word, followed by the encoder's tile offsets for the parallel decoder.
+ * buffer keeps every word; the encoder's tile offsets for the parallel decoder are kept out of band
+ * by the library (keyed by the buffer pointer); mi_frame.h serialises stream + tree + offsets.
  * Errors the reference reports with printf + exit(1) are reported the same way.
  */
 #ifndef MI_HUFFMAN_H
@@ -38,11 +39,37 @@ struct Node {
     Node    *right;
 };
 
+/* huffman.h:62-66 — declared so that reference-style sources compile; the queue FUNCTIONS (init_priority_queue,
+ * swap_nodes, heapify_up/down, enqueue, dequeue, is_empty: huffman.h:67-73) are NOT exported: the heap lives inside
+ * k_huff_build, which replays the reference's heap operation by operation on the GPU (its tie-breaking defines the
+ * codes), and has no host-resident form. */
+typedef struct PriorityQueue {
+    Node   **nodes;
+    uint64_t size;
+    uint64_t capacity;
+} PriorityQueue;
+
 char *read_input_buffer(const char *filename, uint64_t *size);
+/* huffman.c:9-15 / :18-48: host-side bit writer helpers (MSB-first into u32 words), same semantics */
+void  init_bitwriter(BitWriter *writer, uint64_t buffer_size);
+void  write_bits(BitWriter *writer, uint32_t bits, uint8_t length);
+Node *init_node(uint8_t value, uint32_t frequency);                                     /* huffman.c:165-177 */
+void  print_bit_string(uint8_t *buffer, uint64_t size);                                 /* huffman.c:50-59 */
+void  print_codes(uint32_t *codes, uint8_t *code_lengths);                              /* huffman.c:252-265 */
+/* huffman.c:179-215 on the GPU: histogram + heap-exact tree; *root receives a malloc'd tree of the reference's shape */
+void  build_huffman_tree(char *buffer, uint64_t size, Node **root);
+/* huffman.c:267-285 on the GPU: packs `buffer` with the GIVEN codes, appending to `writer` wherever it stands */
+void  _huffman_compress(char *buffer, uint64_t size, uint32_t *codes, uint8_t *code_lengths, BitWriter *writer);
 Node  huffman_compress(char *buffer, uint64_t size, BitWriter *writer);
 /* *output_size carries the ORIGINAL length on entry (huffman/main.c:69) and the decoded count on return */
 void  huffman_decompress(BitWriter *writer, Node *root, char *output, uint64_t *output_size);
 void  gather_codes(Node *root, uint32_t code, uint32_t length, uint32_t *codes, uint8_t *code_lengths);
+
+/* Extensions (no counterpart in huffman.h): the same codec to and from a self-describing FILE (mi_frame.h: serialised
+ * tree + {last_block, size} chunks, after zig_huffman/src/main.zig:155-176,513-530), so that decoding needs neither the
+ * in-memory Node tree nor the original size.  Return 0; errors follow the reference's printf + exit(1) convention. */
+int huffman_compress_file(const char *input_filename, const char *output_filename);
+int huffman_decompress_file(const char *input_filename, const char *output_filename);
 
 #ifdef __cplusplus
 }

@@ -14,8 +14,8 @@
  * concatenated bit-contiguously.  A buffer of at most one block therefore yields the
  * reference's stream bit for bit; larger buffers yield a stream the reference's own
  * lz77_decompress still decodes whenever no block's last match overshoots (it never does on
- * text).  The per-block bit offsets that a parallel decoder needs ride
- * behind the stream bytes inside the same malloc'd `data` block.
+ * text).  The per-block bit offsets that a parallel decoder needs are kept
+ * out of band by the library (keyed by the `data` pointer); mi_frame.h serialises both.
  */
 #ifndef MI_LZ77_H
 #define MI_LZ77_H
@@ -40,10 +40,40 @@ typedef struct {
     uint64_t bit_index;
 } BitStream;
 
+/* algorithms/lz77/lz77.h:19-30, same layout: reference-style callers (`HashTableArray t; init_hash_table(&t);`) compile
+ * and run.  The GPU path never materialises this table: see insert_hash_table / find below. */
+typedef struct ArrayNode {
+    uint32_t pattern;
+    uint64_t index;
+    bool     is_set;
+} ArrayNode;
+
+typedef struct {
+    ArrayNode *buckets;
+    uint32_t   bucket_indices[1 << WINDOW_BITS];
+    uint32_t   current_idx;
+    bool       is_full;
+} HashTableArray;
+
 uint64_t min(uint64_t a, uint64_t b);
 uint64_t max(uint64_t a, uint64_t b);
+/* lz77.h:32, lz77.c:13-41: the host twin of the device constant every kernel hashes with (lz_common.h lz_mix32) */
+uint32_t hash(uint32_t pattern);
+/* lz77.h:33, lz77.c:43-53: allocates and zeroes the table exactly like the reference */
+void init_hash_table(HashTableArray *table);
+/* NOT exported: insert_hash_table, find (lz77.h:34-35) — single-entry operations on a host-resident table.  The hot path
+ * replaces the table by a per-block replay in LDS and has no per-entry host form; a caller that wants find() for every
+ * position of a buffer uses mi_lz_find_all_dev (mi_codec.h).  Also NOT exported: lz77_compress_old (lz77.h:51-54), the
+ * reference's unused brute-force parser (commented out at lz77/main.c:26): a different stream, O(n * W) by design. */
+void  print_bit_string(const char *buffer, uint64_t size);
 char *read_input_buffer(const char *filename, uint64_t *size);
 bool  check_buffer_equivalence(const char *buffer1, const char *buffer2, uint64_t size);
+/* lz77.h:39-44, lz77.c:139-184: LSB-first bit I/O on a caller's buffer (host helpers, not on the hot path) */
+void     init_bitstream(BitStream *stream, uint8_t *buffer);
+void     write_bit(BitStream *stream, bool bit);
+bool     read_bit(BitStream *stream);
+void     write_bits(BitStream *stream, uint64_t value, uint64_t num_bits);
+uint64_t read_bits(BitStream *stream, uint64_t num_bits);
 
 /* returns a malloc'd BitStream whose data is malloc'd; caller frees ->data then the struct (lz77/main.c:66-67) */
 BitStream *lz77_compress(const char *buffer, uint64_t size);

@@ -27,6 +27,14 @@ def test_header_symbols_are_exported(built):
     assert not missing, f"libmi_codec.so does not export: {missing}"
 
 
+def test_frame_header_symbols_are_exported(built):
+    hdr = open(os.path.join(ROOT, "include", "mi_frame.h")).read()
+    declared = set(re.findall(r"\b(mi_frame_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) == 7, declared
+    missing = [s for s in sorted(declared) if not hasattr(built, s)]
+    assert not missing, f"libmi_codec.so does not export: {missing}"
+
+
 def test_no_device_is_an_error_not_a_fallback(built):
     import ctypes as C
     import torch
