@@ -34,6 +34,7 @@ struct mi_ctx {
     int         last_hip = 0;
     int         profiling = 0;
     int         num_cu = 256;
+    int         lds_rank_ok = 0;       // LDS returning atomics serve the lanes of one instruction in lane order (self-check at creation)
     // workspace (device), grown on demand, never inside a captured region
     void       *ws = nullptr;
     size_t      ws_bytes = 0;

@@ -2,6 +2,43 @@
 #include "common.h"
 #include <stdlib.h>
 
+// Self-check behind LZP_ARANK (lz_common.h, radix_pass): do the lanes of ONE returning LDS add that hit the same address
+// receive their values in lane order?  The stable radix scatter relies on it; the ISA does not promise it, so every
+// context measures it once (8 waves on their own counters, digit patterns from one address to 256, a few thousand
+// instructions) and the ballot ranking is used if a single pair is out of order.  MI_LZ_NO_ARANK=1 forces the ballots.
+__global__ __launch_bounds__(512)
+static void k_lds_rank_probe(uint32_t rounds, uint32_t *__restrict__ bad)
+{
+    __shared__ uint32_t cnt[256 * 9];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t i = tid; i < 256 * 9; i += 512) cnt[i] = 0;
+    __syncthreads();
+    uint32_t errs = 0, x = tid * 2654435761u + blockIdx.x * 40503u + 12345u;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        x = x * 1664525u + 1013904223u;
+        const uint32_t ndig = 1u << (r % 9u);                                  // 1, 2, 4, ... 256 distinct addresses per wave
+        const uint32_t d = (blockIdx.x & 1u) ? ((x >> 16) % ndig) : (((x >> 16) % ndig) * 32u) % 256u;   // odd blocks: spread; even: one bank
+        const uint32_t old = atomicAdd(&cnt[d * 9 + wave], 1u);
+        for (uint32_t o = 1; o < 64; ++o) {
+            const uint32_t src = (lane + o) & 63u;
+            const uint32_t od = __shfl(d, src), oo = __shfl(old, src);
+            if (od == d && ((src < lane) != (oo < old))) ++errs;
+        }
+    }
+    if (errs) atomicAdd(bad, errs);
+}
+
+static int lds_rank_selfcheck(mi_ctx *c)
+{
+    if (getenv("MI_LZ_NO_ARANK")) return 0;
+    uint32_t h = 1;
+    if (hipMemset(c->d_err, 0, 4) != hipSuccess) return 0;
+    hipLaunchKernelGGL(k_lds_rank_probe, dim3(64), dim3(512), 0, 0, 72u, c->d_err);
+    if (hipGetLastError() != hipSuccess || hipMemcpy(&h, c->d_err, 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    (void)hipMemset(c->d_err, 0, 4);
+    return h == 0;
+}
+
 extern "C" {
 
 const char *mi_version(void) { return "mi_codec 0.1 (gfx950)"; }
@@ -62,6 +99,7 @@ mi_status mi_ctx_create(mi_ctx **out, int device)
         mi_ctx_destroy(c); return MI_ERR_NOMEM;
     }
     if (hipMalloc((void **)&c->d_err, MI_ERR_SLOTS * sizeof(uint32_t)) != hipSuccess) { mi_ctx_destroy(c); return MI_ERR_NOMEM; }
+    c->lds_rank_ok = lds_rank_selfcheck(c);
     *out = c;
     return MI_OK;
 }

@@ -325,7 +325,7 @@ extern "C" mi_status mi_deflate_h_decode_dev(mi_ctx *ctx, const mi_lz_params *p,
     if (!p->deflate || p->lbits > 5 || p->wbits > 16 || ((uintptr_t)d_stream & 3u)) return MI_ERR_ARG;
     if (n == 0) return MI_OK;
     hipStream_t s = (hipStream_t)stream;
-    const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block};
+    const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block, ctx->lds_rank_ok ? LZP_ARANK : 0u};
     const uint64_t nblocks = (n + P.block - 1) / P.block;
     uint32_t *err = mi_err_slot(ctx, s);
     if (!err) return MI_ERR_HIP;

@@ -11,11 +11,22 @@
 //   LSB-first bit append main.zig:28-39
 //
 // One wave per block.  The block is read twice from HBM/L2 (histogram pass, coalesced 16 B per
-// lane; encode pass, each lane streaming its own contiguous sub-stream), the tables (<= 12 KiB
-// at table_log 12) live in LDS, so up to 8 waves per SIMD hide the table-lookup latency of the
-// serial state chain.  The encode loop runs twice: a dry run that only counts bits, a prefix sum
-// over the lanes, then the real run writing each sub-stream at its final offset — no staging
-// buffer, no intra-block compaction.
+// lane; encode pass, each lane streaming its own contiguous sub-stream with 16-byte loads, the next
+// one in flight), the tables (3N bytes: 768 B at table_log 8, 12 KiB at 12) live in dynamic LDS, so
+// ~20 waves per CU hide the table-lookup latency of the serial state chain.  The encode loop runs
+// ONCE: the chain is serial, so a dry run that only counts bits costs as much as the coding.  Every
+// lane writes its words at a fixed stride inside the block's record (the worst case, which is what
+// the record is sized for) and the wave then closes the gaps in place, left to right.
+//
+// Why the in-place compaction needs no fence: sub-stream l moves DOWN, from l * lstr to its prefix
+// offset woff[l], and woff[l] + cnt[l] = woff[l+1] <= (l+1) * lstr, so a store for sub-stream l never
+// lands on a word that a LATER load (of l itself or of any l' > l) still has to read; the only loads
+// a store can overlap are ones of the same or an earlier copy step, and the store carries their data
+// (v = payload[src]; payload[dst] = v), so it cannot issue before they have returned.
+//
+// Staging the sub-stream words through LDS instead was not done: the worst case
+// is 64 lanes x 257 words = 64 KiB per wave, i.e. two waves per CU instead of twenty — the state
+// chain needs the occupancy more than the ~36 KiB per block of L2 write traffic it would save.
 #include "common.h"
 
 #define FSE_MAX_LOG   12

@@ -216,20 +216,21 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     const uint32_t plo_ = mt->part_lo[part];
     const uint32_t phi_ = (part + 1 < mt->nparts) ? mt->part_lo[part + 1] : T;
     const bool three = (phi_ - plo_) > 65536u;
+    const bool arank = (P.flags & LZP_ARANK) != 0;
     auto keyp = [&](uint32_t j) -> uint32_t { return homep(j) - plo_; };
     uint16_t *srt = s_j0;                                   // where the home order ends up
     if (three) {
         radix_pass<LZ2_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return i; },
-            [&](uint32_t e) { return keyp(e) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; });
+            [&](uint32_t e) { return keyp(e) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; }, arank);
         radix_pass<LZ2_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return (uint32_t)s_j0[i]; },
-            [&](uint32_t e) { return (keyp(e) >> 8) & 255u; }, [&](uint32_t d, uint32_t e) { s_j1[d] = (uint16_t)e; });
+            [&](uint32_t e) { return (keyp(e) >> 8) & 255u; }, [&](uint32_t d, uint32_t e) { s_j1[d] = (uint16_t)e; }, arank);
         radix_pass<LZ2_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return (uint32_t)s_j1[i]; },
-            [&](uint32_t e) { return (keyp(e) >> 16) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; });
+            [&](uint32_t e) { return (keyp(e) >> 16) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; }, arank);
     } else {
         radix_pass<LZ2_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return i; },
-            [&](uint32_t e) { return keyp(e) & 255u; }, [&](uint32_t d, uint32_t e) { s_j1[d] = (uint16_t)e; }, sc.dbg);
+            [&](uint32_t e) { return keyp(e) & 255u; }, [&](uint32_t d, uint32_t e) { s_j1[d] = (uint16_t)e; }, arank, sc.dbg);
         radix_pass<LZ2_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return (uint32_t)s_j1[i]; },
-            [&](uint32_t e) { return (keyp(e) >> 8) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; }, sc.dbg);
+            [&](uint32_t e) { return (keyp(e) >> 8) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; }, arank, sc.dbg);
     }
     (void)srt;
 
@@ -357,9 +358,9 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     //      (cluster numbers are < LZ2_CAP <= 4096: two 6-bit passes, fewer ballots and a shorter offset scan than 8 + 8)
     static_assert(LZ2_CAP <= 4096, "cluster numbers must fit 12 bits");
     radix_pass<LZ2_NWAVES, 6, uint32_t>(m, s_cnt, [&](uint32_t i) { return i; },
-        [&](uint32_t e) { return (uint32_t)s_g[e] & 63u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; });
+        [&](uint32_t e) { return (uint32_t)s_g[e] & 63u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; }, arank);
     radix_pass<LZ2_NWAVES, 6, uint32_t>(m, s_cnt, [&](uint32_t i) { return (uint32_t)s_j0[i]; },
-        [&](uint32_t e) { return (uint32_t)s_g[e] >> 6; }, [&](uint32_t d, uint32_t e) { s_j1[d] = (uint16_t)e; });
+        [&](uint32_t e) { return (uint32_t)s_g[e] >> 6; }, [&](uint32_t d, uint32_t e) { s_j1[d] = (uint16_t)e; }, arank);
 
     LZ2_TICK(3);
     // ---- permute into replay order (cluster, time).  e_pos / e_rs overlay the dead word array.

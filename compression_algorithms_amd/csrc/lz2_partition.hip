@@ -235,7 +235,7 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     radix_pass_1024<5, uint32_t>(n, s_cnt,
         [&](uint32_t i) { return i | ((uint32_t)part_in[i] << 16); },
         [&](uint32_t e) { return e >> 16; },
-        [&](uint32_t j, uint32_t e) { plist[j] = (uint16_t)e; });
+        [&](uint32_t j, uint32_t e) { plist[j] = (uint16_t)e; }, (P.flags & LZP_ARANK) != 0);
 }
 
 void lz2_launch_partition(const uint8_t *d_in, uint64_t n, const LzP &P, const Lz2Scratch &sc, uint64_t block0, uint32_t nb, hipStream_t s)

@@ -25,7 +25,9 @@
 
 struct LzP {
     uint32_t wbits, lbits, tbits, deflate, block;
+    uint32_t flags;        // LZP_ARANK: the context's self-check found LDS returning atomics lane-ordered (ctx.hip)
 };
+#define LZP_ARANK 1u
 
 // per-block record written by k_lz_sort_home
 struct LzBlockMeta {
@@ -132,7 +134,7 @@ struct OpMaxI32 { __device__ int32_t operator()(int32_t a, int32_t b) const { re
 //            owns a digit reads its NWAVES counters at once (no read-modify-write chain through LDS) and the lanes of a
 //            wave, which hit different digits, still spread over the banks.
 template <int NWAVES, int NBITS, typename E, typename CntRow, typename Load, typename Digit, typename Store>
-__device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load, Digit digit, Store store, uint64_t *dbg = nullptr)
+__device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load, Digit digit, Store store, bool arank = false, uint64_t *dbg = nullptr)
 {
     long long tk_ = dbg ? clock64() : 0;
 #define RP_TICK(k) do { if (dbg && threadIdx.x == 0) { long long t2 = clock64(); atomicAdd((unsigned long long *)&dbg[k], (unsigned long long)(t2 - tk_)); tk_ = t2; } } while (0)
@@ -167,6 +169,26 @@ __device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load,
     }
     __syncthreads();
     RP_TICK(9);
+    if (arank) {
+        // Rank by the LDS itself: a returning add on the (digit, wave) cursor hands every lane of the instruction its slot,
+        // and lanes that hit one address are served in LANE order (measured on gfx950, scripts/micro/lds_atomic_order.hip;
+        // the context re-checks it when it is created and clears LZP_ARANK otherwise) — so the pass stays stable with ~10
+        // instructions per 64 elements instead of the ~60 of the ballot ranking below (NBITS ballots build each lane's
+        // peer mask).  The scatter was bound by VALU issue (SQ counters, profiles/r02a): this is where the instructions were.
+        E en{};
+        uint32_t dn = 0;
+        if (a + lane < b) { en = load(a + lane); dn = digit(en); }
+        for (uint32_t i0 = a; i0 < b; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const E e = en;
+            const uint32_t d = dn;
+            if (i + 64 < b) { en = load(i + 64); dn = digit(en); }
+            if (i < b) store(atomicAdd(&cnt[d * ST + wave], 1u), e);
+        }
+        __syncthreads();
+        RP_TICK(10);
+        return;
+    }
     // the element and its digit of the NEXT step are fetched while this step ranks and stores (two dependent LDS reads
     // off the chain: measured, the scatter is a chain of LDS round trips, 58 % of a pass)
     E en{};
@@ -204,7 +226,7 @@ __device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load,
 // 2 x 8 bits (12.35 vs 13.1 GB/s); it was removed.
 
 template <int NBITS, typename E, typename CntRow, typename Load, typename Digit, typename Store>
-__device__ __forceinline__ void radix_pass_1024(uint32_t n, CntRow *s_cnt, Load load, Digit digit, Store store)
+__device__ __forceinline__ void radix_pass_1024(uint32_t n, CntRow *s_cnt, Load load, Digit digit, Store store, bool arank = false)
 {
-    radix_pass<16, NBITS, E>(n, s_cnt, load, digit, store);
+    radix_pass<16, NBITS, E>(n, s_cnt, load, digit, store, arank);
 }

@@ -511,7 +511,7 @@ static mi_status lz_encode_impl(mi_ctx *ctx, const mi_lz_params *p, const uint8_
     if (mode_h && (!p->deflate || p->lbits > 5 || p->wbits > 16)) return MI_ERR_ARG;
     if (cap_bytes < (mode_h ? mi_deflate_h_bound_bytes(n, p) : mi_lz_bound_bytes(n, p))) return MI_ERR_CAPACITY;
     hipStream_t s = (hipStream_t)stream;
-    const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block};
+    const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block, ctx->lds_rank_ok ? LZP_ARANK : 0u};
     const uint64_t nblocks = (n + P.block - 1) / P.block;
     const uint32_t nbmax = lz_batch_blocks(nblocks);
     // three stages on three streams, MI_SETS scratch sets in rotation:
@@ -635,7 +635,7 @@ extern "C" mi_status mi_lz_decode_dev(mi_ctx *ctx, const mi_lz_params *p, const 
     if (st) return st;
     if (n == 0) return MI_OK;
     hipStream_t s = (hipStream_t)stream;
-    const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block};
+    const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block, ctx->lds_rank_ok ? LZP_ARANK : 0u};
     const uint64_t nblocks = (n + P.block - 1) / P.block;
     uint32_t *err = mi_err_slot(ctx, s);
     if (!err) return MI_ERR_HIP;

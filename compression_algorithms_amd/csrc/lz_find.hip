@@ -628,7 +628,7 @@ extern "C" mi_status mi_lz_find_all_dev(mi_ctx *ctx, const mi_lz_params *p, cons
     if (st) return st;
     if (n == 0) return MI_OK;
     hipStream_t s = (hipStream_t)stream;
-    const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block};
+    const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block, ctx->lds_rank_ok ? LZP_ARANK : 0u};
     const uint64_t nblocks = (n + P.block - 1) / P.block;
     const uint32_t nbmax = lz_batch_blocks(nblocks);
     st = mi_ws_reserve(ctx, lz_scratch_bytes(nbmax));

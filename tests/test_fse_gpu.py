@@ -88,3 +88,44 @@ def test_full_size_roundtrip_and_ratio():
     got = int(st.offsets[20]) // 8
     framing = 20 * (32 + 2 * 100 + 6 * 64 + 4 * 64)
     assert got <= ideal * 1.01 + framing
+
+
+def test_table_log_8_is_near_its_ideal_cost():
+    """the reference's TABLE_LOG (fse/src/main.zig:80) is 8: size within 1 % of the ideal cost of the table_log-8
+    normalised tables (sum of -log2(cnt/256) over the symbols) plus the documented framing — checked per block against
+    the oracle's ideal-cost function on the first 40 blocks."""
+    from compression_algorithms_amd import fse
+    from oracle import orc
+    host = synth.enwik_like(40 * 65536, seed=77).numpy()
+    st = fse.compress(host, fse.params(8, 64, 1, 65536))
+    offs = st.offsets.cpu().numpy()
+    nsym = len(np.unique(host))
+    for b in range(40):
+        blk = host[b * 65536:(b + 1) * 65536]
+        ideal = orc.fse_ideal_bits(blk, 8) / 8
+        framing = 32 + 2 * (nsym + 1) + 2 * 64 + 4 * 64 + 4 * 64      # bitmap, counts, states, lengths, <= one pad word per lane
+        got = (int(offs[b + 1]) - int(offs[b])) // 8
+        assert got <= ideal * 1.01 + framing, (b, got, ideal)
+        assert got >= ideal                                           # a tANS stream cannot beat its table's entropy
+
+
+def test_config_3_size_properties():
+    """BASELINE config 3 at its stated size, 10^9 bytes, table_log 8: decode(encode(x)) == x; every record is word aligned
+    and within the worst-case bound; the block table is an exclusive prefix; sampled blocks equal the oracle's records."""
+    from compression_algorithms_amd import fse
+    from oracle import orc
+    x = synth.enwik_like(1_000_000_000, seed=12345, device="cuda")
+    p = fse.params(8, 64, 1, 65536)
+    st = fse.compress(x, p)
+    back = fse.decompress(st)
+    assert torch.equal(back, x)
+    del back
+    offs = st.offsets.cpu().numpy()
+    nblocks = (x.numel() + 65535) // 65536
+    assert len(offs) == nblocks + 1 and offs[0] == 0
+    d = np.diff(offs)
+    assert (d > 0).all() and (d % 32 == 0).all() and (d // 8 <= fse.block_bound(p)).all()
+    assert 0.5 < st.nbytes / x.numel() < 0.75                         # order-0 coding of this corpus: ~5.1-5.4 bits per byte
+    for b in (0, 7000, nblocks - 1):
+        blk = x[b * 65536:(b + 1) * 65536].cpu().numpy()
+        assert np.array_equal(st.record(b).cpu().numpy(), orc.fse_encode_block(blk, 8, 64, 1)), b
