@@ -70,4 +70,5 @@ struct Lz2Scratch {
     uint32_t     *big_count;                         // [LZ2_NCLASS]
     uint64_t     *dbg;                               // phase cycle counters (MI_LZ_DEBUG=1), else NULL
     uint32_t      wave_min;                          // see lz2_class_of
+    uint32_t      stop_phase;                        // measurement only (MI_LZ_STOP_PHASE=k): k_lz2_find leaves after phase k; 0 = run everything
 };

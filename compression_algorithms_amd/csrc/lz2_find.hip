@@ -145,12 +145,18 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     // off a cursor made this kernel 30.3 -> 51 ms per GB on its own — the loop keeps every scratch pointer live across
     // the whole body: 84 -> 176 VGPRs, one workgroup per CU instead of two (forced back to 128 VGPRs it spills) — and the
     // hardware dispatcher already IS a dynamic scheduler: ~13 k empty workgroups per batch cost nothing measurable.
-    if (blockIdx.x >= *sc.work_count) return;
-    const uint32_t item = sc.work[blockIdx.x];
+    // XCD-aware order: workgroup ids go round the 8 XCDs (each with its own L2), the work list holds a block's parts one
+    // after the other — so give every XCD a CONTIGUOUS eighth of the list: the ~19 parts of a block then gather their
+    // words from one L2 instead of pulling the block's 64 KiB into all eight (HBM fetch of this kernel: profiles/).
+    const uint32_t nwork = *sc.work_count;
+    const uint32_t cpx = (nwork + 7u) >> 3, item_idx = (blockIdx.x & 7u) * cpx + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= cpx || item_idx >= nwork) return;
+    const uint32_t item = sc.work[item_idx];
     const uint32_t lb = item & 0xFFFFu, part = item >> 16;
     Lz2BlockMeta *mt = sc.meta + lb;
     long long tk = clock64();
-#define LZ2_TICK(k) do { if (sc.dbg && tid == 0) { long long t2 = clock64(); atomicAdd((unsigned long long *)&sc.dbg[k], (unsigned long long)(t2 - tk)); tk = t2; } } while (0)
+#define LZ2_TICK(k) do { if (sc.dbg && tid == 0) { long long t2 = clock64(); atomicAdd((unsigned long long *)&sc.dbg[k], (unsigned long long)(t2 - tk)); tk = t2; } \
+                         if ((k) < 7 && sc.stop_phase == (uint32_t)(k) + 1u) return; } while (0)     /* stop_phase: per-phase counter runs (scripts/phase_pmc.sh) */
     if (mt->fallback || part >= mt->nparts) return;
     const uint32_t m = mt->part_count[part];
     if (m == 0) return;
@@ -430,6 +436,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
             }
         }
         __syncthreads();
+        LZ2_TICK(11);
         if (tid == 0) {                                      // bucket offsets, largest size first
             uint32_t run = 0;
             for (int sz = (int)LZ2_BIG - 1; sz >= 2; --sz) { const uint32_t t = s_bin[sz]; s_bin[sz] = run; run += t; }
@@ -439,6 +446,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
         for (uint32_t c = 0; c < CH; ++c)
             if (my_n[c] >= 2 && my_n[c] < LZ2_BIG) c_start[atomicAdd(&s_bin[my_n[c]], 1u)] = (uint16_t)my_s[c];
         __syncthreads();
+        LZ2_TICK(12);
         // reserve the output space of the clusters this part exports NOW — ONE global atomic per part and class (the class
         // counters are shared by every workgroup of the batch), local ranks first in LDS — so that the round trips of
         // those atomics pass while the lanes replay
@@ -453,14 +461,23 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
             }
         }
         __syncthreads();
-        if (tid < (int)LZ2_NCLASS && s_cls[tid]) s_clsbase[tid] = atomicAdd(&sc.big_count[tid], s_cls[tid]);
-        if (tid == 32 && s_ent) { s_entbase = atomicAdd(&mt->nbig_entries, s_ent); atomicAdd(&mt->nbig, nbig); }
+        // The returns of these global atomics (every part of the batch adds to the same eight class counters: ~12 k cycles
+        // under that contention, measured) are only needed by the export below: they stay in a register until the lane
+        // replay is through, so the wave that issues them does not stall in front of its share of the replay.
+        uint32_t pending_base = 0;
+        const bool want_cls = tid < (int)LZ2_NCLASS && s_cls[tid], want_ent = tid == 32 && s_ent;
+        if (want_cls) pending_base = atomicAdd(&sc.big_count[tid], s_cls[tid]);
+        if (want_ent) { pending_base = atomicAdd(&mt->nbig_entries, s_ent); atomicAdd(&mt->nbig, nbig); }
         for (uint32_t q = tid >> 6; q < s_nquiet; q += LZ2_NWAVES)
             for (uint32_t k = (uint32_t)s_quiet[2 * q] + (tid & 63u); k < s_quiet[2 * q + 1]; k += 64) {
                 const uint32_t id = e_pid[k];
                 cand_i[k] = (id != e_pos[k]) ? (uint16_t)id : (uint16_t)LZ_NONE16;
             }
         const uint32_t ncl = s_ncl;
+        LZ2_TICK(13);
+        if (sc.dbg && tid == 0) { atomicAdd((unsigned long long *)&sc.dbg[23], (unsigned long long)ncl); atomicAdd((unsigned long long *)&sc.dbg[24], (unsigned long long)nbig);
+                                  atomicAdd((unsigned long long *)&sc.dbg[25], (unsigned long long)s_ent); atomicAdd((unsigned long long *)&sc.dbg[26], (unsigned long long)s_nquiet);
+                                  atomicAdd((unsigned long long *)&sc.dbg[27], (unsigned long long)m); atomicAdd((unsigned long long *)&sc.dbg[28], (unsigned long long)s_ngroups); }
         for (uint32_t q = tid; q < ncl; q += LZ2_THREADS) {
             const uint32_t s = c_start[q];
             uint32_t e = s + 1;
@@ -469,6 +486,8 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
             if (zc) replay_small(e_pos, e_rs, e_pid, occ, s_bm, s, e, W, s_zslot, P.deflate ? s_zslot : ~0u, cand_i);
             else replay_small_reg(e_pos, e_rs, e_pid, s, e, W, cand_i);
         }
+        if (want_cls) s_clsbase[tid] = pending_base;
+        if (want_ent) s_entbase = pending_base;
     }
     __syncthreads();
     LZ2_TICK(5);
@@ -706,6 +725,7 @@ void lz2_carve(mi_carver &cv, uint32_t nb, Lz2Scratch *sc)
     sc->work = cv.take<uint32_t>((size_t)nb * LZ2_MAXPARTS);
     sc->dbg = getenv("MI_LZ_DEBUG") ? cv.take<uint64_t>(32) : nullptr;
     sc->wave_min = LZ2_WAVE;
+    sc->stop_phase = getenv("MI_LZ_STOP_PHASE") ? (uint32_t)atoi(getenv("MI_LZ_STOP_PHASE")) : 0u;
 }
 
 static uint32_t lz2_env_u32(const char *name, uint32_t dflt)

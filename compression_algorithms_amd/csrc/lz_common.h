@@ -148,7 +148,15 @@ __device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load,
     const uint32_t a = wave * seg, b = (a + seg < n) ? a + seg : n;
     for (int i = tid; i < ND * ST; i += NT) cnt[i] = 0;
     __syncthreads();
-    for (uint32_t i = a + lane; i < b; i += 64) atomicAdd(&cnt[digit(load(i)) * ST + wave], 1u);
+    // four elements per lane and step: their (dependent) key lookups are in flight together — at 4 waves per SIMD a pass is
+    // a chain of LDS round trips, not a stream of instructions
+    for (uint32_t i = a + lane; i < b; i += 256) {
+        uint32_t dg[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dg[u] = (i + 64u * u < b) ? digit(load(i + 64u * u)) : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (i + 64u * u < b) atomicAdd(&cnt[dg[u] * ST + wave], 1u);
+    }
     __syncthreads();
     RP_TICK(8);
     // offsets: thread d < ND owns digit d: exclusive prefix over its waves in registers, then an exclusive scan over digits
@@ -175,15 +183,17 @@ __device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load,
         // the context re-checks it when it is created and clears LZP_ARANK otherwise) — so the pass stays stable with ~10
         // instructions per 64 elements instead of the ~60 of the ballot ranking below (NBITS ballots build each lane's
         // peer mask).  The scatter was bound by VALU issue (SQ counters, profiles/r02a): this is where the instructions were.
-        E en{};
-        uint32_t dn = 0;
-        if (a + lane < b) { en = load(a + lane); dn = digit(en); }
-        for (uint32_t i0 = a; i0 < b; i0 += 64) {
-            const uint32_t i = i0 + lane;
-            const E e = en;
-            const uint32_t d = dn;
-            if (i + 64 < b) { en = load(i + 64); dn = digit(en); }
-            if (i < b) store(atomicAdd(&cnt[d * ST + wave], 1u), e);
+        // Four 64-element steps at a time: loads and key lookups of all four first, then the four returning adds IN STEP
+        // ORDER (one wave's LDS instructions execute in issue order, so step k's elements still rank before step k+1's),
+        // then the stores.
+        for (uint32_t i = a + lane; i < b; i += 256) {
+            E ee[4]; uint32_t dg[4], sl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { ee[u] = E{}; dg[u] = 0; if (i + 64u * u < b) { ee[u] = load(i + 64u * u); dg[u] = digit(ee[u]); } }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sl[u] = (i + 64u * u < b) ? atomicAdd(&cnt[dg[u] * ST + wave], 1u) : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (i + 64u * u < b) store(sl[u], ee[u]);
         }
         __syncthreads();
         RP_TICK(10);
