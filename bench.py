@@ -402,7 +402,7 @@ def main():
 
         cpu = None
         ratio_vs_ref = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU baseline is a rank-0, N = 1 measurement
             rate = {"deflate": 0.045, "deflate-h": 0.029, "lz77w16": 0.012, "lz77w14": 0.014, "huffman": 0.23, "fse": 0.15}[args.workload]
             mb = args.cpu_sample_mb if args.cpu_sample_mb else min(n / 1e6, max(4.0, 5.0 * rate * 1e3))
             nsamp = int(mb * 1e6) // BLOCK * BLOCK or min(n, BLOCK)

@@ -15,7 +15,10 @@
 #define LZ2_THREADS   512                   // k_lz2_find workgroup
 #endif
 #define LZ2_NWAVES    (LZ2_THREADS / 64)
-#define LZ2_MAXPARTS  32u
+#ifndef LZ2_PARTBITS
+#define LZ2_PARTBITS  5                     // parts per block <= 2^LZ2_PARTBITS (one radix digit of stage 1)
+#endif
+#define LZ2_MAXPARTS  (1u << LZ2_PARTBITS)
 static_assert(LZ2_CAP % LZ2_THREADS == 0, "entries per thread must be whole");
 #define LZ2_BIG       8u                    // clusters of at least this many entries leave k_lz2_find
 #define LZ2_WAVE      128u                  // ... and from this size on a whole wave replays one cluster

@@ -42,7 +42,7 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     __shared__ __attribute__((aligned(16))) uint8_t s_in[LZ_MAX_BLOCK + LZ_TAIL + 16];
     __shared__ uint32_t s_grp[LZ2_NG];               // counts -> inclusive prefix; later the staging area
     __shared__ uint32_t s_safe[LZ2_NG / 32];
-    __shared__ uint32_t s_cnt[17][32];               // 5-bit digits only (<= 32 parts): 2 KiB, not 16 — this kernel shares CUs with the replay kernels
+    __shared__ uint32_t s_cnt[17][LZ2_MAXPARTS];               // 5-bit digits only (<= 32 parts): 2 KiB, not 16 — this kernel shares CUs with the replay kernels
     __shared__ uint64_t s_scan64[18];
     __shared__ uint32_t s_scan32[18];
     __shared__ uint32_t s_thr[LZ2_MAXPARTS + 1];     // part k = home' in [s_thr[k], s_thr[k+1])
@@ -232,7 +232,7 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     __syncthreads();
     for (uint32_t p = tid; p < n; p += 1024) part_in[p] = s_gpart[((home_of(p) - base) & Tmask) >> gshift];
     __syncthreads();
-    radix_pass_1024<5, uint32_t>(n, s_cnt,
+    radix_pass_1024<LZ2_PARTBITS, uint32_t>(n, s_cnt,
         [&](uint32_t i) { return i | ((uint32_t)part_in[i] << 16); },
         [&](uint32_t e) { return e >> 16; },
         [&](uint32_t j, uint32_t e) { plist[j] = (uint16_t)e; }, (P.flags & LZP_ARANK) != 0);
