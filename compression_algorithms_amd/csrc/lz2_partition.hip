@@ -242,3 +242,31 @@ void lz2_launch_partition(const uint8_t *d_in, uint64_t n, const LzP &P, const L
 {
     hipLaunchKernelGGL(k_lz2_partition, dim3(nb), dim3(1024), 0, s, d_in, n, P, sc, block0);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Self-test of block_exclusive_scan with a NON-commutative operator (development / test hook, not in the public header):
+// composition of the partition's own x -> max(x + a, b) maps over 1024 threads must equal the serial left-to-right
+// composition.  The overflow certificate is only a certificate if earlier maps are applied first.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024)
+void k_selftest_scan(const int32_t *__restrict__ ab, uint64_t *__restrict__ out)
+{
+    __shared__ uint64_t s_tmp[18];
+    const int tid = threadIdx.x;
+    uint64_t tot;
+    const uint64_t pre = block_exclusive_scan<uint64_t>(am_pack(AffMax{ab[2 * tid], ab[2 * tid + 1]}), OpAm(), am_pack(AffMax{0, AM_NEG}), s_tmp, &tot);
+    out[tid] = pre;
+    if (tid == 0) out[1024] = tot;
+}
+
+extern "C" int mi_selftest_scan(mi_ctx *ctx, const int32_t *h_ab /* [1024][2] */, uint64_t *h_out /* [1025] packed a << 32 | b */)
+{
+    if (!ctx || !h_ab || !h_out) return 0;
+    int32_t *d_ab = nullptr; uint64_t *d_out = nullptr;
+    if (hipMalloc(&d_ab, 2048 * 4) != hipSuccess || hipMalloc(&d_out, 1025 * 8) != hipSuccess) return 0;
+    int ok = hipMemcpy(d_ab, h_ab, 2048 * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) { hipLaunchKernelGGL(k_selftest_scan, dim3(1), dim3(1024), 0, 0, d_ab, d_out); ok = hipDeviceSynchronize() == hipSuccess; }
+    if (ok) ok = hipMemcpy(h_out, d_out, 1025 * 8, hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d_ab); (void)hipFree(d_out);
+    return ok;
+}

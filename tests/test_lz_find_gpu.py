@@ -84,3 +84,27 @@ def test_pure_runs_closed_form(flavour, wbits):
     data = np.concatenate([np.zeros(65536, np.uint8), np.full(65536, 0x41, np.uint8),
                            synth.enwik_like(65536, seed=3).numpy(), np.full(30000, 0xFF, np.uint8)])
     _check(data, flavour, wbits)
+
+
+def test_block_scan_composes_earlier_maps_first():
+    """The partition's overflow certificate is a prefix scan of non-commutative maps x -> max(x + a, b): the device scan must
+    equal the serial left-to-right composition (round 1's wave-level step composed them backwards and under-estimated
+    the carry behind a long run — parity held only because such cuts rarely change find()'s answer)."""
+    import ctypes as C
+    from compression_algorithms_amd.context import default_context
+    ctx = default_context()
+    rng = np.random.default_rng(5)
+    NEG = -(1 << 28)
+    for trial in range(6):
+        c = rng.integers(0, 9, 1024)
+        c[rng.integers(0, 1024)] += int(rng.integers(800, 3000))            # one long run somewhere
+        ab = np.stack([c - 64, np.where(c > 0, c - 1, 0)], axis=1).astype(np.int32)
+        out = np.zeros(1025, np.uint64)
+        ctx.L.mi_selftest_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        assert ctx.L.mi_selftest_scan(ctx.h, ab.ctypes.data, out.ctypes.data) == 1
+        a_run, b_run = 0, NEG
+        for t in range(1024):
+            got_a, got_b = np.int32(np.uint32(int(out[t]) >> 32)), np.int32(np.uint32(int(out[t]) & 0xFFFFFFFF))
+            assert (int(got_a), int(got_b)) == (a_run, b_run), (trial, t)
+            a2, b2 = int(ab[t, 0]), int(ab[t, 1])
+            a_run, b_run = max(a_run + a2, NEG), max(max(b_run + a2, NEG), b2)
