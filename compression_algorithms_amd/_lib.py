@@ -54,7 +54,7 @@ EXPORTS = [
     "mi_huffman_encode_dev", "mi_huffman_encode", "mi_huffman_encode2", "mi_huffman_decode_dev", "mi_huffman_decode",
     "mi_huffman_num_tiles", "mi_huffman_hist_dev", "mi_huffman_build_dev", "mi_huffman_encode_with_tree_dev",
     "mi_huffman_build", "mi_huffman_encode_with_codes",
-    "mi_lz_encode_dev", "mi_lz_encode", "mi_lz_decode_dev", "mi_lz_decode", "mi_lz_find_all_dev",
+    "mi_lz_encode_dev", "mi_lz_encode", "mi_lz_decode_dev", "mi_lz_decode", "mi_lz_find_all_dev", "mi_lz_find_all32_dev",
     "mi_deflate_h_bound_bytes", "mi_deflate_h_encode_dev", "mi_deflate_h_decode_dev", "mi_deflate_h_encode", "mi_deflate_h_decode",
     "mi_fse_block_bound", "mi_fse_encode_dev", "mi_fse_decode_dev", "mi_fse_encode", "mi_fse_decode", "mi_fse_normalise_dev",
     "mi_set_profiling", "mi_get_kernel_times",
@@ -107,6 +107,7 @@ def lib():
             L.mi_lz_decode_dev.argtypes = [vp, C.POINTER(LzParams), vp, u64, vp, vp, u64, vp]
             L.mi_lz_decode.argtypes = [vp, C.POINTER(LzParams), vp, u64, vp, vp, u64]
             L.mi_lz_find_all_dev.argtypes = [vp, C.POINTER(LzParams), vp, u64, vp, vp]
+            L.mi_lz_find_all32_dev.argtypes = [vp, C.POINTER(LzParams), vp, u64, vp, vp]
         if hasattr(L, "mi_deflate_h_encode_dev"):
             L.mi_deflate_h_bound_bytes.restype = u64
             L.mi_deflate_h_bound_bytes.argtypes = [u64, C.POINTER(LzParams)]

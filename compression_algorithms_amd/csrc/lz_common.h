@@ -60,6 +60,22 @@ struct LzScratch {
 };
 #define LZ_SLOT_WORDS  (LZ_MAX_BLOCK / 2 + 16)     // 2 bytes per input byte worst case (+ slack), in u32
 
+// scratch of the HBM-resident finder for blocks above 64 KiB (lzw.hip)
+struct LzwScratch {
+    uint64_t *eA, *eB;          // [nb][S] sort ping-pong: key << 32 | position
+    uint32_t *gid;              // [nb][S] cluster number by position
+    uint32_t *rd;               // [nb][S] dense home slot by position
+    uint32_t *cstart;           // [nb][S + 2] first (cluster, time)-sorted index of every cluster; [ncl] = n
+    uint32_t *ncl;              // [nb][4] clusters, flag: bucket 0 is inside cluster 0
+    uint8_t  *t_live;           // [nb][S + 64] literal table, by dense bucket
+    uint32_t *t_pos, *t_mix;    // [nb][S]
+    uint32_t *slot_of;          // [nb][S] bucket of the k-th (cluster, time)-sorted entry (for its retirement)
+    uint32_t *cand;             // [nb][S] find() by position (LZW_NONE = none)
+    uint32_t *slot;             // [nb][slot_words] block-local token stream
+    uint64_t *block_bits;       // [nb + 1]
+    uint32_t  S, slot_words;
+};
+
 // reference hash(): algorithms/lz77/lz77.c:13-41 == algorithms/deflate/lz77.c:14-42
 __device__ __forceinline__ uint32_t lz_mix32(uint32_t w)
 {

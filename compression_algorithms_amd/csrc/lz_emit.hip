@@ -388,7 +388,7 @@ __device__ __forceinline__ uint32_t extract_bits(const uint32_t *w, uint64_t lo,
 // one thread per output dword of the batch's bit range [base, base + total)
 __global__ __launch_bounds__(256)
 void k_lz_concat(const uint32_t *__restrict__ slots, const uint64_t *__restrict__ excl_local, uint32_t nb,
-                 const uint64_t *__restrict__ base_bits, uint32_t *__restrict__ out, uint64_t cap_words)
+                 const uint64_t *__restrict__ base_bits, uint32_t *__restrict__ out, uint64_t cap_words, uint32_t slot_words)
 {
     const uint64_t base = *base_bits, total = excl_local[nb];
     const uint64_t wfirst = base >> 5;
@@ -409,7 +409,7 @@ void k_lz_concat(const uint32_t *__restrict__ slots, const uint64_t *__restrict_
             const uint64_t se = be < end ? be : end;
             if (se > pos) {
                 const uint32_t k = (uint32_t)(se - pos);
-                word |= extract_bits(slots + (size_t)i * LZ_SLOT_WORDS, pos - bs, k) << (uint32_t)(pos - g0);
+                word |= extract_bits(slots + (size_t)i * slot_words, pos - bs, k) << (uint32_t)(pos - g0);
                 pos = se;
             }
             if (pos == be) ++i;
@@ -497,6 +497,15 @@ mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t
 uint32_t lz_batch_blocks(uint64_t nblocks);
 
 void defh_launch_encode(const uint32_t *trec, uint32_t *slots, uint64_t *block_bits, uint32_t nb, hipStream_t s);
+
+// lzw.hip: the lz77 flavour on blocks above 64 KiB
+size_t    lzw_scratch_bytes(uint32_t nb, uint32_t block);
+void      lzw_carve(mi_ctx *ctx, uint32_t nb, uint32_t block, LzwScratch *sc);
+uint32_t  lzw_batch_blocks(uint64_t nblocks, uint32_t block);
+mi_status lzw_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb, const LzwScratch &sc, hipStream_t s);
+void      lzw_launch_parse_emit(const uint8_t *d_in, uint64_t n, const LzP &P, const LzwScratch &sc, uint64_t block0, uint32_t nb, hipStream_t s);
+void      lzw_launch_decode(const uint8_t *d_stream, uint64_t stream_bytes, const uint64_t *d_block_bits, const LzP &P, uint8_t *d_out,
+                            uint64_t n, uint64_t nblocks, uint32_t *err, hipStream_t s);
 extern "C" uint64_t mi_deflate_h_bound_bytes(uint64_t n, const mi_lz_params *p);
 
 // mode_h = 0: the reference's token stream.  mode_h = 1: the same tokens, entropy coded per block (defh.hip); the
@@ -513,6 +522,33 @@ static mi_status lz_encode_impl(mi_ctx *ctx, const mi_lz_params *p, const uint8_
     hipStream_t s = (hipStream_t)stream;
     const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block, ctx->lds_rank_ok ? LZP_ARANK : 0u};
     const uint64_t nblocks = (n + P.block - 1) / P.block;
+    if (P.block > LZ_MAX_BLOCK) {
+        // blocks above 64 KiB (lz77 flavour): the HBM-resident finder of lzw.hip, one stream, batches sized by workspace
+        if (mode_h) return MI_ERR_ARG;
+        const uint32_t nbw = lzw_batch_blocks(nblocks, P.block);
+        st = mi_ws_reserve(ctx, lzw_scratch_bytes(nbw, P.block) + 4096);
+        if (st) return st;
+        LzwScratch ws;
+        lzw_carve(ctx, nbw, P.block, &ws);
+        uint64_t *base_bits_w = reinterpret_cast<uint64_t *>((uint8_t *)ctx->ws + lzw_scratch_bytes(nbw, P.block));
+        MI_HIP(ctx, hipMemsetAsync(base_bits_w, 0, 8, s));
+        if (nblocks == 0) { MI_HIP(ctx, hipMemsetAsync(d_block_bits, 0, 8, s)); return MI_OK; }
+        for (uint64_t b0 = 0; b0 < nblocks; b0 += nbw) {
+            const uint32_t nb = (uint32_t)((nblocks - b0) < nbw ? (nblocks - b0) : nbw);
+            st = lzw_find(ctx, P, d_in, n, b0, nb, ws, s);
+            if (st) return st;
+            { mi_prof_scope pr(ctx, "k_lzw_parse_emit", s, (uint64_t)nb * P.block);
+              lzw_launch_parse_emit(d_in, n, P, ws, b0, nb, s); }
+            hipLaunchKernelGGL(k_lz_scan_blocks, dim3(1), dim3(1024), 0, s, ws.block_bits, nb, base_bits_w, ws.block_bits, d_block_bits + b0);
+            { mi_prof_scope pr(ctx, "k_lz_concat", s, (uint64_t)nb * P.block);
+              const uint64_t typw = (uint64_t)nb * (P.block / 4 + 64);
+              hipLaunchKernelGGL(k_lz_concat, dim3((unsigned)((typw + 255) / 256 < 65535 ? (typw + 255) / 256 : 65535)), dim3(256), 0, s, ws.slot, ws.block_bits, nb,
+                                 base_bits_w, reinterpret_cast<uint32_t *>(d_out), cap_bytes / 4, ws.slot_words); }
+            hipLaunchKernelGGL(k_lz_advance, dim3(1), dim3(1), 0, s, base_bits_w, ws.block_bits, nb);
+        }
+        MI_HIP(ctx, hipGetLastError());
+        return MI_OK;
+    }
     const uint32_t nbmax = lz_batch_blocks(nblocks);
     // three stages on three streams, MI_SETS scratch sets in rotation:
     //   `s`          partition + find of batch i+2          (LDS heavy, two workgroups per CU)
@@ -549,7 +585,7 @@ static mi_status lz_encode_impl(mi_ctx *ctx, const mi_lz_params *p, const uint8_
             mi_prof_scope pr(ctx, "k_lz_concat", sp, (uint64_t)nb * P.block);
             const uint64_t typw = (uint64_t)nb * (P.block / 4 + 64);   // about one output byte per input byte; the kernel strides
             hipLaunchKernelGGL(k_lz_concat, dim3((unsigned)((typw + 255) / 256)), dim3(256), 0, sp, sc[k].slot, excl_local, nb,
-                               base_bits, reinterpret_cast<uint32_t *>(d_out), cap_bytes / 4);
+                               base_bits, reinterpret_cast<uint32_t *>(d_out), cap_bytes / 4, (uint32_t)LZ_SLOT_WORDS);
         }
         hipLaunchKernelGGL(k_lz_advance, dim3(1), dim3(1), 0, sp, base_bits, excl_local, nb);
         if (overlap) MI_HIP(ctx, hipEventRecord(ctx->ev_done[k], sp));
@@ -639,7 +675,11 @@ extern "C" mi_status mi_lz_decode_dev(mi_ctx *ctx, const mi_lz_params *p, const 
     const uint64_t nblocks = (n + P.block - 1) / P.block;
     uint32_t *err = mi_err_slot(ctx, s);
     if (!err) return MI_ERR_HIP;
-    {
+    if (P.block > LZ_MAX_BLOCK) {
+        if (((uintptr_t)d_out & 15u) != 0) return MI_ERR_ARG;             // 16-byte flushes of the decoder's ring
+        mi_prof_scope pr(ctx, "k_lzw_decode", s, n);
+        lzw_launch_decode(d_stream, stream_bytes, d_block_bits, P, d_out, n, nblocks, err, s);
+    } else {
         mi_prof_scope pr(ctx, "k_lz_decode", s, n);
         hipLaunchKernelGGL(k_lz_decode, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, stream_bytes, d_block_bits, P, d_out, n, err);
     }

@@ -574,7 +574,9 @@ mi_status lz_check_params(const mi_lz_params *p)
     if (p->wbits < 8 || p->wbits > 16) return MI_ERR_ARG;
     if (p->lbits < 3 || p->lbits > 8) return MI_ERR_ARG;
     if (p->tbits < 17 || p->tbits > 24) return MI_ERR_ARG;
-    if (p->block < 1 || p->block > LZ_MAX_BLOCK) return MI_ERR_ARG;
+    // blocks above 64 KiB: the lz77 flavour only (lzw.hip), multiples of 256 bytes up to 1 MiB, so that WINDOW_BITS 16 slides
+    if (p->block < 1) return MI_ERR_ARG;
+    if (p->block > LZ_MAX_BLOCK && (p->deflate || p->block > (1u << 20) || (p->block & 255u) || p->lbits > 5)) return MI_ERR_ARG;
     if (1u + p->wbits + p->lbits > 32) return MI_ERR_ARG;
     return MI_OK;
 }
@@ -645,6 +647,43 @@ extern "C" mi_status mi_lz_find_all_dev(mi_ctx *ctx, const mi_lz_params *p, cons
             const uint64_t off = (b0 + i) * (uint64_t)P.block;
             const uint64_t len = (n - off) < P.block ? (n - off) : P.block;
             MI_HIP(ctx, hipMemcpyAsync(d_cand + off, sc.cand + (size_t)i * LZ_MAX_BLOCK, len * 2, hipMemcpyDeviceToDevice, s));
+        }
+    }
+    return MI_OK;
+}
+
+
+// lzw.hip
+size_t    lzw_scratch_bytes(uint32_t nb, uint32_t block);
+void      lzw_carve(mi_ctx *ctx, uint32_t nb, uint32_t block, LzwScratch *sc);
+uint32_t  lzw_batch_blocks(uint64_t nblocks, uint32_t block);
+mi_status lzw_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb, const LzwScratch &sc, hipStream_t s);
+
+// the same hook for blocks above 64 KiB (lz77 flavour, lzw.hip): 32-bit positions, 0xFFFFFFFF = none
+extern "C" mi_status mi_lz_find_all32_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_in, uint64_t n,
+                                          uint32_t *d_cand, void *stream)
+{
+    if (!ctx || !d_in || !d_cand) return MI_ERR_ARG;
+    mi_status st = lz_check_params(p);
+    if (st) return st;
+    if (p->block <= LZ_MAX_BLOCK) return MI_ERR_ARG;
+    if (n == 0) return MI_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block, ctx->lds_rank_ok ? LZP_ARANK : 0u};
+    const uint64_t nblocks = (n + P.block - 1) / P.block;
+    const uint32_t nbw = lzw_batch_blocks(nblocks, P.block);
+    st = mi_ws_reserve(ctx, lzw_scratch_bytes(nbw, P.block) + 4096);
+    if (st) return st;
+    LzwScratch ws;
+    lzw_carve(ctx, nbw, P.block, &ws);
+    for (uint64_t b0 = 0; b0 < nblocks; b0 += nbw) {
+        const uint32_t nb = (uint32_t)((nblocks - b0) < nbw ? (nblocks - b0) : nbw);
+        st = lzw_find(ctx, P, d_in, n, b0, nb, ws, s);
+        if (st) return st;
+        for (uint32_t i = 0; i < nb; ++i) {
+            const uint64_t off = (b0 + i) * (uint64_t)P.block;
+            const uint64_t len = (n - off) < P.block ? (n - off) : P.block;
+            MI_HIP(ctx, hipMemcpyAsync(d_cand + off, ws.cand + (size_t)i * ws.S, len * 4, hipMemcpyDeviceToDevice, s));
         }
     }
     return MI_OK;

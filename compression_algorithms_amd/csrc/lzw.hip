@@ -1,0 +1,576 @@
+// lzw.hip — the lz77 flavour on blocks LARGER than 64 KiB (up to 1 MiB), so that a 64 KiB window really slides
+// (SURVEY.md 8d config 2 "64 KiB ... 1 MiB").  Replaces the same reference functions as the LDS-resident
+// finder — hash / insert_hash_table / find and the loop of lz77_compress, algorithms/lz77/lz77.c:13-108,264-345 — for
+// blocks the u16 / 65 536-entry kernels of lz2_*.hip cannot hold.
+//
+// Same idea, different residence.  find() at p is a function of the block prefix (every position is inserted once, in
+// order), and a probe cluster — a maximal run of the parking sweep over the homes of ALL entries of the block — owns
+// exactly as many consecutive buckets as it has entries and never meets another cluster.  So:
+//   k_lzw_keys          mix32(word) | position for every position              (the hash, lz77.c:13-41)
+//   k_lzw_sort          stable LSD radix sort by home bucket, through HBM      (3 x 8 bits)
+//   k_lzw_sweep         parking sweep -> cluster number and dense home slot of every position
+//   k_lzw_sort (again)  positions by (cluster, time)
+//   k_lzw_heads         first sorted index of every cluster; singletons answered ("none")
+//   k_lzw_replay        one WAVE per cluster replays its entries in time order against the cluster's own slice of a LITERAL
+//                       table in HBM (live flag, position, mixed word per dense bucket): 64 buckets per probe step,
+//                       FIFO retirement by position (lz77.c:70-76), the one-time spurious clear of bucket 0
+//   k_lzw_parse_emit    one workgroup per block walks its 64 KiB segments in order: match lengths from the bytes in HBM/L2,
+//                       the greedy chain by composed 64-position exit tables (as k_lz_parse_emit) entered at the offset the
+//                       previous segment left, tokens LSB-first (lz77.c:290-330) appended to the block's slot
+//   k_lzw_decode        one wave per block, a 128 KiB ring in LDS (a match reaches back < 64 KiB)
+// The table state lives in HBM and is touched through agent-scope atomics (the wave re-reads what it wrote a moment ago;
+// plain loads could hit stale lines of the CU's L1).  This path is exact, not fast: a cluster is a serial chain of HBM/L2
+// round trips.  It exists so that WINDOW_BITS 16 means what it says; DESIGN.md 6 says what would make it quick.
+#include "lz_common.h"
+#include <stdlib.h>
+
+#define LZW_MAX_BLOCK   (1u << 20)
+#define LZW_SEG         65536u                    // parse/emit segment
+#define LZW_NONE        0xFFFFFFFFu
+#define LZW_SLOT_WORDS(block) ((uint32_t)(((uint64_t)(block) * 9u + 7u) / 8u / 4u + 24u))     // 9 bits per byte worst case + one overshoot
+
+// 4 bytes at an arbitrary offset of the block; bytes past the block end read as zero (the parity definition of the
+// reference's over-read)
+__device__ __forceinline__ uint32_t lzw_word(const uint8_t *src, uint32_t p, uint32_t n)
+{
+    if (p + 8u <= n && ((((uintptr_t)src) & 3u) == 0)) {
+        const uint32_t *a = reinterpret_cast<const uint32_t *>(src + (p & ~3u));
+        const uint64_t v = (uint64_t)a[0] | ((uint64_t)a[1] << 32);
+        return (uint32_t)(v >> ((p & 3u) * 8u));
+    }
+    uint32_t w = 0;
+    for (uint32_t k = 0; k < 4 && p + k < n; ++k) w |= (uint32_t)src[p + k] << (8 * k);
+    return w;
+}
+
+__global__ __launch_bounds__(256)
+void k_lzw_keys(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, LzwScratch sc, uint64_t block0)
+{
+    const uint32_t lb = blockIdx.y;
+    const uint64_t off = (block0 + lb) * (uint64_t)P.block;
+    const uint32_t n = (uint32_t)((n_total - off) < P.block ? (n_total - off) : P.block);
+    const uint8_t *src = in + off;
+    uint64_t *e = sc.eA + (size_t)lb * sc.S;
+    for (uint32_t p = blockIdx.x * 256u + threadIdx.x; p < n; p += gridDim.x * 256u)
+        e[p] = ((uint64_t)lz_mix32(lzw_word(src, p, n)) << 32) | p;
+}
+
+// stable LSD radix sort of the block's u64 elements by `bits` key bits starting at `shift` of (element >> 32) & mask,
+// 8 bits per pass, ping-pong through HBM; one workgroup per block.  Result in eA when the number of passes is even.
+__global__ __launch_bounds__(1024)
+void k_lzw_sort(uint64_t n_total, LzP P, LzwScratch sc, uint64_t block0, uint32_t key_mask, uint32_t npass, int from_gid)
+{
+    __shared__ uint32_t s_cnt[17][256];
+    const uint32_t lb = blockIdx.x;
+    const uint64_t off = (block0 + lb) * (uint64_t)P.block;
+    const uint32_t n = (uint32_t)((n_total - off) < P.block ? (n_total - off) : P.block);
+    uint64_t *a = sc.eA + (size_t)lb * sc.S, *b = sc.eB + (size_t)lb * sc.S;
+    if (from_gid) {                                   // second sort: (cluster << 32 | position) in time order
+        const uint32_t *g = sc.gid + (size_t)lb * sc.S;
+        for (uint32_t p = threadIdx.x; p < n; p += 1024) a[p] = ((uint64_t)g[p] << 32) | p;
+        __syncthreads();
+    }
+    const bool arank = (P.flags & LZP_ARANK) != 0;
+    for (uint32_t pass = 0; pass < npass; ++pass) {
+        const uint64_t *src = (pass & 1u) ? b : a;
+        uint64_t *dst = (pass & 1u) ? a : b;
+        const uint32_t sh = 8u * pass;
+        radix_pass_1024<8, uint64_t>(n, s_cnt,
+            [&](uint32_t i) { return __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },   // this CU's L1 may hold lines of an earlier pass
+            [&](uint64_t e) { return (((uint32_t)(e >> 32) & key_mask) >> sh) & 255u; },
+            [&](uint32_t j, uint64_t e) { dst[j] = e; }, arank);
+        __threadfence();
+        __syncthreads();
+    }
+}
+
+// parking sweep over the home-sorted order (in `srt`): cluster heads are the weak prefix maxima of home_k - k
+// (DESIGN.md 2); dense home slot = index of the cluster's head + (home - the head's home).
+__global__ __launch_bounds__(1024)
+void k_lzw_sweep(uint64_t n_total, LzP P, LzwScratch sc, uint64_t block0, int sorted_in_b)
+{
+    __shared__ int32_t  s_i32[18];
+    __shared__ uint64_t s_u64[18];
+    __shared__ int32_t  s_run;
+    __shared__ uint32_t s_gs, s_base, s_count;
+    constexpr uint32_t CH = 8;
+    const uint32_t lb = blockIdx.x, tid = threadIdx.x;
+    const uint64_t off = (block0 + lb) * (uint64_t)P.block;
+    const uint32_t n = (uint32_t)((n_total - off) < P.block ? (n_total - off) : P.block);
+    const uint64_t *srt = (sorted_in_b ? sc.eB : sc.eA) + (size_t)lb * sc.S;
+    uint32_t *gid = sc.gid + (size_t)lb * sc.S, *rd = sc.rd + (size_t)lb * sc.S;
+    const uint32_t Tmask = (1u << P.tbits) - 1u;
+    if (tid == 0) { s_run = INT32_MIN; s_gs = 0; s_base = 0; s_count = 0; }
+    __syncthreads();
+    for (uint32_t t0 = 0; t0 < n; t0 += 1024u * CH) {
+        const uint32_t k0 = t0 + tid * CH, k1 = (k0 + CH < n) ? k0 + CH : n;
+        uint32_t rp[CH]; int32_t rh[CH];
+        int32_t mx = INT32_MIN;
+#pragma unroll
+        for (uint32_t c = 0; c < CH; ++c) {
+            const uint32_t k = k0 + c;
+            rp[c] = 0; rh[c] = 0;
+            if (k < k1) {
+                const uint64_t e = srt[k];
+                rp[c] = (uint32_t)e; rh[c] = (int32_t)((uint32_t)(e >> 32) & Tmask);
+                const int32_t g = rh[c] - (int32_t)k;
+                mx = g > mx ? g : mx;
+            }
+        }
+        int32_t tile_max;
+        int32_t premax = block_exclusive_scan<int32_t>(mx, OpMaxI32(), INT32_MIN, s_i32, &tile_max);
+        const int32_t carry_run = s_run;
+        premax = premax > carry_run ? premax : carry_run;
+        // heads in my chunk, the last head's index + 1 (for the carry of the open cluster)
+        uint32_t nheads = 0; int32_t lasthead = -1;
+        {
+            int32_t run = premax;
+#pragma unroll
+            for (uint32_t c = 0; c < CH; ++c) {
+                const uint32_t k = k0 + c;
+                if (k < k1) {
+                    const int32_t g = rh[c] - (int32_t)k;
+                    const bool head = (k == 0) || (g >= run);
+                    run = g > run ? g : run;
+                    if (head) { ++nheads; lasthead = (int32_t)k; }
+                }
+            }
+        }
+        struct OpHL {           // heads: sum (low 32); last head index + 1: max (high 32)
+            __device__ uint64_t operator()(uint64_t a, uint64_t b) const {
+                const uint64_t s0 = (a & 0xFFFFFFFFull) + (b & 0xFFFFFFFFull), a1 = a >> 32, b1 = b >> 32;
+                return (s0 & 0xFFFFFFFFull) | ((a1 > b1 ? a1 : b1) << 32);
+            }
+        };
+        uint64_t tot2;
+        const uint64_t pre2 = block_exclusive_scan<uint64_t>((uint64_t)nheads | ((uint64_t)(uint32_t)(lasthead + 1) << 32), OpHL(), 0ull, s_u64, &tot2);
+        const uint32_t count0 = s_count;
+        uint32_t cur_gs = s_gs, cur_base = s_base, cur_gid = count0 + (uint32_t)(pre2 & 0xFFFFFFFFull) - 1u;   // the cluster open at my first entry
+        const int32_t gs_carry = (int32_t)(pre2 >> 32) - 1;                 // last head before my chunk inside this tile
+        if (gs_carry >= 0) { cur_gs = (uint32_t)gs_carry; cur_base = (uint32_t)((uint32_t)(srt[cur_gs] >> 32) & Tmask); }
+        {
+            int32_t run = premax;
+            uint32_t seen = 0;
+#pragma unroll
+            for (uint32_t c = 0; c < CH; ++c) {
+                const uint32_t k = k0 + c;
+                if (k < k1) {
+                    const int32_t h = rh[c], g = h - (int32_t)k;
+                    const bool head = (k == 0) || (g >= run);
+                    run = g > run ? g : run;
+                    if (head) { cur_gs = k; cur_base = (uint32_t)h; cur_gid = count0 + (uint32_t)(pre2 & 0xFFFFFFFFull) + seen; ++seen; }
+                    gid[rp[c]] = cur_gid;
+                    rd[rp[c]] = cur_gs + ((uint32_t)h - cur_base);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            s_run = tile_max > carry_run ? tile_max : carry_run;
+            s_count = count0 + (uint32_t)(tot2 & 0xFFFFFFFFull);
+            const int32_t lh = (int32_t)(tot2 >> 32) - 1;                   // last head of the tile, if any
+            if (lh >= 0) { s_gs = (uint32_t)lh; s_base = (uint32_t)((uint32_t)(srt[lh] >> 32) & Tmask); }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        uint32_t *nc = sc.ncl + (size_t)lb * 4;
+        nc[0] = s_count;
+        nc[1] = (n && ((uint32_t)(srt[0] >> 32) & Tmask) == 0u) ? 1u : 0u;   // cluster 0 starts at bucket 0: the spurious clear is its
+    }
+}
+
+// first sorted index of every cluster (clusters are contiguous in the (cluster, time) order); a cluster of one entry is
+// answered here: its only find() precedes its only insert
+__global__ __launch_bounds__(256)
+void k_lzw_heads(uint64_t n_total, LzP P, LzwScratch sc, uint64_t block0, int sorted_in_b)
+{
+    const uint32_t lb = blockIdx.y;
+    const uint64_t off = (block0 + lb) * (uint64_t)P.block;
+    const uint32_t n = (uint32_t)((n_total - off) < P.block ? (n_total - off) : P.block);
+    const uint64_t *srt = (sorted_in_b ? sc.eB : sc.eA) + (size_t)lb * sc.S;
+    uint32_t *cs = sc.cstart + (size_t)lb * (sc.S + 2);
+    uint32_t *cand = sc.cand + (size_t)lb * sc.S;
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n; k += gridDim.x * 256u) {
+        const uint32_t g = (uint32_t)(srt[k] >> 32);
+        const bool head = k == 0 || (uint32_t)(srt[k - 1] >> 32) != g;
+        if (head) {
+            cs[g] = k;
+            if (k + 1 == n || (uint32_t)(srt[k + 1] >> 32) != g) cand[(uint32_t)srt[k]] = LZW_NONE;
+        }
+        if (k + 1 == n) cs[g + 1] = n;
+    }
+}
+
+// coherent (L2) accesses to the table state this wave keeps rewriting
+template <typename T> __device__ __forceinline__ T lzw_ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T> __device__ __forceinline__ void lzw_st(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// one wave per cluster of >= 2 entries: the literal table of lz77.c:55-108 restricted to the cluster's own buckets
+__global__ __launch_bounds__(64)
+void k_lzw_replay(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, LzwScratch sc, uint64_t block0, uint32_t nb)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t W = 1u << P.wbits;
+    for (uint32_t lb = 0; lb < nb; ++lb) {
+        const uint64_t off = (block0 + lb) * (uint64_t)P.block;
+        const uint32_t n = (uint32_t)((n_total - off) < P.block ? (n_total - off) : P.block);
+        const uint8_t *src = in + off;
+        const uint32_t ncl = sc.ncl[(size_t)lb * 4], zero_in_0 = sc.ncl[(size_t)lb * 4 + 1];
+        const uint64_t *srt = sc.eA + (size_t)lb * sc.S;            // (cluster, time) order: three passes end in eB, see host
+        const uint32_t *cs = sc.cstart + (size_t)lb * (sc.S + 2);
+        const uint32_t *rd = sc.rd + (size_t)lb * sc.S;
+        uint8_t  *live = sc.t_live + (size_t)lb * (sc.S + 64);
+        uint32_t *tpos = sc.t_pos + (size_t)lb * sc.S, *tmix = sc.t_mix + (size_t)lb * sc.S, *slot_of = sc.slot_of + (size_t)lb * sc.S;
+        uint32_t *cand = sc.cand + (size_t)lb * sc.S;
+        for (uint32_t c = blockIdx.x; c < ncl; c += gridDim.x) {
+            const uint32_t s = cs[c], e = cs[c + 1], m = e - s;
+            if (m < 2) continue;
+            // the cluster's dense buckets are [s, e): its head's dense slot is its own sorted index in the HOME order, which
+            // the sweep used as the base — and the (cluster, time) order permutes entries only inside [s, e)
+            const uint32_t lo = s, hi = e;
+            uint32_t ev = s;
+            bool anom_pending = (c == 0u) && zero_in_0;
+            for (uint32_t k = s; k < e; ++k) {
+                const uint32_t p = (uint32_t)srt[k];
+                const uint32_t r = rd[p];
+                const uint32_t x = lz_mix32(lzw_word(src, p, n));
+                // FIFO retirement: insertion q + W clears the bucket insertion q wrote, whoever sits there now (lz77.c:70-76)
+                while (ev < k) {
+                    const uint32_t q = (uint32_t)srt[ev];
+                    if ((uint64_t)q + W >= (uint64_t)p) break;
+                    if (lane == 0) lzw_st<uint8_t>(&live[lzw_ld(&slot_of[ev])], (uint8_t)0);
+                    ++ev;
+                }
+                // the ring starts zero-filled: insertion W-1 clears bucket 0 once
+                if (anom_pending && p > W - 1u) { if (lane == 0) lzw_st<uint8_t>(&live[lo], (uint8_t)0); anom_pending = false; }
+                __builtin_amdgcn_wave_barrier();
+                // one walk serves find() and the insert: the first bucket that is empty or holds this word ends find();
+                // the first empty bucket takes the entry.  Bucket `hi` is never occupied by this cluster (parking bound) and a
+                // probe that reached it would find nothing of this word beyond: it reads as empty.
+                uint32_t res = LZW_NONE, free_b = LZW_NONE;
+                bool found_done = false;
+                for (uint32_t b0 = r; free_b == LZW_NONE; b0 += 64u) {
+                    const uint32_t b = b0 + lane;
+                    const bool in = b < hi;
+                    const uint32_t lv = in ? (uint32_t)lzw_ld(&live[b]) : 0u;
+                    const uint32_t mx = (in && lv) ? lzw_ld(&tmix[b]) : 0u;
+                    const uint64_t empty = __ballot(!lv);
+                    const uint64_t hit = __ballot(lv && mx == x);
+                    if (!found_done) {
+                        const uint64_t stop = empty | hit;
+                        if (stop) {
+                            const uint32_t f = (uint32_t)__builtin_ctzll(stop);
+                            if ((hit >> f) & 1ull) res = lzw_ld(&tpos[b0 + f]);
+                            found_done = true;
+                        }
+                    }
+                    if (empty) free_b = b0 + (uint32_t)__builtin_ctzll(empty);
+                }
+                if (lane == 0) {
+                    cand[p] = res;
+                    lzw_st<uint32_t>(&tpos[free_b], p);
+                    lzw_st<uint32_t>(&tmix[free_b], x);
+                    lzw_st<uint32_t>(&slot_of[k], free_b);
+                    lzw_st<uint8_t>(&live[free_b], (uint8_t)1);
+                }
+                __threadfence();                          // the next entry's probes must see these stores
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+
+// =============================================================================================
+// parse + emit: one workgroup per block, 64 KiB segments in order
+// =============================================================================================
+__device__ __forceinline__ uint32_t lzw_select_bit(uint64_t m, uint32_t r)
+{
+    for (uint32_t k = 0; k < r; ++k) m &= m - 1;
+    return (uint32_t)__builtin_ctzll(m);
+}
+
+__global__ __launch_bounds__(1024)
+void k_lzw_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, LzwScratch sc, uint64_t block0)
+{
+    __shared__ uint8_t  s_ex[64 * 1024];             // exit tables [64][1024]; later {token base, match base, staging}
+    __shared__ uint8_t  s_L[LZW_SEG];
+    __shared__ uint64_t s_tok[1024], s_mat[1024];
+    __shared__ uint8_t  s_entry[1024];
+    __shared__ uint8_t  s_sexit[32][32];
+    __shared__ uint8_t  s_sentry[33];
+    __shared__ uint32_t s_scan[18];
+    __shared__ uint64_t s_q0, s_q1;
+
+    const int tid = threadIdx.x;
+    const uint32_t lb = blockIdx.x;
+    const uint64_t off = (block0 + lb) * (uint64_t)P.block;
+    const uint32_t n = (uint32_t)((n_total - off) < P.block ? (n_total - off) : P.block);
+    const uint8_t *src = in + off;
+    const uint32_t *cand = sc.cand + (size_t)lb * sc.S;
+    uint32_t *slot = sc.slot + (size_t)lb * sc.slot_words;
+    const uint32_t W = 1u << P.wbits, max_len = (1u << P.lbits) - 1u;      // max_len <= 31 (checked on the host)
+    const uint32_t LB = 9u, MB = 1u + P.wbits + P.lbits;
+    uint32_t e_in = 0;                                // offset at which the greedy chain enters the segment
+    uint64_t qbase = 0;                               // bits emitted so far
+    uint32_t carry = 0;
+
+    for (uint32_t seg0 = 0; seg0 < n; seg0 += LZW_SEG) {
+        const uint32_t ns = (n - seg0) < LZW_SEG ? (n - seg0) : LZW_SEG;
+        // ---- A: token length at every position of the segment (bytes from HBM / L2; zero past the block end)
+        for (uint32_t q = tid; q < ns; q += 1024u) {
+            const uint32_t p = seg0 + q, c = cand[p];
+            uint32_t len = 0;
+            if (c != LZW_NONE && (p - c) != W) {                            // lz77.c:290: distance == W is a literal
+                len = 4;
+                while (len < max_len) {
+                    const uint32_t x = lzw_word(src, c + len, n) ^ lzw_word(src, p + len, n);
+                    if (x) { len += (uint32_t)__builtin_ctz(x) >> 3; break; }
+                    len += 4;
+                }
+                if (len > max_len) len = max_len;
+            }
+            s_L[q] = (uint8_t)len;
+        }
+        __syncthreads();
+        // ---- B: exit offset of every position of a 64-position chunk into the next chunk
+        {
+            const uint32_t c = tid;
+            for (int o = 63; o >= 0; --o) {
+                const uint32_t q = c * 64u + (uint32_t)o;
+                uint32_t e = 0;
+                if (q < ns) {
+                    const uint32_t l = s_L[q];
+                    const uint32_t nx = (uint32_t)o + (l ? l : 1u);
+                    e = nx >= 64u ? nx - 64u : s_ex[nx * 1024u + c];
+                }
+                s_ex[(uint32_t)o * 1024u + c] = (uint8_t)e;
+            }
+        }
+        __syncthreads();
+        {
+            const uint32_t scn = tid >> 5, o = tid & 31u;
+            uint32_t x = o;
+            for (uint32_t c = scn * 32u; c < scn * 32u + 32u; ++c) x = s_ex[x * 1024u + c];
+            s_sexit[scn][o] = (uint8_t)x;
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t e = e_in;
+                for (uint32_t s = 0; s < 32; ++s) { s_sentry[s] = (uint8_t)e; e = s_sexit[s][e]; }
+                s_sentry[32] = (uint8_t)e;                                  // where the chain enters the NEXT segment
+            }
+            __syncthreads();
+            if (tid < 32) {
+                uint32_t xx = s_sentry[tid];
+                for (uint32_t c = tid * 32u; c < tid * 32u + 32u; ++c) { s_entry[c] = (uint8_t)xx; xx = s_ex[xx * 1024u + c]; }
+            }
+            __syncthreads();
+        }
+        // ---- C: token starts of each chunk
+        {
+            const uint32_t c = tid;
+            uint64_t tok = 0, mat = 0;
+            if (c * 64u < ns) {
+                uint32_t o = s_entry[c];
+                while (o < 64u && c * 64u + o < ns) {
+                    const uint32_t l = s_L[c * 64u + o];
+                    tok |= 1ull << o;
+                    if (l) mat |= 1ull << o;
+                    o += l ? l : 1u;
+                }
+            }
+            s_tok[c] = tok; s_mat[c] = mat;
+        }
+        __syncthreads();
+        const uint32_t e_next = s_sentry[32];
+        const uint64_t my_tok = s_tok[tid], my_mat = s_mat[tid];
+        uint32_t ntok = 0, nmat = 0;
+        const uint32_t tbase = block_exclusive_scan<uint32_t>((uint32_t)__popcll(my_tok), OpAddU32(), 0u, s_scan, &ntok);
+        const uint32_t mbase = block_exclusive_scan<uint32_t>((uint32_t)__popcll(my_mat), OpAddU32(), 0u, s_scan, &nmat);
+        uint32_t *tb = reinterpret_cast<uint32_t *>(s_ex);             // [1025]
+        uint32_t *mb = tb + 1026;                                       // [1025]
+        uint32_t *stage = mb + 1026;                                    // [4 * 1024 + 16]
+        constexpr uint32_t TPR = 4;
+        uint16_t *tch = reinterpret_cast<uint16_t *>(stage + TPR * 1024 + 16);   // [<= 1024] chunk that holds token 64 * k
+        tb[tid] = tbase; mb[tid] = mbase;
+        if (tid == 0) { tb[1024] = ntok; mb[1024] = nmat; }
+        for (uint32_t mlt = (tbase + 63u) & ~63u; mlt < tbase + (uint32_t)__popcll(my_tok); mlt += 64u) tch[mlt >> 6] = (uint16_t)tid;
+        __syncthreads();
+        auto chunk_of = [&](uint32_t t) -> uint32_t { uint32_t c = tch[t >> 6]; while (tb[c + 1] <= t) ++c; return c; };
+        // ---- D: emit, 4096 tokens per barrier round, appended behind the bits of the earlier segments
+        for (uint32_t t0 = 0; t0 < ntok; t0 += TPR * 1024u) {
+            uint64_t q[TPR]; uint32_t v[TPR], nbits[TPR]; bool valid[TPR];
+#pragma unroll
+            for (uint32_t u = 0; u < TPR; ++u) {
+                const uint32_t t = t0 + u * 1024u + (uint32_t)tid;
+                valid[u] = t < ntok; q[u] = 0; v[u] = 0; nbits[u] = 0;
+                if (valid[u]) {
+                    const uint32_t c = chunk_of(t), o = lzw_select_bit(s_tok[c], t - tb[c]);
+                    const uint32_t p = seg0 + c * 64u + o;
+                    const uint32_t mbefore = mb[c] + (uint32_t)__popcll(s_mat[c] & ((1ull << o) - 1ull));
+                    q[u] = qbase + (uint64_t)(t - mbefore) * LB + (uint64_t)mbefore * MB;
+                    if ((s_mat[c] >> o) & 1ull) {
+                        const uint32_t d = p - cand[p], l = s_L[c * 64u + o];
+                        v[u] = 1u | (d << 1) | (l << (1u + P.wbits)); nbits[u] = MB;     // flag, offset (wbits), length (lbits)
+                    } else { v[u] = (uint32_t)src[p] << 1; nbits[u] = LB; }
+                    if (u == 0 && tid == 0) s_q0 = q[0];
+                    if (t == ntok - 1 || (u == TPR - 1 && tid == 1023)) s_q1 = q[u] + nbits[u];
+                }
+            }
+            __syncthreads();
+            const uint64_t q0 = s_q0, q1 = s_q1;
+            const uint64_t w0 = q0 >> 5;
+            const uint32_t nwords = (uint32_t)(((q1 + 31) >> 5) - w0);
+            for (uint32_t i = tid; i < nwords + 1; i += 1024u) stage[i] = (i == 0) ? carry : 0u;
+            __syncthreads();
+#pragma unroll
+            for (uint32_t u = 0; u < TPR; ++u) {
+                if (valid[u]) {
+                    const uint32_t rel = (uint32_t)(q[u] - (w0 << 5)), wi = rel >> 5, sh = rel & 31u;
+                    atomicOr(&stage[wi], v[u] << sh);
+                    if (sh + nbits[u] > 32u) atomicOr(&stage[wi + 1], v[u] >> (32u - sh));
+                }
+            }
+            __syncthreads();
+            const uint32_t ncomplete = (uint32_t)((q1 >> 5) - w0);
+            for (uint32_t i = tid; i < ncomplete; i += 1024u) slot[w0 + i] = stage[i];
+            carry = stage[ncomplete];
+            __syncthreads();
+        }
+        qbase += (uint64_t)(ntok - nmat) * LB + (uint64_t)nmat * MB;
+        e_in = e_next;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        slot[qbase >> 5] = (qbase & 31u) ? carry : 0u;
+        slot[(qbase >> 5) + 1] = 0;
+        sc.block_bits[lb] = qbase;
+    }
+}
+
+// =============================================================================================
+// decode: one wave per block; the last 128 KiB of output live in an LDS ring (a match reaches back < 64 KiB)
+// =============================================================================================
+__device__ __forceinline__ uint32_t lzw_bits(const uint8_t *s, uint64_t nbytes, uint64_t pos, uint32_t k)   // k <= 25
+{
+    const uint64_t byte = pos >> 3;
+    uint64_t v = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) if (byte + i < nbytes) v |= (uint64_t)s[byte + i] << (8 * i);
+    return (uint32_t)(v >> (pos & 7u)) & ((1u << k) - 1u);
+}
+
+__global__ __launch_bounds__(64)
+void k_lzw_decode(const uint8_t *__restrict__ stream, uint64_t stream_bytes, const uint64_t *__restrict__ block_bits, LzP P,
+                  uint8_t *__restrict__ out, uint64_t n_total, uint32_t *__restrict__ err)
+{
+    constexpr uint32_t RING = 131072u, RMASK = RING - 1u, HALF = 65536u;
+    __shared__ __attribute__((aligned(16))) uint8_t s_ring[RING];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t b = blockIdx.x;
+    const uint64_t off = b * (uint64_t)P.block;
+    const uint32_t n = (uint32_t)((n_total - off) < P.block ? (n_total - off) : P.block);
+    uint64_t pos = block_bits[b];
+    const uint64_t end = block_bits[b + 1];
+    bool bad = end < pos || end > stream_bytes * 8ull;
+    const uint32_t MB = 1u + P.wbits + P.lbits, W = 1u << P.wbits;
+    uint32_t o = 0, flushed = 0;
+    while (!bad && o < n && pos < end) {
+        const uint32_t flag = lzw_bits(stream, stream_bytes, pos, 1);
+        if (pos + (flag ? MB : 9u) > end) { bad = true; break; }
+        if (!flag) {
+            if (lane == 0) s_ring[o & RMASK] = (uint8_t)lzw_bits(stream, stream_bytes, pos + 1, 8);
+            pos += 9; o += 1;
+        } else {
+            const uint32_t d = lzw_bits(stream, stream_bytes, pos + 1, P.wbits), len = lzw_bits(stream, stream_bytes, pos + 1 + P.wbits, P.lbits);
+            pos += MB;
+            if (d == 0 || d > o || d >= W) { bad = true; break; }
+            const uint32_t take = (o + len <= n) ? len : n - o;
+            for (uint32_t j = lane; j < take; j += 64) s_ring[(o + j) & RMASK] = s_ring[(o - d + (j % d)) & RMASK];
+            o += take;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // position x's ring cell is rewritten by position x + RING, and nothing reaches back further than W - 1 < 64 KiB:
+        // the oldest half only has to be copied out before the write cursor comes round to it
+        while (o + 64u > flushed + RING) {
+            for (uint32_t i = lane * 16u; i < HALF; i += 64u * 16u)
+                *reinterpret_cast<uint4 *>(out + off + flushed + i) = *reinterpret_cast<const uint4 *>(&s_ring[(flushed + i) & RMASK]);
+            flushed += HALF;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (o != n) bad = true;
+    if (bad) { if (lane == 0) atomicOr(err, 1u); return; }
+    for (uint32_t i = flushed + lane; i < n; i += 64) out[off + i] = s_ring[i & RMASK];
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+size_t lzw_scratch_bytes(uint32_t nb, uint32_t block)
+{
+    const size_t S = mi_align_up(block, 256);
+    return (size_t)nb * (S * (8 + 8 + 4 + 4 + 4 + 4 + 4 + 4 + 4) + (S + 64) + 8 * 4 + 16 + (size_t)LZW_SLOT_WORDS(block) * 4 + 8 + 4096) + 65536;
+}
+
+void lzw_carve(mi_ctx *ctx, uint32_t nb, uint32_t block, LzwScratch *sc)
+{
+    mi_carver cv(ctx->ws);
+    const size_t S = mi_align_up(block, 256);
+    sc->S = (uint32_t)S; sc->slot_words = LZW_SLOT_WORDS(block);
+    sc->eA = cv.take<uint64_t>(nb * S); sc->eB = cv.take<uint64_t>(nb * S);
+    sc->gid = cv.take<uint32_t>(nb * S); sc->rd = cv.take<uint32_t>(nb * S);
+    sc->cstart = cv.take<uint32_t>(nb * (S + 2)); sc->ncl = cv.take<uint32_t>((size_t)nb * 4);
+    sc->t_live = cv.take<uint8_t>(nb * (S + 64));
+    sc->t_pos = cv.take<uint32_t>(nb * S); sc->t_mix = cv.take<uint32_t>(nb * S); sc->slot_of = cv.take<uint32_t>(nb * S);
+    sc->cand = cv.take<uint32_t>(nb * S);
+    sc->slot = cv.take<uint32_t>((size_t)nb * sc->slot_words);
+    sc->block_bits = cv.take<uint64_t>(nb + 1);
+}
+
+// blocks per batch: the workspace is ~50 bytes per input byte
+uint32_t lzw_batch_blocks(uint64_t nblocks, uint32_t block)
+{
+    uint64_t cap = (256ull << 20) / block;                                 // 256 MiB of input per batch
+    if (cap < 1) cap = 1;
+    if (cap > 1024) cap = 1024;
+    return (uint32_t)(nblocks < cap ? (nblocks ? nblocks : 1) : cap);
+}
+
+// find() at every position of blocks [block0, block0 + nb): results in sc.cand (by position, LZW_NONE = none)
+mi_status lzw_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
+                   const LzwScratch &sc, hipStream_t s)
+{
+    const uint32_t chunks = (P.block + 256u * 16u - 1u) / (256u * 16u);
+    const uint32_t Tmask = (1u << P.tbits) - 1u;
+    const uint32_t np_home = (P.tbits + 7u) / 8u;                          // passes over the home bits
+    MI_HIP(ctx, hipMemsetAsync(sc.t_live, 0, (size_t)nb * (sc.S + 64), s));
+    { mi_prof_scope p(ctx, "k_lzw_keys", s, (uint64_t)nb * P.block);
+      hipLaunchKernelGGL(k_lzw_keys, dim3(chunks, nb), dim3(256), 0, s, d_in, n, P, sc, block0); }
+    { mi_prof_scope p(ctx, "k_lzw_sort(home)", s, (uint64_t)nb * P.block);
+      hipLaunchKernelGGL(k_lzw_sort, dim3(nb), dim3(1024), 0, s, n, P, sc, block0, Tmask, np_home, 0); }
+    { mi_prof_scope p(ctx, "k_lzw_sweep", s, (uint64_t)nb * P.block);
+      hipLaunchKernelGGL(k_lzw_sweep, dim3(nb), dim3(1024), 0, s, n, P, sc, block0, (int)(np_home & 1u)); }
+    // cluster numbers are < 2^20 (<= one per position): three passes, starting again from eA: result in eB
+    { mi_prof_scope p(ctx, "k_lzw_sort(cluster)", s, (uint64_t)nb * P.block);
+      hipLaunchKernelGGL(k_lzw_sort, dim3(nb), dim3(1024), 0, s, n, P, sc, block0, 0xFFFFFFFFu, 3u, 1); }
+    // the replay reads the (cluster, time) order from eA: copy it there (three passes end in eB)
+    MI_HIP(ctx, hipMemcpyAsync(sc.eA, sc.eB, (size_t)nb * sc.S * 8, hipMemcpyDeviceToDevice, s));
+    { mi_prof_scope p(ctx, "k_lzw_heads", s, (uint64_t)nb * P.block);
+      hipLaunchKernelGGL(k_lzw_heads, dim3(chunks, nb), dim3(256), 0, s, n, P, sc, block0, 0); }
+    { mi_prof_scope p(ctx, "k_lzw_replay", s, (uint64_t)nb * P.block);
+      hipLaunchKernelGGL(k_lzw_replay, dim3((unsigned)ctx->num_cu * 16u), dim3(64), 0, s, d_in, n, P, sc, block0, nb); }
+    MI_HIP(ctx, hipGetLastError());
+    return MI_OK;
+}
+
+void lzw_launch_parse_emit(const uint8_t *d_in, uint64_t n, const LzP &P, const LzwScratch &sc, uint64_t block0, uint32_t nb, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_lzw_parse_emit, dim3(nb), dim3(1024), 0, s, d_in, n, P, sc, block0);
+}
+
+void lzw_launch_decode(const uint8_t *d_stream, uint64_t stream_bytes, const uint64_t *d_block_bits, const LzP &P, uint8_t *d_out,
+                       uint64_t n, uint64_t nblocks, uint32_t *err, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_lzw_decode, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, stream_bytes, d_block_bits, P, d_out, n, err);
+}

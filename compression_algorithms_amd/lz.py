@@ -36,6 +36,17 @@ def find_all(data, p, ctx=None):
     return cand[:n]
 
 
+def find_all32(data, p, ctx=None):
+    """find() at every position of every block, for blocks above 64 KiB -> int32 tensor viewed as uint32 (0xFFFFFFFF = none)."""
+    ctx = ctx or default_context()
+    d_in = as_device_bytes(data, ctx.device)
+    n = d_in.numel()
+    cand = torch.empty(max(n, 1), dtype=torch.int32, device=ctx.device)
+    st = ctx.L.mi_lz_find_all32_dev(ctx.h, C.byref(p), C.c_void_p(d_in.data_ptr()), n, C.c_void_p(cand.data_ptr()), ctx.stream_ptr())
+    _lib.check(st, "mi_lz_find_all32_dev")
+    return cand[:n]
+
+
 class LzStream:
     """A block-parallel LZ77 stream on the device.
 

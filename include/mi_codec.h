@@ -157,7 +157,8 @@ typedef struct {
     uint32_t lbits;       /* length bits: lz77 4; deflate 5                               */
     uint32_t tbits;       /* log2 table size: lz77 wbits+6; deflate 20                    */
     uint32_t deflate;     /* 1: deflate rules (insert probe wraps, literal iff p-m >= W-1, byte tokens) */
-    uint32_t block;       /* block size in bytes, 1..65536                                */
+    uint32_t block;       /* block size in bytes: 1..65536; lz77 flavour also 65792..1048576 in steps of 256 —
+                           * the HBM-resident finder of lzw.hip, where a 64 KiB window really slides (exact, slower) */
 } mi_lz_params;
 
 static inline mi_lz_params mi_lz_params_deflate(void) { mi_lz_params p = {15, 5, 20, 1, 65536}; return p; }
@@ -201,6 +202,9 @@ mi_status mi_lz_decode(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *h_stre
  * (0xFFFF = none), i.e. the output of the match-finder stage alone. */
 mi_status mi_lz_find_all_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_in, uint64_t n,
                              uint16_t *d_cand, void *stream);
+/* the same for blocks above 64 KiB (lz77 flavour only): 32-bit positions, 0xFFFFFFFF = none */
+mi_status mi_lz_find_all32_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_in, uint64_t n,
+                               uint32_t *d_cand, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Deflate "mode H": the entropy stage algorithms/deflate/lz77.c:279 leaves as a TODO

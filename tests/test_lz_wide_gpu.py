@@ -1,0 +1,127 @@
+"""The lz77 flavour on blocks ABOVE 64 KiB (lzw.hip): WINDOW_BITS 16 with a window that really slides (SURVEY.md 8d
+config 2 "64 KiB ... 1 MiB").  Parity against the oracle's literal table (find() at every position),
+against the oracle's encoder per block, against tests/golden/lz77_wide.json — vectors the REAL reference produced
+(oracle/gen_golden_wide.py) — and against the committed 300 kB whole-buffer fixture of round 1 (one 1 MiB block = the
+reference's whole-buffer stream); every stream is decoded back on the GPU."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from compression_algorithms_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _check_find(data, wbits, block):
+    from compression_algorithms_amd import lz
+    from oracle import orc
+    p = lz.params("lz77", wbits, block)
+    got = lz.find_all32(data, p).cpu().numpy().view(np.uint32)
+    for at in range(0, len(data), block):
+        want = orc.find_all(data[at:at + block], wbits, wbits + 6, False)
+        g = got[at:at + block]
+        bad = np.flatnonzero(g != want)
+        assert bad.size == 0, f"block at {at}: {bad.size} mismatches, first {bad[:5]}: got {g[bad[:5]]} want {want[bad[:5]]}"
+
+
+def _check_stream(data, wbits, block):
+    from compression_algorithms_amd import lz
+    from oracle import orc
+    p = lz.params("lz77", wbits, block)
+    st = lz.compress(data, p)
+    bb = st.block_bits.cpu().numpy()
+    raw = np.frombuffer(st.tobytes(), dtype=np.uint8)
+    allbits = np.unpackbits(raw, bitorder="little")
+    out = []
+    for k, at in enumerate(range(0, len(data), block)):
+        s, nb = orc.lz77_encode(data[at:at + block].tobytes(), wbits, 4)
+        assert int(bb[k + 1] - bb[k]) == nb, (k, int(bb[k + 1] - bb[k]), nb)
+        got = np.packbits(allbits[int(bb[k]):int(bb[k + 1])], bitorder="little")
+        want = s[: (nb + 7) // 8].copy()
+        assert np.array_equal(got, want), f"block {k}: stream differs at byte {np.flatnonzero(got != want)[:5]}"
+        out.append((got, nb))
+    assert np.array_equal(lz.decompress(st).cpu().numpy(), data)
+    return out
+
+
+@pytest.mark.parametrize("wbits,block", [(16, 131072), (16, 262144), (14, 131072)])
+def test_find_all_equals_the_literal_table(wbits, block):
+    _check_find(synth.enwik_like(300_000, seed=51).numpy(), wbits, block)
+
+
+def test_window_really_slides():
+    """sanity of the premise: with a 256 KiB block and W = 64 KiB some candidates of the 64 KiB-block encoding are gone and
+    the stream differs from the concatenation of 64 KiB blocks"""
+    from oracle import orc
+    data = synth.enwik_like(262144, seed=52).numpy()
+    whole = orc.find_all(data, 16, 22, False)
+    first = orc.find_all(data[:65536], 16, 22, False)
+    assert np.array_equal(whole[:65532], first[:65532])               # nothing retired in the first 64 KiB (the last 3 words see the zero tail)
+    assert (whole[65536:] != 0xFFFFFFFF).any()
+    _check_stream(data, 16, 262144)
+
+
+@pytest.mark.parametrize("kind,n", [("zeros", 70000), ("two", 100_000), ("random", 140_000), ("period3", 90_000), ("period16384", 150_000),
+                                    ("zero_tail", 66_000), ("skewed", 131072)])
+def test_adversarial(kind, n):
+    data = np.frombuffer(synth.adversarial(kind, n), dtype=np.uint8)
+    _check_find(data, 16, 131072)
+    _check_stream(data, 16, 131072)
+
+
+def test_bucket_zero_cluster_and_short_last_block():
+    """a word whose home is bucket 0 (the ring's zero-fill clears bucket 0 at insertion W-1) repeated across
+    the window boundary, and a last block shorter than the others"""
+    from oracle import orc
+    rng = np.random.default_rng(9)
+    # find a 4-byte word with home 0 at T = 2^22
+    w = None
+    for cand in range(1, 1 << 26):
+        if orc.home(cand, 22) == 0:
+            w = cand
+            break
+    assert w is not None
+    word = np.frombuffer(int(w).to_bytes(4, "little"), dtype=np.uint8)
+    data = rng.integers(1, 255, 200_000, dtype=np.uint8)
+    for at in (100, 5000, 65000, 65530, 66000, 70000, 131000, 140000, 199000):
+        data[at:at + 4] = word
+    _check_find(data, 16, 131072)
+    _check_stream(data, 16, 131072)
+
+
+def test_golden_vectors_from_the_reference(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "lz77_wide.json")))
+    for name, e in g.items():
+        data = synth.enwik_like(e["n"], seed=e["seed"]).numpy()
+        assert _sha(data) == e["input_sha256"], name
+        blocks = _check_stream(data, 16, e["block"])
+        for k, (got, nb) in enumerate(blocks):
+            ref = e["blocks"][k]
+            if ref is None:
+                continue                                              # the reference's own UB on this block: not pinned
+            s = np.zeros(nb // 8 + 1, np.uint8)
+            s[: len(got)] = got
+            assert nb == ref["bits"] and _sha(s) == ref["sha256"], (name, k)
+
+
+def test_whole_buffer_fixture_of_round_1(golden_dir):
+    """tests/golden/enwik_like_300k: ONE 1 MiB block holds the whole 300 kB sample, so the HIP stream must be the reference's
+    whole-buffer lz77_compress stream (lz77_w16_whole / lz77_w14_whole), which round 1 could only check against the oracle"""
+    from compression_algorithms_amd import lz
+    e = json.load(open(os.path.join(golden_dir, "enwik_like_300k.json")))
+    sample = np.fromfile(os.path.join(golden_dir, "enwik_like_300k.bin"), dtype=np.uint8)
+    for wb in (16, 14):
+        st = lz.compress(sample, lz.params("lz77", wb, 1 << 20))
+        nb = st.total_bits
+        s = np.zeros(nb // 8 + 1, np.uint8)
+        raw = np.frombuffer(st.tobytes(), dtype=np.uint8)
+        s[: len(raw)] = raw
+        assert nb == e[f"lz77_w{wb}_whole"]["bits"] and _sha(s) == e[f"lz77_w{wb}_whole"]["sha256"], wb
+        assert np.array_equal(lz.decompress(st).cpu().numpy(), sample)
