@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BLOCK = 65536
-WORKLOADS = ["deflate-h", "deflate", "lz77w16", "lz77w14", "huffman", "fse"]
+WORKLOADS = ["deflate-h", "deflate", "lz77w16", "lz77w14", "lz77w16-256k", "lz77w16-1m", "huffman", "fse"]
 
 
 def parse_args():
@@ -69,6 +69,8 @@ DESC = {
     "deflate": "deflate tokeniser alone (LZ77, W=32 KiB, len<=31, the reference's byte tokens, mode T), independent 64 KiB blocks",
     "lz77w16": "lz77 (W=64 KiB, len<=15, bit-packed), independent 64 KiB blocks",
     "lz77w14": "lz77 (W=16 KiB, len<=15, bit-packed), independent 64 KiB blocks",
+    "lz77w16-256k": "lz77 (W=64 KiB, len<=15, bit-packed), independent 256 KiB blocks: the window slides (HBM-resident finder)",
+    "lz77w16-1m": "lz77 (W=64 KiB, len<=15, bit-packed), independent 1 MiB blocks: the window slides (HBM-resident finder)",
     "huffman": "whole-buffer Huffman, one tree",
     "fse": "FSE/tANS table_log 8, independent 64 KiB blocks x 64 sub-streams",
 }
@@ -82,12 +84,13 @@ class Codec:
         self.w, self.ctx = workload, ctx
         self.lz, self.huffman, self.fse = lz, huffman, fse
         self.p = {"deflate": lz.params("deflate"), "deflate-h": lz.params("deflate"), "lz77w16": lz.params("lz77", 16),
-                  "lz77w14": lz.params("lz77", 14), "fse": fse.params(), "huffman": None}[workload]
+                  "lz77w14": lz.params("lz77", 14), "lz77w16-256k": lz.params("lz77", 16, 262144), "lz77w16-1m": lz.params("lz77", 16, 1 << 20),
+                  "fse": fse.params(), "huffman": None}[workload]
 
     def encode(self, x):
         if self.w == "deflate-h":
             return self.lz.compress_h(x, self.p, self.ctx)
-        if self.w in ("deflate", "lz77w16", "lz77w14"):
+        if self.w in ("deflate", "lz77w16", "lz77w14", "lz77w16-256k", "lz77w16-1m"):
             return self.lz.compress(x, self.p, self.ctx)
         if self.w == "huffman":
             return self.huffman.huffman_compress(x, self.ctx)
@@ -99,7 +102,7 @@ class Codec:
     def decode(self, h):
         if self.w == "deflate-h":
             return self.lz.decompress_h(h, self.ctx)
-        if self.w in ("deflate", "lz77w16", "lz77w14"):
+        if self.w in ("deflate", "lz77w16", "lz77w14", "lz77w16-256k", "lz77w16-1m"):
             return self.lz.decompress(h, self.ctx)
         if self.w == "huffman":
             return self.huffman.huffman_decompress(h, ctx=self.ctx)
@@ -172,11 +175,12 @@ def cpu_baseline(workload, sample, sample_desc):
         extra = {"tokeniser_only_gbs": round(n / t_tok / 1e9, 5),
                  "note": "tokeniser = " + ("the compiled reference" if rd else "oracle port") +
                          "; entropy stage = oracle port (the reference has none)"}
-    elif workload in ("lz77w16", "lz77w14"):
-        wb = 16 if workload == "lz77w16" else 14
+    elif workload.startswith("lz77w"):
+        wb = 14 if workload == "lz77w14" else 16
+        blk = {"lz77w16-256k": 262144, "lz77w16-1m": 1 << 20}.get(workload, BLOCK)
         t0 = time.perf_counter()
-        for at in range(0, n, BLOCK):
-            orc.lz77_encode(sample[at:at + BLOCK].tobytes(), wb, 4)
+        for at in range(0, n, blk):
+            orc.lz77_encode(sample[at:at + blk].tobytes(), wb, 4)
     elif workload == "huffman":
         if ref.available():
             kind = "reference"
@@ -210,8 +214,8 @@ def reference_output_bytes(workload, sample):
             return len(s), "reference compress(): persistent-table byte-token stream (deflate/deflate.c:47-63), compiled reference"
         s, _ = orc.deflate_stream(sample, BLOCK, False)
         return len(s), "reference compress(): persistent-table byte-token stream (deflate/deflate.c:47-63), oracle port"
-    if workload in ("lz77w16", "lz77w14"):
-        wb = 16 if workload == "lz77w16" else 14
+    if workload.startswith("lz77w"):
+        wb = 14 if workload == "lz77w14" else 16
         if ref.available():
             s, nb = ref.lz77_compress(sample, wb)
         else:
@@ -403,7 +407,7 @@ def main():
         cpu = None
         ratio_vs_ref = None
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is a rank-0, N = 1 measurement
-            rate = {"deflate": 0.045, "deflate-h": 0.029, "lz77w16": 0.012, "lz77w14": 0.014, "huffman": 0.23, "fse": 0.15}[args.workload]
+            rate = {"deflate": 0.045, "deflate-h": 0.029, "lz77w16": 0.012, "lz77w14": 0.014, "lz77w16-256k": 0.012, "lz77w16-1m": 0.012, "huffman": 0.23, "fse": 0.15}[args.workload]
             mb = args.cpu_sample_mb if args.cpu_sample_mb else min(n / 1e6, max(4.0, 5.0 * rate * 1e3))
             nsamp = int(mb * 1e6) // BLOCK * BLOCK or min(n, BLOCK)
             sample = x[:nsamp].cpu().numpy()

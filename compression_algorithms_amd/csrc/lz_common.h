@@ -71,6 +71,11 @@ struct LzwScratch {
     uint32_t *t_pos, *t_mix;    // [nb][S]
     uint32_t *slot_of;          // [nb][S] bucket of the k-th (cluster, time)-sorted entry (for its retirement)
     uint32_t *cand;             // [nb][S] find() by position (LZW_NONE = none)
+    uint32_t *ent;              // [nb][S] per (cluster, time)-sorted entry: home slot relative to the cluster | word id << 16
+    uint32_t *relw;             // [nb][S] by position: the same pair, written by the sweep
+    uint16_t *cand_e;           // [nb][S] per sorted entry: index (inside its cluster) of the entry find() returned, 0xFFFF = none
+    uint64_t *clist[5];         // per size class: block << 32 | cluster number (classes: <= 1024, <= 4096, <= 8192, <= 24576 entries, larger)
+    uint32_t *ccount;           // [5] entries of the class lists (zeroed per batch)
     uint32_t *slot;             // [nb][slot_words] block-local token stream
     uint64_t *block_bits;       // [nb + 1]
     uint32_t  S, slot_words;

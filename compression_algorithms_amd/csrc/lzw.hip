@@ -22,6 +22,7 @@
 // plain loads could hit stale lines of the CU's L1).  This path is exact, not fast: a cluster is a serial chain of HBM/L2
 // round trips.  It exists so that WINDOW_BITS 16 means what it says; DESIGN.md 6 says what would make it quick.
 #include "lz_common.h"
+#include "lz_replay.h"
 #include <stdlib.h>
 
 #define LZW_MAX_BLOCK   (1u << 20)
@@ -92,27 +93,27 @@ void k_lzw_sweep(uint64_t n_total, LzP P, LzwScratch sc, uint64_t block0, int so
     __shared__ int32_t  s_i32[18];
     __shared__ uint64_t s_u64[18];
     __shared__ int32_t  s_run;
-    __shared__ uint32_t s_gs, s_base, s_count;
+    __shared__ uint32_t s_gs, s_base, s_count, s_hs;
     constexpr uint32_t CH = 8;
     const uint32_t lb = blockIdx.x, tid = threadIdx.x;
     const uint64_t off = (block0 + lb) * (uint64_t)P.block;
     const uint32_t n = (uint32_t)((n_total - off) < P.block ? (n_total - off) : P.block);
     const uint64_t *srt = (sorted_in_b ? sc.eB : sc.eA) + (size_t)lb * sc.S;
-    uint32_t *gid = sc.gid + (size_t)lb * sc.S, *rd = sc.rd + (size_t)lb * sc.S;
+    uint32_t *gid = sc.gid + (size_t)lb * sc.S, *rd = sc.rd + (size_t)lb * sc.S, *relw = sc.relw + (size_t)lb * sc.S;
     const uint32_t Tmask = (1u << P.tbits) - 1u;
-    if (tid == 0) { s_run = INT32_MIN; s_gs = 0; s_base = 0; s_count = 0; }
+    if (tid == 0) { s_run = INT32_MIN; s_gs = 0; s_base = 0; s_count = 0; s_hs = 0; }
     __syncthreads();
     for (uint32_t t0 = 0; t0 < n; t0 += 1024u * CH) {
         const uint32_t k0 = t0 + tid * CH, k1 = (k0 + CH < n) ? k0 + CH : n;
-        uint32_t rp[CH]; int32_t rh[CH];
+        uint32_t rp[CH], rm[CH]; int32_t rh[CH];
         int32_t mx = INT32_MIN;
 #pragma unroll
         for (uint32_t c = 0; c < CH; ++c) {
             const uint32_t k = k0 + c;
-            rp[c] = 0; rh[c] = 0;
+            rp[c] = 0; rh[c] = 0; rm[c] = 0;
             if (k < k1) {
                 const uint64_t e = srt[k];
-                rp[c] = (uint32_t)e; rh[c] = (int32_t)((uint32_t)(e >> 32) & Tmask);
+                rp[c] = (uint32_t)e; rm[c] = (uint32_t)(e >> 32); rh[c] = (int32_t)(rm[c] & Tmask);
                 const int32_t g = rh[c] - (int32_t)k;
                 mx = g > mx ? g : mx;
             }
@@ -136,21 +137,38 @@ void k_lzw_sweep(uint64_t n_total, LzP P, LzwScratch sc, uint64_t block0, int so
                 }
             }
         }
-        struct OpHL {           // heads: sum (low 32); last head index + 1: max (high 32)
+        // last start of a home run in my chunk (the word id of an entry is the sorted index of the first entry of its word)
+        int32_t lastrun = -1;
+        {
+            uint32_t prev_h = (k0 > 0 && k0 < n) ? (uint32_t)((uint32_t)(srt[k0 - 1] >> 32) & Tmask) : 0u;
+#pragma unroll
+            for (uint32_t c = 0; c < CH; ++c) {
+                const uint32_t k = k0 + c;
+                if (k < k1) { if (k == 0 || (uint32_t)rh[c] != prev_h) lastrun = (int32_t)k; prev_h = (uint32_t)rh[c]; }
+            }
+        }
+        struct OpHL {           // heads: sum (bits 0..20); last head index + 1: max (21..41); last run start + 1: max (42..62)
             __device__ uint64_t operator()(uint64_t a, uint64_t b) const {
-                const uint64_t s0 = (a & 0xFFFFFFFFull) + (b & 0xFFFFFFFFull), a1 = a >> 32, b1 = b >> 32;
-                return (s0 & 0xFFFFFFFFull) | ((a1 > b1 ? a1 : b1) << 32);
+                const uint64_t M = 0x1FFFFFull;
+                const uint64_t s0 = ((a & M) + (b & M)) & M, a1 = (a >> 21) & M, b1 = (b >> 21) & M, a2 = (a >> 42) & M, b2 = (b >> 42) & M;
+                return s0 | ((a1 > b1 ? a1 : b1) << 21) | ((a2 > b2 ? a2 : b2) << 42);
             }
         };
         uint64_t tot2;
-        const uint64_t pre2 = block_exclusive_scan<uint64_t>((uint64_t)nheads | ((uint64_t)(uint32_t)(lasthead + 1) << 32), OpHL(), 0ull, s_u64, &tot2);
+        const uint64_t pre2 = block_exclusive_scan<uint64_t>((uint64_t)nheads | ((uint64_t)(uint32_t)(lasthead >= 0 ? lasthead + 1 - (int32_t)t0 : 0) << 21) |
+                                                             ((uint64_t)(uint32_t)(lastrun >= 0 ? lastrun + 1 - (int32_t)t0 : 0) << 42), OpHL(), 0ull, s_u64, &tot2);
         const uint32_t count0 = s_count;
-        uint32_t cur_gs = s_gs, cur_base = s_base, cur_gid = count0 + (uint32_t)(pre2 & 0xFFFFFFFFull) - 1u;   // the cluster open at my first entry
-        const int32_t gs_carry = (int32_t)(pre2 >> 32) - 1;                 // last head before my chunk inside this tile
-        if (gs_carry >= 0) { cur_gs = (uint32_t)gs_carry; cur_base = (uint32_t)((uint32_t)(srt[cur_gs] >> 32) & Tmask); }
+        uint32_t cur_gs = s_gs, cur_base = s_base, cur_gid = count0 + (uint32_t)(pre2 & 0x1FFFFFull) - 1u;   // the cluster open at my first entry
+        const int32_t gs_carry = (int32_t)((pre2 >> 21) & 0x1FFFFFull) - 1;      // last head before my chunk inside this tile (tile-relative)
+        if (gs_carry >= 0) { cur_gs = t0 + (uint32_t)gs_carry; cur_base = (uint32_t)((uint32_t)(srt[cur_gs] >> 32) & Tmask); }
+        uint32_t cur_hs = s_hs;                                                // start of the home run open at my first entry
+        const int32_t hs_carry = (int32_t)((pre2 >> 42) & 0x1FFFFFull) - 1;
+        if (hs_carry >= 0) cur_hs = t0 + (uint32_t)hs_carry;
+        uint32_t hs_mix = (k0 < n && (k0 > 0)) ? (uint32_t)(srt[cur_hs] >> 32) : 0u;
         {
             int32_t run = premax;
             uint32_t seen = 0;
+            uint32_t prev_h2 = (k0 > 0 && k0 < n) ? (uint32_t)((uint32_t)(srt[k0 - 1] >> 32) & Tmask) : 0u;
 #pragma unroll
             for (uint32_t c = 0; c < CH; ++c) {
                 const uint32_t k = k0 + c;
@@ -158,18 +176,34 @@ void k_lzw_sweep(uint64_t n_total, LzP P, LzwScratch sc, uint64_t block0, int so
                     const int32_t h = rh[c], g = h - (int32_t)k;
                     const bool head = (k == 0) || (g >= run);
                     run = g > run ? g : run;
-                    if (head) { cur_gs = k; cur_base = (uint32_t)h; cur_gid = count0 + (uint32_t)(pre2 & 0xFFFFFFFFull) + seen; ++seen; }
+                    if (head) { cur_gs = k; cur_base = (uint32_t)h; cur_gid = count0 + (uint32_t)(pre2 & 0x1FFFFFull) + seen; ++seen; }
+                    // word id: sorted index of the first entry of this word (entries of one home are in time order; two
+                    // different words on one home are rare: a short scan of the run)
+                    const uint32_t mixk = rm[c];
+                    uint32_t id;
+                    if (k == 0 || (uint32_t)h != prev_h2) { cur_hs = k; hs_mix = mixk; id = k; }
+                    else if (mixk == hs_mix) id = cur_hs;
+                    else {
+                        id = k;
+                        for (uint32_t kk = cur_hs + 1; kk < k; ++kk) if ((uint32_t)(srt[kk] >> 32) == mixk) { id = kk; break; }
+                    }
+                    prev_h2 = (uint32_t)h;
                     gid[rp[c]] = cur_gid;
                     rd[rp[c]] = cur_gs + ((uint32_t)h - cur_base);
+                    // relative to the cluster (both < its size): what the LDS-resident replay reads, if the cluster is <= 65535
+                    const uint32_t rrel = (uint32_t)h - cur_base, irel = id - cur_gs;
+                    relw[rp[c]] = (rrel < 0xFFFFu ? rrel : 0xFFFFu) | ((irel < 0xFFFFu ? irel : 0xFFFFu) << 16);
                 }
             }
         }
         __syncthreads();
         if (tid == 0) {
             s_run = tile_max > carry_run ? tile_max : carry_run;
-            s_count = count0 + (uint32_t)(tot2 & 0xFFFFFFFFull);
-            const int32_t lh = (int32_t)(tot2 >> 32) - 1;                   // last head of the tile, if any
-            if (lh >= 0) { s_gs = (uint32_t)lh; s_base = (uint32_t)((uint32_t)(srt[lh] >> 32) & Tmask); }
+            s_count = count0 + (uint32_t)(tot2 & 0x1FFFFFull);
+            const int32_t lh = (int32_t)((tot2 >> 21) & 0x1FFFFFull) - 1;   // last head of the tile, if any (tile-relative)
+            if (lh >= 0) { s_gs = t0 + (uint32_t)lh; s_base = (uint32_t)((uint32_t)(srt[t0 + (uint32_t)lh] >> 32) & Tmask); }
+            const int32_t lr = (int32_t)((tot2 >> 42) & 0x1FFFFFull) - 1;
+            if (lr >= 0) s_hs = t0 + (uint32_t)lr;
         }
         __syncthreads();
     }
@@ -180,8 +214,14 @@ void k_lzw_sweep(uint64_t n_total, LzP P, LzwScratch sc, uint64_t block0, int so
     }
 }
 
-// first sorted index of every cluster (clusters are contiguous in the (cluster, time) order); a cluster of one entry is
-// answered here: its only find() precedes its only insert
+// first sorted index of every cluster (clusters are contiguous in the (cluster, time) order, and in the same index range
+// as in the home order); a cluster of one entry is answered here: its only find() precedes its only insert.  Larger ones
+// join the list of their size class; every entry's {relative home slot, word id} moves into (cluster, time) order.
+#define LZW_CAP_S 1024u
+#define LZW_CAP_M 4096u
+#define LZW_CAP_L 24576u
+#define LZW_CAP_K 8192u
+#define LZW_NCLS  5u
 __global__ __launch_bounds__(256)
 void k_lzw_heads(uint64_t n_total, LzP P, LzwScratch sc, uint64_t block0, int sorted_in_b)
 {
@@ -191,14 +231,138 @@ void k_lzw_heads(uint64_t n_total, LzP P, LzwScratch sc, uint64_t block0, int so
     const uint64_t *srt = (sorted_in_b ? sc.eB : sc.eA) + (size_t)lb * sc.S;
     uint32_t *cs = sc.cstart + (size_t)lb * (sc.S + 2);
     uint32_t *cand = sc.cand + (size_t)lb * sc.S;
+    const uint32_t *relw = sc.relw + (size_t)lb * sc.S;
+    uint32_t *ent = sc.ent + (size_t)lb * sc.S;
     for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n; k += gridDim.x * 256u) {
-        const uint32_t g = (uint32_t)(srt[k] >> 32);
+        const uint64_t e = srt[k];
+        const uint32_t g = (uint32_t)(e >> 32), p = (uint32_t)e;
+        ent[k] = relw[p];
         const bool head = k == 0 || (uint32_t)(srt[k - 1] >> 32) != g;
         if (head) {
             cs[g] = k;
-            if (k + 1 == n || (uint32_t)(srt[k + 1] >> 32) != g) cand[(uint32_t)srt[k]] = LZW_NONE;
+            if (k + 1 == n || (uint32_t)(srt[k + 1] >> 32) != g) cand[p] = LZW_NONE;
         }
         if (k + 1 == n) cs[g + 1] = n;
+    }
+}
+
+// after k_lzw_heads: one thread per cluster appends it to the list of its size class.  Ranks are taken in LDS and ONE
+// global atomic per workgroup, class and round reserves the list space (four counters shared by every cluster of the
+// batch: a global atomic per cluster serialised ~4 M of them, 50-100 ms per 100 MB).
+__global__ __launch_bounds__(256)
+void k_lzw_classify(LzwScratch sc, uint32_t nb)
+{
+    __shared__ uint32_t s_n[LZW_NCLS], s_base[LZW_NCLS];
+    for (uint32_t lb = blockIdx.y; lb < nb; lb += gridDim.y) {
+        const uint32_t ncl = sc.ncl[(size_t)lb * 4];
+        const uint32_t *cs = sc.cstart + (size_t)lb * (sc.S + 2);
+        for (uint32_t c0 = blockIdx.x * 256u; c0 < ncl; c0 += gridDim.x * 256u) {     // uniform trip count per workgroup
+            if (threadIdx.x < LZW_NCLS) s_n[threadIdx.x] = 0;
+            __syncthreads();
+            const uint32_t c = c0 + threadIdx.x;
+            uint32_t cls = LZW_NCLS, rank = 0;
+            if (c < ncl) {
+                const uint32_t m = cs[c + 1] - cs[c];
+                if (m >= 2) { cls = m <= LZW_CAP_S ? 0u : m <= LZW_CAP_M ? 1u : m <= LZW_CAP_K ? 2u : m <= LZW_CAP_L ? 3u : 4u; rank = atomicAdd(&s_n[cls], 1u); }
+            }
+            __syncthreads();
+            if (threadIdx.x < LZW_NCLS && s_n[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&sc.ccount[threadIdx.x], s_n[threadIdx.x]);
+            __syncthreads();
+            if (cls < LZW_NCLS) sc.clist[cls][s_base[cls] + rank] = ((uint64_t)lb << 32) | c;
+            __syncthreads();
+        }
+    }
+}
+
+// LDS-resident replay of one cluster by one wave (the shape of big_replay in lz_replay.h, with 32-bit positions kept out
+// of the loop): occupancy bitmap in registers, per bucket the occupant as {word id, entry index}, per entry its bucket.
+// find() returns an ENTRY INDEX; k_lzw_resolve turns it into a position afterwards, off the serial chain.
+template <int CAP, int NW>
+__global__ __launch_bounds__(64)
+void k_lzw_replay_lds(LzP P, LzwScratch sc, uint32_t cls)
+{
+    __shared__ uint32_t s_occ[CAP];                       // bucket -> word id | entry index << 16
+    __shared__ uint16_t s_slot[CAP];                      // entry -> bucket
+    const uint32_t lane = threadIdx.x;
+    const uint32_t W = 1u << P.wbits;
+    const uint32_t count = sc.ccount[cls];
+    for (uint32_t ci = blockIdx.x; ci < count; ci += gridDim.x) {
+        const uint64_t item = sc.clist[cls][ci];
+        const uint32_t lb = (uint32_t)(item >> 32), c = (uint32_t)item;
+        const uint32_t *cs = sc.cstart + (size_t)lb * (sc.S + 2);
+        const uint32_t s = cs[c], m = cs[c + 1] - s;
+        const uint64_t *srt = sc.eA + (size_t)lb * sc.S + s;              // the cluster's entries in time order
+        const uint32_t *ent = sc.ent + (size_t)lb * sc.S + s;
+        uint16_t *ce = sc.cand_e + (size_t)lb * sc.S + s;
+        bool anom_pending = (c == 0u) && sc.ncl[(size_t)lb * 4 + 1];
+        WaveBitmap<NW> bm;
+        bm.clear();
+        uint32_t ev = 0, out_acc = 0xFFFFu;
+        uint32_t ev_pos = lane < m ? (uint32_t)srt[lane] : 0u;            // positions of entries [ev & ~63, +64): the next to retire
+        uint32_t pe = RLANE(ev_pos, 0);
+        uint32_t n_pos = ev_pos, n_ent = lane < m ? ent[lane] : 0u;       // the next 64 entries are in flight while these are replayed
+        for (uint32_t i0 = 0; i0 < m; i0 += 64) {
+            const uint32_t ii = i0 + lane;
+            const uint32_t c_pos = n_pos, c_ent = n_ent;
+            if (ii + 64 < m) { n_pos = (uint32_t)srt[ii + 64]; n_ent = ent[ii + 64]; }
+            const uint32_t lim = (m - i0) < 64u ? (m - i0) : 64u;
+            for (uint32_t t = 0; t < lim; ++t) {
+                const uint32_t i = i0 + t;
+                const uint32_t p = RLANE(c_pos, t), re = RLANE(c_ent, t), r = re & 0xFFFFu, id = re >> 16;
+                while (ev < i && (uint64_t)pe + W < (uint64_t)p) {           // FIFO retirement (lz77.c:70-76)
+                    const uint32_t sl = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_slot[ev]);
+                    bm.clear_bit(sl, lane);                                 // clears the bucket, whoever sits there
+                    ++ev;
+                    if ((ev & 63u) == 0) { const uint32_t q = ev + lane; ev_pos = q < m ? (uint32_t)srt[q] : 0u; }
+                    pe = RLANE(ev_pos, ev & 63u);
+                }
+                if (anom_pending && p > W - 1u) { bm.clear_bit(0u, lane); anom_pending = false; }   // bucket 0, once
+                uint32_t res = 0xFFFFu;
+                if (bm.test(r)) {
+                    const uint32_t h = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_occ[r]);
+                    if ((h & 0xFFFFu) == id) res = h >> 16;
+                    else {
+                        uint32_t e = bm.first_zero_from(r + 1u, lane);
+                        if (e > (uint32_t)CAP) e = (uint32_t)CAP;
+                        for (uint32_t b0 = r + 1u; b0 < e; b0 += 64u) {
+                            const uint32_t b = b0 + lane;
+                            const uint32_t o = b < e ? s_occ[b] : 0u;
+                            const uint64_t hit = __ballot(b < e && (o & 0xFFFFu) == id);
+                            if (hit) { res = RLANE(o, (uint32_t)__builtin_ctzll(hit)) >> 16; break; }
+                        }
+                    }
+                }
+                const uint32_t b = bm.first_zero_from(r, lane);             // insert: first fit (inside the cluster by the parking bound)
+                bm.flip(b, lane);
+                s_occ[b] = id | (i << 16); s_slot[i] = (uint16_t)b;
+                if (lane == t) out_acc = res;
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (ii < m) ce[ii] = (uint16_t)out_acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// entry index -> position for every cluster the LDS replay handled
+__global__ __launch_bounds__(256)
+void k_lzw_resolve(LzwScratch sc)
+{
+    for (uint32_t cls = 0; cls < 4; ++cls) {
+        const uint32_t count = sc.ccount[cls];
+        for (uint32_t ci = blockIdx.x; ci < count; ci += gridDim.x) {
+            const uint64_t item = sc.clist[cls][ci];
+            const uint32_t lb = (uint32_t)(item >> 32), c = (uint32_t)item;
+            const uint32_t *cs = sc.cstart + (size_t)lb * (sc.S + 2);
+            const uint32_t s = cs[c], m = cs[c + 1] - s;
+            const uint64_t *srt = sc.eA + (size_t)lb * sc.S + s;
+            const uint16_t *ce = sc.cand_e + (size_t)lb * sc.S + s;
+            uint32_t *cand = sc.cand + (size_t)lb * sc.S;
+            for (uint32_t i = threadIdx.x; i < m; i += 256u) {
+                const uint32_t r = ce[i];
+                cand[(uint32_t)srt[i]] = r == 0xFFFFu ? LZW_NONE : (uint32_t)srt[r];
+            }
+        }
     }
 }
 
@@ -212,7 +376,10 @@ void k_lzw_replay(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, LzwSc
 {
     const uint32_t lane = threadIdx.x;
     const uint32_t W = 1u << P.wbits;
-    for (uint32_t lb = 0; lb < nb; ++lb) {
+    (void)nb;
+    const uint32_t count = sc.ccount[4];                  // only clusters too large for the LDS replay (> 24 576 entries)
+    for (uint32_t ci = blockIdx.x; ci < count; ci += gridDim.x) {
+        const uint32_t lb = (uint32_t)(sc.clist[4][ci] >> 32), c_only = (uint32_t)sc.clist[4][ci];
         const uint64_t off = (block0 + lb) * (uint64_t)P.block;
         const uint32_t n = (uint32_t)((n_total - off) < P.block ? (n_total - off) : P.block);
         const uint8_t *src = in + off;
@@ -223,7 +390,8 @@ void k_lzw_replay(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, LzwSc
         uint8_t  *live = sc.t_live + (size_t)lb * (sc.S + 64);
         uint32_t *tpos = sc.t_pos + (size_t)lb * sc.S, *tmix = sc.t_mix + (size_t)lb * sc.S, *slot_of = sc.slot_of + (size_t)lb * sc.S;
         uint32_t *cand = sc.cand + (size_t)lb * sc.S;
-        for (uint32_t c = blockIdx.x; c < ncl; c += gridDim.x) {
+        (void)ncl;
+        for (uint32_t c = c_only; c == c_only; ++c) {
             const uint32_t s = cs[c], e = cs[c + 1], m = e - s;
             if (m < 2) continue;
             // the cluster's dense buckets are [s, e): its head's dense slot is its own sorted index in the HOME order, which
@@ -510,7 +678,7 @@ void k_lzw_decode(const uint8_t *__restrict__ stream, uint64_t stream_bytes, con
 size_t lzw_scratch_bytes(uint32_t nb, uint32_t block)
 {
     const size_t S = mi_align_up(block, 256);
-    return (size_t)nb * (S * (8 + 8 + 4 + 4 + 4 + 4 + 4 + 4 + 4) + (S + 64) + 8 * 4 + 16 + (size_t)LZW_SLOT_WORDS(block) * 4 + 8 + 4096) + 65536;
+    return (size_t)nb * (S * (8 + 8 + 4 + 4 + 4 + 4 + 4 + 4 + 4 + 4 + 4 + 2 + 20) + (S + 64) + 8 * 4 + 16 + (size_t)LZW_SLOT_WORDS(block) * 4 + 8 + 4096) + 65536;
 }
 
 void lzw_carve(mi_ctx *ctx, uint32_t nb, uint32_t block, LzwScratch *sc)
@@ -524,6 +692,9 @@ void lzw_carve(mi_ctx *ctx, uint32_t nb, uint32_t block, LzwScratch *sc)
     sc->t_live = cv.take<uint8_t>(nb * (S + 64));
     sc->t_pos = cv.take<uint32_t>(nb * S); sc->t_mix = cv.take<uint32_t>(nb * S); sc->slot_of = cv.take<uint32_t>(nb * S);
     sc->cand = cv.take<uint32_t>(nb * S);
+    sc->ent = cv.take<uint32_t>(nb * S); sc->relw = cv.take<uint32_t>(nb * S); sc->cand_e = cv.take<uint16_t>(nb * S);
+    for (int c = 0; c < 5; ++c) sc->clist[c] = cv.take<uint64_t>(nb * S / 2 + 64);
+    sc->ccount = cv.take<uint32_t>(64);
     sc->slot = cv.take<uint32_t>((size_t)nb * sc->slot_words);
     sc->block_bits = cv.take<uint64_t>(nb + 1);
 }
@@ -556,10 +727,23 @@ mi_status lzw_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, u
       hipLaunchKernelGGL(k_lzw_sort, dim3(nb), dim3(1024), 0, s, n, P, sc, block0, 0xFFFFFFFFu, 3u, 1); }
     // the replay reads the (cluster, time) order from eA: copy it there (three passes end in eB)
     MI_HIP(ctx, hipMemcpyAsync(sc.eA, sc.eB, (size_t)nb * sc.S * 8, hipMemcpyDeviceToDevice, s));
+    MI_HIP(ctx, hipMemsetAsync(sc.ccount, 0, 64 * 4, s));
     { mi_prof_scope p(ctx, "k_lzw_heads", s, (uint64_t)nb * P.block);
-      hipLaunchKernelGGL(k_lzw_heads, dim3(chunks, nb), dim3(256), 0, s, n, P, sc, block0, 0); }
-    { mi_prof_scope p(ctx, "k_lzw_replay", s, (uint64_t)nb * P.block);
-      hipLaunchKernelGGL(k_lzw_replay, dim3((unsigned)ctx->num_cu * 16u), dim3(64), 0, s, d_in, n, P, sc, block0, nb); }
+      hipLaunchKernelGGL(k_lzw_heads, dim3(chunks, nb), dim3(256), 0, s, n, P, sc, block0, 0);
+      hipLaunchKernelGGL(k_lzw_classify, dim3(chunks, nb < 256 ? nb : 256), dim3(256), 0, s, sc, nb); }
+    // longest chains first: the launch of a class lasts as long as its largest cluster
+    { mi_prof_scope p(ctx, "k_lzw_replay(global)", s, (uint64_t)nb * P.block);
+      hipLaunchKernelGGL(k_lzw_replay, dim3((unsigned)ctx->num_cu), dim3(64), 0, s, d_in, n, P, sc, block0, nb); }
+    { mi_prof_scope p(ctx, "k_lzw_replay<24576>", s, (uint64_t)nb * P.block);
+      hipLaunchKernelGGL((k_lzw_replay_lds<LZW_CAP_L, 12>), dim3((unsigned)ctx->num_cu), dim3(64), 0, s, P, sc, 3u); }
+    { mi_prof_scope p(ctx, "k_lzw_replay<8192>", s, (uint64_t)nb * P.block);
+      hipLaunchKernelGGL((k_lzw_replay_lds<LZW_CAP_K, 4>), dim3((unsigned)ctx->num_cu * 3u), dim3(64), 0, s, P, sc, 2u); }
+    { mi_prof_scope p(ctx, "k_lzw_replay<4096>", s, (uint64_t)nb * P.block);
+      hipLaunchKernelGGL((k_lzw_replay_lds<LZW_CAP_M, 2>), dim3((unsigned)ctx->num_cu * 6u), dim3(64), 0, s, P, sc, 1u); }
+    { mi_prof_scope p(ctx, "k_lzw_replay<1024>", s, (uint64_t)nb * P.block);
+      hipLaunchKernelGGL((k_lzw_replay_lds<LZW_CAP_S, 1>), dim3((unsigned)ctx->num_cu * 64u), dim3(64), 0, s, P, sc, 0u); }
+    { mi_prof_scope p(ctx, "k_lzw_resolve", s, (uint64_t)nb * P.block);
+      hipLaunchKernelGGL(k_lzw_resolve, dim3((unsigned)ctx->num_cu * 32u), dim3(256), 0, s, sc); }
     MI_HIP(ctx, hipGetLastError());
     return MI_OK;
 }
