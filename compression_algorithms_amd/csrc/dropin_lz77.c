@@ -11,6 +11,16 @@ static uint32_t cur_wbits(void)
     return e ? (uint32_t)atoi(e) : g_wbits;
 }
 
+/* block size: MI_LZ77_BLOCK (default 65 536).  Up to 1 MiB (multiples of 256 above 64 KiB): the window then slides inside a
+ * block as in the reference, and a buffer of at most one block yields the reference's whole-buffer stream bit for bit. */
+static uint32_t cur_block(void)
+{
+    const char *e = getenv("MI_LZ77_BLOCK");
+    long v = e ? atol(e) : (long)MI_LZ77_BLOCK;
+    if (v < 1 || v > (1 << 20) || (v > 65536 && (v & 255))) { fprintf(stderr, "MI_LZ77_BLOCK: 1..65536, or a multiple of 256 up to 1048576\n"); exit(1); }
+    return (uint32_t)v;
+}
+
 uint64_t min(uint64_t a, uint64_t b) { return a < b ? a : b; }
 uint64_t max(uint64_t a, uint64_t b) { return a > b ? a : b; }
 
@@ -97,7 +107,7 @@ BitStream *lz77_compress(const char *buffer, uint64_t size)
 {
     mi_ctx *ctx = dropin_ctx();
     mi_lz_params p = mi_lz_params_lz77(cur_wbits());
-    p.block = MI_LZ77_BLOCK;
+    p.block = cur_block();
     const uint64_t nblocks = mi_lz_num_blocks(size, &p);
     const uint64_t cap = mi_lz_bound_bytes(size, &p) + 64;
     uint8_t *data = (uint8_t *)calloc(1, cap + 8);
@@ -121,7 +131,7 @@ char *lz77_decompress(BitStream *cs, uint64_t size, uint64_t *decompressed_size)
     cs->bit_index = 0;                                          /* lz77.c:355-356 */
     char *out = (char *)malloc(size ? size : 1);
     mi_lz_params p = mi_lz_params_lz77(cur_wbits());
-    p.block = MI_LZ77_BLOCK;
+    p.block = cur_block();
     uint64_t one[2] = {0, total};
     const uint64_t *bits = one;
     if (size > p.block) {

@@ -731,17 +731,27 @@ mi_status lzw_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, u
     { mi_prof_scope p(ctx, "k_lzw_heads", s, (uint64_t)nb * P.block);
       hipLaunchKernelGGL(k_lzw_heads, dim3(chunks, nb), dim3(256), 0, s, n, P, sc, block0, 0);
       hipLaunchKernelGGL(k_lzw_classify, dim3(chunks, nb < 256 ? nb : 256), dim3(256), 0, s, sc, nb); }
-    // longest chains first: the launch of a class lasts as long as its largest cluster
+    // The size classes are independent: their replays run side by side on the context's other streams (a launch lasts as
+    // long as its longest chain — one wave — so running them one after the other adds the tails up), joined before the
+    // resolve pass.
+    hipStream_t s1 = ctx->side ? ctx->side : s, s2 = ctx->parse ? ctx->parse : s, s3 = ctx->fb ? ctx->fb : s;
+    MI_HIP(ctx, hipEventRecord(ctx->ev_fork, s));
+    if (s1 != s) MI_HIP(ctx, hipStreamWaitEvent(s1, ctx->ev_fork, 0));
+    if (s2 != s) MI_HIP(ctx, hipStreamWaitEvent(s2, ctx->ev_fork, 0));
+    if (s3 != s) MI_HIP(ctx, hipStreamWaitEvent(s3, ctx->ev_fork, 0));
     { mi_prof_scope p(ctx, "k_lzw_replay(global)", s, (uint64_t)nb * P.block);
       hipLaunchKernelGGL(k_lzw_replay, dim3((unsigned)ctx->num_cu), dim3(64), 0, s, d_in, n, P, sc, block0, nb); }
     { mi_prof_scope p(ctx, "k_lzw_replay<24576>", s, (uint64_t)nb * P.block);
       hipLaunchKernelGGL((k_lzw_replay_lds<LZW_CAP_L, 12>), dim3((unsigned)ctx->num_cu), dim3(64), 0, s, P, sc, 3u); }
-    { mi_prof_scope p(ctx, "k_lzw_replay<8192>", s, (uint64_t)nb * P.block);
-      hipLaunchKernelGGL((k_lzw_replay_lds<LZW_CAP_K, 4>), dim3((unsigned)ctx->num_cu * 3u), dim3(64), 0, s, P, sc, 2u); }
-    { mi_prof_scope p(ctx, "k_lzw_replay<4096>", s, (uint64_t)nb * P.block);
-      hipLaunchKernelGGL((k_lzw_replay_lds<LZW_CAP_M, 2>), dim3((unsigned)ctx->num_cu * 6u), dim3(64), 0, s, P, sc, 1u); }
-    { mi_prof_scope p(ctx, "k_lzw_replay<1024>", s, (uint64_t)nb * P.block);
-      hipLaunchKernelGGL((k_lzw_replay_lds<LZW_CAP_S, 1>), dim3((unsigned)ctx->num_cu * 64u), dim3(64), 0, s, P, sc, 0u); }
+    { mi_prof_scope p(ctx, "k_lzw_replay<8192>", s1, (uint64_t)nb * P.block);
+      hipLaunchKernelGGL((k_lzw_replay_lds<LZW_CAP_K, 4>), dim3((unsigned)ctx->num_cu * 3u), dim3(64), 0, s1, P, sc, 2u); }
+    { mi_prof_scope p(ctx, "k_lzw_replay<4096>", s2, (uint64_t)nb * P.block);
+      hipLaunchKernelGGL((k_lzw_replay_lds<LZW_CAP_M, 2>), dim3((unsigned)ctx->num_cu * 6u), dim3(64), 0, s2, P, sc, 1u); }
+    { mi_prof_scope p(ctx, "k_lzw_replay<1024>", s3, (uint64_t)nb * P.block);
+      hipLaunchKernelGGL((k_lzw_replay_lds<LZW_CAP_S, 1>), dim3((unsigned)ctx->num_cu * 64u), dim3(64), 0, s3, P, sc, 0u); }
+    if (s1 != s) { MI_HIP(ctx, hipEventRecord(ctx->ev_replay[0], s1)); MI_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_replay[0], 0)); }
+    if (s2 != s) { MI_HIP(ctx, hipEventRecord(ctx->ev_replay[1], s2)); MI_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_replay[1], 0)); }
+    if (s3 != s) { MI_HIP(ctx, hipEventRecord(ctx->ev_replay[2], s3)); MI_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_replay[2], 0)); }
     { mi_prof_scope p(ctx, "k_lzw_resolve", s, (uint64_t)nb * P.block);
       hipLaunchKernelGGL(k_lzw_resolve, dim3((unsigned)ctx->num_cu * 32u), dim3(256), 0, s, sc); }
     MI_HIP(ctx, hipGetLastError());

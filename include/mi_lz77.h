@@ -8,7 +8,9 @@
  *   check_buffer_equivalence        algorithms/lz77/lz77.h:45-49   (lz77.c:379-392)
  *   read_input_buffer, min          algorithms/lz77/lz77.h:11,37   (used by lz77/main.c)
  *
- * Behaviour.  The buffer is cut into MI_LZ77_BLOCK-byte blocks that are encoded
+ * Behaviour.  The buffer is cut into MI_LZ77_BLOCK-byte blocks (64 KiB by default; up to 1 MiB through the environment
+ * variable of the same name — the window then slides inside a block as in the reference, on a slower, HBM-resident
+ * finder) that are encoded
  * independently on the GPU, each exactly as the reference encodes a buffer of that size
  * (WINDOW_BITS / LENGTH_BITS / TABLE_SIZE as in lz77.h:6-8), and the block streams are
  * concatenated bit-contiguously.  A buffer of at most one block therefore yields the
@@ -29,7 +31,7 @@
 #define WINDOW_BITS 14          /* override with -DWINDOW_BITS=16 for the 64 KiB window; or MI_LZ77_WINDOW_BITS at run time */
 #endif
 #define TABLE_SIZE (1 << (WINDOW_BITS + 6))
-#define MI_LZ77_BLOCK 65536u
+#define MI_LZ77_BLOCK 65536u      /* default; MI_LZ77_BLOCK=<bytes> at run time: up to 1048576 (multiples of 256 above 65536) */
 
 #ifdef __cplusplus
 extern "C" {

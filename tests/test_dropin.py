@@ -320,3 +320,33 @@ def test_huffman_framed_files(tmp_path):
     assert bits == want["bits"] and np.array_equal(words, want["words"]) and info.original_size == len(data)
     assert L.huffman_decompress_file(str(dst).encode(), str(back).encode()) == 0
     assert np.array_equal(np.fromfile(back, dtype=np.uint8), data)
+
+
+@pytest.mark.gpu
+def test_lz77_one_large_block_is_the_reference_stream(golden_dir, monkeypatch):
+    """MI_LZ77_BLOCK=1048576: a buffer of at most one block is encoded as the reference encodes the WHOLE buffer —
+    the committed whole-buffer vectors of the compiled reference (tests/golden/enwik_like_300k.json, lz77_w{14,16}_whole)"""
+    import hashlib
+    import json
+    e = json.load(open(os.path.join(golden_dir, "enwik_like_300k.json")))
+    sample = np.fromfile(os.path.join(golden_dir, "enwik_like_300k.bin"), dtype=np.uint8)
+    monkeypatch.setenv("MI_LZ77_BLOCK", "1048576")
+    L = _load("lz77")
+    L.lz77_compress.restype = C.POINTER(BitStream)
+    L.lz77_compress.argtypes = [C.c_void_p, C.c_uint64]
+    L.lz77_decompress.restype = C.c_void_p
+    L.lz77_decompress.argtypes = [C.POINTER(BitStream), C.c_uint64, C.POINTER(C.c_uint64)]
+    L.mi_lz77_set_window_bits.argtypes = [C.c_uint32]
+    for wb in (14, 16):
+        L.mi_lz77_set_window_bits(wb)
+        bs = L.lz77_compress(sample.ctypes.data_as(C.c_void_p), len(sample))
+        nbits = int(bs.contents.bit_index)
+        got = np.ctypeslib.as_array(bs.contents.data, shape=(nbits // 8 + 1,)).copy()
+        if nbits % 8:
+            got[-1] &= (1 << (nbits % 8)) - 1
+        want = e[f"lz77_w{wb}_whole"]
+        assert nbits == want["bits"] and hashlib.sha256(got.tobytes()).hexdigest() == want["sha256"], wb
+        dsz = C.c_uint64(0)
+        out = L.lz77_decompress(bs, len(sample), C.byref(dsz))
+        assert np.array_equal(np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(len(sample),)), sample)
+    L.mi_lz77_set_window_bits(14)
