@@ -361,7 +361,10 @@ def main():
             # config 2 (lz77, 10^8 B, W = 64 KiB and the shipped 16 KiB), config 3 (FSE table_log 8, 10^9 B)
             others = {}
             for key, wl, nb_ in (("config1_huffman_1e8", "huffman", 100_000_000), ("config2_lz77_w16_1e8", "lz77w16", 100_000_000),
-                                 ("config2_lz77_w14_1e8", "lz77w14", 100_000_000), ("config3_fse_1e9", "fse", 1_000_000_000)):
+                                 ("config2_lz77_w14_1e8", "lz77w14", 100_000_000),
+                                 ("config2_lz77_w16_256KiB_blocks_1e8", "lz77w16-256k", 100_000_000),
+                                 ("config2_lz77_w16_1MiB_blocks_1e8", "lz77w16-1m", 100_000_000),
+                                 ("config3_fse_1e9", "fse", 1_000_000_000)):
                 try:
                     co = Codec(wl, ctx)
                     xo = x[:nb_]

@@ -344,25 +344,24 @@ void k_lzw_replay_lds(LzP P, LzwScratch sc, uint32_t cls)
     }
 }
 
-// entry index -> position for every cluster the LDS replay handled
+// entry index -> position for every entry of a cluster the LDS replay handled (one thread per sorted entry, coalesced;
+// singletons were answered by k_lzw_heads, clusters above the LDS classes by k_lzw_replay itself)
 __global__ __launch_bounds__(256)
-void k_lzw_resolve(LzwScratch sc)
+void k_lzw_resolve(uint64_t n_total, LzP P, LzwScratch sc, uint64_t block0)
 {
-    for (uint32_t cls = 0; cls < 4; ++cls) {
-        const uint32_t count = sc.ccount[cls];
-        for (uint32_t ci = blockIdx.x; ci < count; ci += gridDim.x) {
-            const uint64_t item = sc.clist[cls][ci];
-            const uint32_t lb = (uint32_t)(item >> 32), c = (uint32_t)item;
-            const uint32_t *cs = sc.cstart + (size_t)lb * (sc.S + 2);
-            const uint32_t s = cs[c], m = cs[c + 1] - s;
-            const uint64_t *srt = sc.eA + (size_t)lb * sc.S + s;
-            const uint16_t *ce = sc.cand_e + (size_t)lb * sc.S + s;
-            uint32_t *cand = sc.cand + (size_t)lb * sc.S;
-            for (uint32_t i = threadIdx.x; i < m; i += 256u) {
-                const uint32_t r = ce[i];
-                cand[(uint32_t)srt[i]] = r == 0xFFFFu ? LZW_NONE : (uint32_t)srt[r];
-            }
-        }
+    const uint32_t lb = blockIdx.y;
+    const uint64_t off = (block0 + lb) * (uint64_t)P.block;
+    const uint32_t n = (uint32_t)((n_total - off) < P.block ? (n_total - off) : P.block);
+    const uint64_t *srt = sc.eA + (size_t)lb * sc.S;
+    const uint32_t *cs = sc.cstart + (size_t)lb * (sc.S + 2);
+    const uint16_t *ce = sc.cand_e + (size_t)lb * sc.S;
+    uint32_t *cand = sc.cand + (size_t)lb * sc.S;
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n; k += gridDim.x * 256u) {
+        const uint64_t e = srt[k];
+        const uint32_t g = (uint32_t)(e >> 32), s = cs[g], m = cs[g + 1] - s;
+        if (m < 2 || m > LZW_CAP_L) continue;
+        const uint32_t r = ce[k];
+        cand[(uint32_t)e] = r == 0xFFFFu ? LZW_NONE : (uint32_t)srt[s + r];
     }
 }
 
@@ -753,7 +752,7 @@ mi_status lzw_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, u
     if (s2 != s) { MI_HIP(ctx, hipEventRecord(ctx->ev_replay[1], s2)); MI_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_replay[1], 0)); }
     if (s3 != s) { MI_HIP(ctx, hipEventRecord(ctx->ev_replay[2], s3)); MI_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_replay[2], 0)); }
     { mi_prof_scope p(ctx, "k_lzw_resolve", s, (uint64_t)nb * P.block);
-      hipLaunchKernelGGL(k_lzw_resolve, dim3((unsigned)ctx->num_cu * 32u), dim3(256), 0, s, sc); }
+      hipLaunchKernelGGL(k_lzw_resolve, dim3(chunks, nb), dim3(256), 0, s, n, P, sc, block0); }
     MI_HIP(ctx, hipGetLastError());
     return MI_OK;
 }
