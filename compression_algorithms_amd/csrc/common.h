@@ -6,21 +6,20 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
-#include <vector>
-#include <string>
 
 #include "../../include/mi_codec.h"
 
 #define MI_WAVE 64
 
+// kernel timing records: plain C arrays (the host side of this library uses no C++ containers or strings)
+#define MI_PROF_KERNELS 48
+#define MI_PROF_PENDING 8192
 struct mi_prof_entry {
-    std::string name;
-    double      ms = 0.0;
-    uint64_t    launches = 0;
-    uint64_t    bytes = 0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
-    std::vector<uint64_t> pending_bytes;
+    const char *name;                   // a string literal of the launch site
+    double      ms;
+    uint64_t    launches, bytes;
 };
+struct mi_prof_pending { hipEvent_t a, b; uint64_t bytes; int idx; };
 
 struct mi_ctx {
     int         device = 0;
@@ -47,8 +46,12 @@ struct mi_ctx {
     uint32_t   *d_err = nullptr;
     uint32_t    err_next = 0;
 #define MI_ERR_SLOTS 256
-    std::vector<mi_prof_entry> prof;
-    std::vector<hipEvent_t>    event_pool;
+    mi_prof_entry    prof[MI_PROF_KERNELS];
+    int              nprof = 0;
+    mi_prof_pending *pending = nullptr;     // [MI_PROF_PENDING], allocated when profiling is first switched on
+    int              npending = 0;
+    hipEvent_t      *event_pool = nullptr;  // [2 * MI_PROF_PENDING]
+    int              npool = 0;
 };
 
 #define MI_HIP(ctx, call)                                                     \
@@ -71,7 +74,7 @@ hipStream_t mi_host_stream(mi_ctx *ctx);
 
 // profiling: bracket a launch with events on the launch stream
 struct mi_prof_scope {
-    mi_ctx *ctx; int idx; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
+    mi_ctx *ctx; int idx; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; uint64_t pbytes = 0;
     mi_prof_scope(mi_ctx *c, const char *name, hipStream_t st, uint64_t bytes);
     ~mi_prof_scope();
 };

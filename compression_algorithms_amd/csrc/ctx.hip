@@ -67,10 +67,11 @@ mi_status mi_ctx_create(mi_ctx **out, int device)
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
         return MI_ERR_NO_DEVICE;
-    mi_ctx *c = new (std::nothrow) mi_ctx();
+    mi_ctx *c = (mi_ctx *)calloc(1, sizeof(mi_ctx));
     if (!c) return MI_ERR_NOMEM;
+    c->num_cu = 256;
     c->device = device;
-    if (hipSetDevice(device) != hipSuccess) { delete c; return MI_ERR_NO_DEVICE; }
+    if (hipSetDevice(device) != hipSuccess) { free(c); return MI_ERR_NO_DEVICE; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
     // The host-buffer stream is created on first use (mi_host_stream).  Measured on the deflate pipeline, same box: the
@@ -109,9 +110,9 @@ void mi_ctx_destroy(mi_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     hipDeviceSynchronize();
-    for (auto &p : c->prof)
-        for (auto &ev : p.pending) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
-    for (auto e : c->event_pool) hipEventDestroy(e);
+    for (int i = 0; i < c->npending; ++i) { hipEventDestroy(c->pending[i].a); hipEventDestroy(c->pending[i].b); }
+    for (int i = 0; i < c->npool; ++i) hipEventDestroy(c->event_pool[i]);
+    free(c->pending); free(c->event_pool);
     if (c->ws) hipFree(c->ws);
     if (c->d_err) hipFree(c->d_err);
     if (c->h_pinned) hipHostFree(c->h_pinned);
@@ -127,7 +128,7 @@ void mi_ctx_destroy(mi_ctx *c)
         if (c->ev_fb[i]) hipEventDestroy(c->ev_fb[i]);
     }
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
-    delete c;
+    free(c);
 }
 
 int mi_last_hip_error(const mi_ctx *c) { return c ? c->last_hip : 0; }
@@ -142,6 +143,11 @@ mi_status mi_sync(mi_ctx *c, void *stream)
 mi_status mi_set_profiling(mi_ctx *c, int on)
 {
     if (!c) return MI_ERR_ARG;
+    if (on && !c->pending) {
+        c->pending = (mi_prof_pending *)calloc(MI_PROF_PENDING, sizeof(mi_prof_pending));
+        c->event_pool = (hipEvent_t *)calloc(2 * MI_PROF_PENDING, sizeof(hipEvent_t));
+        if (!c->pending || !c->event_pool) { free(c->pending); free(c->event_pool); c->pending = nullptr; c->event_pool = nullptr; return MI_ERR_NOMEM; }
+    }
     c->profiling = on;
     return MI_OK;
 }
@@ -149,22 +155,23 @@ mi_status mi_set_profiling(mi_ctx *c, int on)
 int mi_get_kernel_times(mi_ctx *c, mi_kernel_time *out, int cap)
 {
     if (!c || !out) return 0;
-    int n = 0;
-    for (auto &p : c->prof) {
-        for (size_t i = 0; i < p.pending.size(); ++i) {
-            float ms = 0.f;
-            hipEventSynchronize(p.pending[i].second);
-            if (hipEventElapsedTime(&ms, p.pending[i].first, p.pending[i].second) == hipSuccess) {
-                p.ms += ms; p.launches += 1; p.bytes += p.pending_bytes[i];
-            }
-            c->event_pool.push_back(p.pending[i].first);
-            c->event_pool.push_back(p.pending[i].second);
+    for (int i = 0; i < c->npending; ++i) {
+        mi_prof_pending &q = c->pending[i];
+        float ms = 0.f;
+        hipEventSynchronize(q.b);
+        if (hipEventElapsedTime(&ms, q.a, q.b) == hipSuccess) {
+            mi_prof_entry &p = c->prof[q.idx];
+            p.ms += ms; p.launches += 1; p.bytes += q.bytes;
         }
-        p.pending.clear(); p.pending_bytes.clear();
+        c->event_pool[c->npool++] = q.a;
+        c->event_pool[c->npool++] = q.b;
     }
-    for (auto &p : c->prof) {
+    c->npending = 0;
+    int n = 0;
+    for (int i = 0; i < c->nprof; ++i) {
+        mi_prof_entry &p = c->prof[i];
         if (!p.launches || n >= cap) continue;
-        out[n].name = p.name.c_str();
+        out[n].name = p.name;
         out[n].ms = p.ms / (double)p.launches;
         out[n].launches = p.launches;
         out[n].bytes = p.bytes;
@@ -223,7 +230,7 @@ mi_status mi_ws_reserve(mi_ctx *c, size_t bytes)
 
 static hipEvent_t take_event(mi_ctx *c)
 {
-    if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+    if (c->npool > 0) return c->event_pool[--c->npool];
     hipEvent_t e = nullptr;
     hipEventCreate(&e);
     return e;
@@ -231,11 +238,15 @@ static hipEvent_t take_event(mi_ctx *c)
 
 mi_prof_scope::mi_prof_scope(mi_ctx *c, const char *name, hipStream_t st, uint64_t bytes) : ctx(c), idx(-1), s(st)
 {
-    if (!c->profiling) return;
-    for (size_t i = 0; i < c->prof.size(); ++i) if (c->prof[i].name == name) { idx = (int)i; break; }
-    if (idx < 0) { c->prof.emplace_back(); c->prof.back().name = name; idx = (int)c->prof.size() - 1; }
+    if (!c->profiling || !c->pending || c->npending >= MI_PROF_PENDING) return;
+    for (int i = 0; i < c->nprof; ++i) if (strcmp(c->prof[i].name, name) == 0) { idx = i; break; }
+    if (idx < 0) {
+        if (c->nprof >= MI_PROF_KERNELS) return;
+        idx = c->nprof++;
+        c->prof[idx].name = name; c->prof[idx].ms = 0; c->prof[idx].launches = 0; c->prof[idx].bytes = 0;
+    }
     a = take_event(c); b = take_event(c);
-    c->prof[idx].pending_bytes.push_back(bytes);
+    pbytes = bytes;
     hipEventRecord(a, s);
 }
 
@@ -243,5 +254,6 @@ mi_prof_scope::~mi_prof_scope()
 {
     if (idx < 0) return;
     hipEventRecord(b, s);
-    ctx->prof[idx].pending.emplace_back(a, b);
+    mi_prof_pending &q = ctx->pending[ctx->npending++];
+    q.a = a; q.b = b; q.bytes = pbytes; q.idx = idx;
 }

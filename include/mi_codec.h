@@ -14,9 +14,15 @@
  *   h_*   host pointers.
  *   stream: a hipStream_t passed as void* (NULL = HIP's default stream, as everywhere in HIP).
  *           The host-buffer convenience calls use a private stream of the context.
- * All *_dev functions are asynchronous on `stream` unless stated; they never allocate
- * (workspace lives in the context and grows only in mi_ctx_reserve / on first use of a
- * larger size, before any launch), so a caller may capture them in a hipGraph.
+ * Encoders (*_encode_dev, mi_huffman_hist/build/encode_with_tree_dev, mi_fse_normalise_dev) are asynchronous on `stream`.
+ * Their scratch is the context workspace: it grows — hipDeviceSynchronize + hipFree + hipMalloc — only when a call needs
+ * more than any earlier call of the context did; after a first call of the largest size a context will see, the encoders
+ * neither allocate nor synchronise.  One encode per context may be in flight at a time (the workspace is shared; use one
+ * context per concurrent stream).  The LZ encoders fork onto three internal streams of the context and join back into
+ * `stream` with events before they return control of it.
+ * Decoders (*_decode_dev) synchronise `stream` before returning: MI_ERR_CORRUPT is decided on the device.  They take the
+ * readable length of the stream and never read outside it, whatever an (untrusted) offset table says; every decode call
+ * uses its own device status word, so decodes on different streams of one context do not interfere.
  */
 #ifndef MI_CODEC_H
 #define MI_CODEC_H
