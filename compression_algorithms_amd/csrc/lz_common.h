@@ -74,8 +74,8 @@ struct LzwScratch {
     uint32_t *ent;              // [nb][S] per (cluster, time)-sorted entry: home slot relative to the cluster | word id << 16
     uint32_t *relw;             // [nb][S] by position: the same pair, written by the sweep
     uint16_t *cand_e;           // [nb][S] per sorted entry: index (inside its cluster) of the entry find() returned, 0xFFFF = none
-    uint64_t *clist[5];         // per size class: block << 32 | cluster number (classes: <= 1024, <= 4096, <= 8192, <= 24576 entries, larger)
-    uint32_t *ccount;           // [5] entries of the class lists (zeroed per batch)
+    uint64_t *clist[6];         // per size class: block << 32 | cluster number (classes: <= 1024, <= 4096, <= 8192, <= 24576 entries, larger; 5: 2..7 entries)
+    uint32_t *ccount;           // [6] entries of the class lists (zeroed per batch)
     uint32_t *slot;             // [nb][slot_words] block-local token stream
     uint64_t *block_bits;       // [nb + 1]
     uint32_t  S, slot_words;

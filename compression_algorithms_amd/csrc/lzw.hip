@@ -221,7 +221,8 @@ void k_lzw_sweep(uint64_t n_total, LzP P, LzwScratch sc, uint64_t block0, int so
 #define LZW_CAP_M 4096u
 #define LZW_CAP_L 24576u
 #define LZW_CAP_K 8192u
-#define LZW_NCLS  5u
+#define LZW_NCLS  6u
+#define LZW_TINY  7u                        // clusters of 2..7 entries: one LANE each, the table in registers
 __global__ __launch_bounds__(256)
 void k_lzw_heads(uint64_t n_total, LzP P, LzwScratch sc, uint64_t block0, int sorted_in_b)
 {
@@ -263,7 +264,7 @@ void k_lzw_classify(LzwScratch sc, uint32_t nb)
             uint32_t cls = LZW_NCLS, rank = 0;
             if (c < ncl) {
                 const uint32_t m = cs[c + 1] - cs[c];
-                if (m >= 2) { cls = m <= LZW_CAP_S ? 0u : m <= LZW_CAP_M ? 1u : m <= LZW_CAP_K ? 2u : m <= LZW_CAP_L ? 3u : 4u; rank = atomicAdd(&s_n[cls], 1u); }
+                if (m >= 2) { cls = m <= LZW_TINY ? 5u : m <= LZW_CAP_S ? 0u : m <= LZW_CAP_M ? 1u : m <= LZW_CAP_K ? 2u : m <= LZW_CAP_L ? 3u : 4u; rank = atomicAdd(&s_n[cls], 1u); }
             }
             __syncthreads();
             if (threadIdx.x < LZW_NCLS && s_n[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&sc.ccount[threadIdx.x], s_n[threadIdx.x]);
@@ -341,6 +342,53 @@ void k_lzw_replay_lds(LzP P, LzwScratch sc, uint32_t cls)
             if (ii < m) ce[ii] = (uint16_t)out_acc;
         }
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// clusters of 2..7 entries (most clusters of a text): one LANE per cluster, the whole table in registers — 7 occupancy bits and
+// 3-bit fields for the occupant's word id, the occupant's entry index and every entry's bucket (the shape of
+// replay_small_reg in lz2_find.hip, with 32-bit positions)
+__global__ __launch_bounds__(256)
+void k_lzw_replay_tiny(LzP P, LzwScratch sc)
+{
+    const uint32_t W = 1u << P.wbits;
+    const uint32_t count = sc.ccount[5];
+    for (uint32_t ci = blockIdx.x * 256u + threadIdx.x; ci < count; ci += gridDim.x * 256u) {
+        const uint64_t item = sc.clist[5][ci];
+        const uint32_t lb = (uint32_t)(item >> 32), c = (uint32_t)item;
+        const uint32_t *cs = sc.cstart + (size_t)lb * (sc.S + 2);
+        const uint32_t s = cs[c], m = cs[c + 1] - s;
+        const uint64_t *srt = sc.eA + (size_t)lb * sc.S + s;
+        const uint32_t *ent = sc.ent + (size_t)lb * sc.S + s;
+        uint16_t *ce = sc.cand_e + (size_t)lb * sc.S + s;
+        uint32_t pos[LZW_TINY], en[LZW_TINY];
+#pragma unroll
+        for (uint32_t k = 0; k < LZW_TINY; ++k) { pos[k] = 0; en[k] = 0; if (k < m) { pos[k] = (uint32_t)srt[k]; en[k] = ent[k]; } }
+        bool anom_pending = (c == 0u) && sc.ncl[(size_t)lb * 4 + 1];
+        uint32_t mask = 0, occ_id = 0, occ_en = 0, slots = 0, ev = 0;
+        auto pos_of = [&](uint32_t k) -> uint32_t {
+            uint32_t v = pos[0];
+#pragma unroll
+            for (uint32_t q = 1; q < LZW_TINY; ++q) v = (k == q) ? pos[q] : v;
+            return v;
+        };
+#pragma unroll
+        for (uint32_t k = 0; k < LZW_TINY; ++k) {
+            if (k < m) {
+                const uint32_t p = pos[k], r = en[k] & 0xFFFFu, id = en[k] >> 16;
+                while (ev < k && (uint64_t)pos_of(ev) + W < (uint64_t)p) { mask &= ~(1u << ((slots >> (3u * ev)) & 7u)); ++ev; }   // FIFO retirement
+                if (anom_pending && p > W - 1u) { mask &= ~1u; anom_pending = false; }
+                uint32_t res = 0xFFFFu;
+                for (uint32_t b = r; (mask >> b) & 1u; ++b)                     // bits >= m are never set: the walk ends inside the cluster
+                    if (((occ_id >> (3u * b)) & 7u) == id) { res = (occ_en >> (3u * b)) & 7u; break; }
+                const uint32_t b = r + (uint32_t)__builtin_ctz(~(mask >> r));   // first fit
+                mask |= 1u << b;
+                occ_id = (occ_id & ~(7u << (3u * b))) | (id << (3u * b));
+                occ_en = (occ_en & ~(7u << (3u * b))) | (k << (3u * b));
+                slots |= b << (3u * k);
+                ce[k] = (uint16_t)res;
+            }
+        }
     }
 }
 
@@ -677,7 +725,7 @@ void k_lzw_decode(const uint8_t *__restrict__ stream, uint64_t stream_bytes, con
 size_t lzw_scratch_bytes(uint32_t nb, uint32_t block)
 {
     const size_t S = mi_align_up(block, 256);
-    return (size_t)nb * (S * (8 + 8 + 4 + 4 + 4 + 4 + 4 + 4 + 4 + 4 + 4 + 2 + 20) + (S + 64) + 8 * 4 + 16 + (size_t)LZW_SLOT_WORDS(block) * 4 + 8 + 4096) + 65536;
+    return (size_t)nb * (S * (8 + 8 + 4 + 4 + 4 + 4 + 4 + 4 + 4 + 4 + 4 + 2 + 24) + (S + 64) + 8 * 4 + 16 + (size_t)LZW_SLOT_WORDS(block) * 4 + 8 + 4096) + 65536;
 }
 
 void lzw_carve(mi_ctx *ctx, uint32_t nb, uint32_t block, LzwScratch *sc)
@@ -692,7 +740,7 @@ void lzw_carve(mi_ctx *ctx, uint32_t nb, uint32_t block, LzwScratch *sc)
     sc->t_pos = cv.take<uint32_t>(nb * S); sc->t_mix = cv.take<uint32_t>(nb * S); sc->slot_of = cv.take<uint32_t>(nb * S);
     sc->cand = cv.take<uint32_t>(nb * S);
     sc->ent = cv.take<uint32_t>(nb * S); sc->relw = cv.take<uint32_t>(nb * S); sc->cand_e = cv.take<uint16_t>(nb * S);
-    for (int c = 0; c < 5; ++c) sc->clist[c] = cv.take<uint64_t>(nb * S / 2 + 64);
+    for (int c = 0; c < 6; ++c) sc->clist[c] = cv.take<uint64_t>(nb * S / 2 + 64);
     sc->ccount = cv.take<uint32_t>(64);
     sc->slot = cv.take<uint32_t>((size_t)nb * sc->slot_words);
     sc->block_bits = cv.take<uint64_t>(nb + 1);
@@ -746,6 +794,8 @@ mi_status lzw_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, u
       hipLaunchKernelGGL((k_lzw_replay_lds<LZW_CAP_K, 4>), dim3((unsigned)ctx->num_cu * 3u), dim3(64), 0, s1, P, sc, 2u); }
     { mi_prof_scope p(ctx, "k_lzw_replay<4096>", s2, (uint64_t)nb * P.block);
       hipLaunchKernelGGL((k_lzw_replay_lds<LZW_CAP_M, 2>), dim3((unsigned)ctx->num_cu * 6u), dim3(64), 0, s2, P, sc, 1u); }
+    { mi_prof_scope p(ctx, "k_lzw_replay_tiny", s3, (uint64_t)nb * P.block);
+      hipLaunchKernelGGL(k_lzw_replay_tiny, dim3((unsigned)ctx->num_cu * 16u), dim3(256), 0, s3, P, sc); }
     { mi_prof_scope p(ctx, "k_lzw_replay<1024>", s3, (uint64_t)nb * P.block);
       hipLaunchKernelGGL((k_lzw_replay_lds<LZW_CAP_S, 1>), dim3((unsigned)ctx->num_cu * 64u), dim3(64), 0, s3, P, sc, 0u); }
     if (s1 != s) { MI_HIP(ctx, hipEventRecord(ctx->ev_replay[0], s1)); MI_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_replay[0], 0)); }
