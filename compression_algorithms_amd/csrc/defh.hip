@@ -104,10 +104,8 @@ void k_defh_encode(const uint32_t *__restrict__ trec_all, uint32_t *__restrict__
     uint32_t *out = slots + (size_t)lb * LZ_SLOT_WORDS;
     auto symbol_of = [](uint32_t r) -> uint32_t { return (r >> 31) ? 256u + clz16(r) : (r & 0xFFu); };
 
-    // ---- tally (lz77.c:206,231,273)
-    for (int i = tid; i < DEFH_NSYM + 2; i += DEFH_THREADS) { s_hist[i] = 0; s_len[i] = 0; }
-    __syncthreads();
-    for (uint32_t t = tid; t < ntok; t += DEFH_THREADS) atomicAdd(&s_hist[symbol_of(trec[t])], 1u);
+    // ---- tally (lz77.c:206,231,273): taken by k_lz_parse_emit while it wrote the token records, left at the end of the slot
+    for (int i = tid; i < DEFH_NSYM + 2; i += DEFH_THREADS) { s_hist[i] = out[LZ_DEFH_HIST_AT + i]; s_len[i] = 0; }
     __syncthreads();
 
     // ---- code lengths: the reference heap, leaves enqueued in symbol order (one lane; <= 285 merges)

@@ -59,6 +59,7 @@ struct LzScratch {
     uint64_t    *block_bits;       // [nb] bits produced per block (this batch)
 };
 #define LZ_SLOT_WORDS  (LZ_MAX_BLOCK / 2 + 16)     // 2 bytes per input byte worst case (+ slack), in u32
+#define LZ_DEFH_HIST_AT 32000u                    // mode H: k_lz_parse_emit leaves the block's 286-bin tally here (a record is < 18 508 words)
 
 // scratch of the HBM-resident finder for blocks above 64 KiB (lzw.hip)
 struct LzwScratch {

@@ -266,17 +266,26 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     if (trec_all) {
         // mode H (defh.hip): no packed tokens; one 32-bit record per token, in token order, for the entropy stage:
         //   literal  byte                       match  1<<31 | length << 16 | distance
+        // The 286-bin tally of the block (deflate/lz77.c:206,231,273; deflate/huffman.c:49-62) is taken here, where every
+        // token passes by anyway, and handed to k_defh_encode at the end of the block's slot: it no longer reads the
+        // token records twice.
         uint32_t *trec = trec_all + (size_t)lb * LZ_MAX_BLOCK;
+        for (uint32_t i = tid; i < 288u; i += 1024u) stage[i] = 0;
+        __syncthreads();
         for (uint32_t t = tid; t < ntok; t += 1024u) {
             const uint32_t c = chunk_of(t), o = select_bit(s_tok[c], t - tb[c]), p = c * 64u + o;
-            uint32_t rec;
+            uint32_t rec, sym;
             if ((s_mat[c] >> o) & 1ull) {
                 const uint32_t mbefore = mb[c] + (uint32_t)__popcll(s_mat[c] & ((1ull << o) - 1ull));
                 const uint32_t d = lists ? (uint32_t)md[mbefore] : p - cand[p];
                 rec = 0x80000000u | ((uint32_t)s_L[p] << 16) | d;
-            } else rec = src[p];
+                sym = 256u + ((uint32_t)__builtin_clz(d & 0xFFFFu) - 16u);
+            } else { rec = src[p]; sym = rec; }
+            atomicAdd(&stage[sym], 1u);
             trec[t] = rec;
         }
+        __syncthreads();
+        for (uint32_t i = tid; i < 288u; i += 1024u) slot[LZ_DEFH_HIST_AT + i] = stage[i];
         if (tid == 0) sc.block_bits[lb] = ntok;
         return;
     }
