@@ -24,38 +24,50 @@
 #define DEFH_MAXBITS  44u           // code <= 24 (65536 tokens: Fibonacci bound) + 15 offset bits + 5 length bits
 #define DEFH_LUT_BITS 11
 
+// The reference's array heap (algorithms/huffman/huffman.c:100-163: strict '<' on the frequency in both sifts, leaves
+// enqueued in symbol order, first pop = left).  A heap cell holds frequency << 10 | node id (frequencies are <= 65 536
+// tokens, ids < 572), so a comparison is ONE LDS read per node instead of two dependent ones (heap[i], then freq[heap[i]]):
+// the merge loop runs on one lane and is the critical path of k_defh_encode.  Ties are still decided by position alone:
+// only the frequency field is compared.
 struct DefhHeap {
     uint32_t freq[2 * DEFH_NSYM];
     int16_t  parent[2 * DEFH_NSYM];
-    int16_t  heap[DEFH_NSYM];
+    uint32_t heap[DEFH_NSYM];            // frequency << 10 | node id
     int16_t  leaf_of[DEFH_NSYM];
     int      nheap, nnodes, root;
 };
+#define DH_F(c) ((c) >> 10)
+#define DH_ID(c) ((int)((c) & 1023u))
 
 __device__ inline void dh_up(DefhHeap &h, int i)
 {
+    const uint32_t me = h.heap[i];
     while (i > 0) {
         const int par = (i - 1) >> 1;
-        if (!(h.freq[h.heap[i]] < h.freq[h.heap[par]])) break;
-        const int16_t t = h.heap[i]; h.heap[i] = h.heap[par]; h.heap[par] = t;
+        const uint32_t pc = h.heap[par];
+        if (!(DH_F(me) < DH_F(pc))) break;
+        h.heap[i] = pc;
         i = par;
     }
+    h.heap[i] = me;
 }
 __device__ inline void dh_down(DefhHeap &h, int i)
 {
+    const uint32_t me = h.heap[i];
     for (;;) {
         const int l = 2 * i + 1, r = l + 1;
-        int best = i;
-        if (l < h.nheap && h.freq[h.heap[l]] < h.freq[h.heap[best]]) best = l;
-        if (r < h.nheap && h.freq[h.heap[r]] < h.freq[h.heap[best]]) best = r;
-        if (best == i) return;
-        const int16_t t = h.heap[i]; h.heap[i] = h.heap[best]; h.heap[best] = t;
+        int best = i; uint32_t bc = me;
+        if (l < h.nheap) { const uint32_t lc = h.heap[l]; if (DH_F(lc) < DH_F(bc)) { best = l; bc = lc; } }
+        if (r < h.nheap) { const uint32_t rc = h.heap[r]; if (DH_F(rc) < DH_F(bc)) { best = r; bc = rc; } }
+        if (best == i) break;
+        h.heap[i] = bc;
         i = best;
     }
+    h.heap[i] = me;
 }
 __device__ inline int dh_pop(DefhHeap &h)
 {
-    const int id = h.heap[0];
+    const int id = DH_ID(h.heap[0]);
     h.heap[0] = h.heap[--h.nheap];
     dh_down(h, 0);
     return id;
@@ -117,7 +129,7 @@ void k_defh_encode(const uint32_t *__restrict__ trec_all, uint32_t *__restrict__
             if (!f) continue;
             const int id = h.nnodes++;
             h.freq[id] = f; h.parent[id] = -1; h.leaf_of[s] = (int16_t)id;
-            h.heap[h.nheap++] = (int16_t)id;
+            h.heap[h.nheap++] = (f << 10) | (uint32_t)id;
             dh_up(h, h.nheap - 1);
         }
         if (h.nnodes > 1) {
@@ -125,7 +137,7 @@ void k_defh_encode(const uint32_t *__restrict__ trec_all, uint32_t *__restrict__
                 const int l = dh_pop(h), r = dh_pop(h), id = h.nnodes++;
                 h.freq[id] = h.freq[l] + h.freq[r]; h.parent[id] = -1;
                 h.parent[l] = (int16_t)id; h.parent[r] = (int16_t)id;
-                h.heap[h.nheap++] = (int16_t)id;
+                h.heap[h.nheap++] = (h.freq[id] << 10) | (uint32_t)id;
                 dh_up(h, h.nheap - 1);
             }
             h.root = dh_pop(h);
