@@ -73,34 +73,42 @@ struct HeapLds {
     uint32_t freq[511];
     int16_t  left[511], right[511], parent[511];
     uint8_t  value[511], is_right[511];
-    int16_t  heap[256];
+    uint64_t heap[256];                 // frequency << 16 | node id: a comparison is ONE LDS read per node (the loop runs on one lane)
     int16_t  leaf_of[256];
     int      nheap, nnodes, root;
 };
+#define HH_F(c) ((uint32_t)((c) >> 16))
+#define HH_ID(c) ((int)((c) & 0xFFFFu))
 
 __device__ inline void heap_up(HeapLds &h, int i)
 {
+    const uint64_t me = h.heap[i];
     while (i > 0) {
-        int par = (i - 1) >> 1;
-        if (!(h.freq[h.heap[i]] < h.freq[h.heap[par]])) break;
-        int16_t t = h.heap[i]; h.heap[i] = h.heap[par]; h.heap[par] = t;
+        const int par = (i - 1) >> 1;
+        const uint64_t pc = h.heap[par];
+        if (!(HH_F(me) < HH_F(pc))) break;           // strict '<' on the frequency alone: ties keep their places (huffman.c:111-119)
+        h.heap[i] = pc;
         i = par;
     }
+    h.heap[i] = me;
 }
 __device__ inline void heap_down(HeapLds &h, int i)
 {
+    const uint64_t me = h.heap[i];
     for (;;) {
-        int l = 2 * i + 1, r = l + 1, best = i;
-        if (l < h.nheap && h.freq[h.heap[l]] < h.freq[h.heap[best]]) best = l;
-        if (r < h.nheap && h.freq[h.heap[r]] < h.freq[h.heap[best]]) best = r;
-        if (best == i) return;
-        int16_t t = h.heap[i]; h.heap[i] = h.heap[best]; h.heap[best] = t;
+        const int l = 2 * i + 1, r = l + 1;
+        int best = i; uint64_t bc = me;
+        if (l < h.nheap) { const uint64_t lc = h.heap[l]; if (HH_F(lc) < HH_F(bc)) { best = l; bc = lc; } }
+        if (r < h.nheap) { const uint64_t rc = h.heap[r]; if (HH_F(rc) < HH_F(bc)) { best = r; bc = rc; } }
+        if (best == i) break;
+        h.heap[i] = bc;
         i = best;
     }
+    h.heap[i] = me;
 }
 __device__ inline int heap_pop(HeapLds &h)
 {
-    int id = h.heap[0];
+    const int id = HH_ID(h.heap[0]);
     h.heap[0] = h.heap[--h.nheap];
     heap_down(h, 0);
     return id;
@@ -127,7 +135,7 @@ void k_huff_build(const uint32_t *__restrict__ hist, mi_huffman_tree *__restrict
             int id = h.nnodes++;
             h.freq[id] = fs; h.left[id] = -1; h.right[id] = -1; h.parent[id] = -1;
             h.value[id] = (uint8_t)s; h.is_right[id] = 0; h.leaf_of[s] = (int16_t)id;
-            h.heap[h.nheap++] = (int16_t)id;
+            h.heap[h.nheap++] = ((uint64_t)fs << 16) | (uint64_t)id;
             heap_up(h, h.nheap - 1);
         }
         if (h.nheap > 0) {
@@ -138,7 +146,7 @@ void k_huff_build(const uint32_t *__restrict__ hist, mi_huffman_tree *__restrict
                 h.left[id] = (int16_t)l; h.right[id] = (int16_t)r; h.parent[id] = -1;
                 h.value[id] = 0; h.is_right[id] = 0;
                 h.parent[l] = (int16_t)id; h.parent[r] = (int16_t)id; h.is_right[r] = 1;
-                h.heap[h.nheap++] = (int16_t)id;
+                h.heap[h.nheap++] = ((uint64_t)h.freq[id] << 16) | (uint64_t)id;
                 heap_up(h, h.nheap - 1);
             }
             h.root = heap_pop(h);
