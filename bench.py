@@ -24,8 +24,12 @@ line also carries
 N > 1, --scaling weak (default): every rank encodes its own --bytes shard of independent blocks.
 N > 1, --scaling strong: ONE --bytes buffer (enwik9's size by default); rank r encodes the contiguous block range
 sharded.shard_bytes gives it (config 5: 1 908 blocks / 125 MB per GPU at N = 8).
-For N > 1 the north star's RCCL gather of the compressed streams to rank 0 is inside the timed region
-(--no-gather leaves it out).
+The north star's RCCL gather of the compressed streams to rank 0 (sharded.gather_streams: one all_gather of sizes, one
+group of point-to-point transfers over xGMI) is INSIDE the timed region for --scaling strong (config 5 as worded: one
+enwik9, 65 MB of mode-H stream per peer) and OUTSIDE it for the default weak scaling, where every rank owns a whole
+enwik9-sized shard and the path itself has no data-path collective (each rank's stream is a finished product; gathering
+8 x 0.5 GB into one GPU is not part of any BASELINE config): there it is run and timed once after the timed region and
+reported as `gather`.  --gather / --no-gather force it in or out.
 """
 import argparse
 import json
@@ -53,7 +57,7 @@ def parse_args():
     ap.add_argument("--bytes", type=int, default=1_000_000_000,
                     help="input bytes per GPU (weak) or of the whole job (strong)")
     ap.add_argument("--gather", dest="gather", action="store_true", default=None,
-                    help="N>1: gather the compressed streams to rank 0 inside the timed region (default for N>1)")
+                    help="N>1: gather the compressed streams to rank 0 inside the timed region (default for --scaling strong)")
     ap.add_argument("--no-gather", dest="gather", action="store_false")
     ap.add_argument("--cpu-sample-mb", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -248,7 +252,8 @@ def main():
     from compression_algorithms_amd.context import Context
     ctx = Context(local)
     codec = Codec(args.workload, ctx)
-    gather = (world > 1 and args.workload != "huffman") if args.gather is None else (args.gather and world > 1)
+    can_gather = world > 1 and args.workload != "huffman"
+    gather = (can_gather and args.scaling == "strong") if args.gather is None else (args.gather and can_gather)
 
     if args.scaling == "strong":
         # ONE corpus of --bytes; rank r owns the contiguous block range of sharded.shard_bytes (config 5's shape)
@@ -298,6 +303,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
+    # ---- outside the timed region (weak scaling): the RCCL gather of the streams to rank 0, timed on its own
+    gather_report = None
+    if can_gather and not gather and args.gather is None:
+        try:
+            gather_streams(last)                      # warm-up: communicators, receive buffers
+            barrier()
+            tg0 = time.perf_counter()
+            gather_streams(last)
+            barrier()
+            tg = time.perf_counter() - tg0
+            tt = torch.tensor([tg], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            gather_report = {"ms": round(float(tt.item()) * 1e3, 3), "what": "one gather of every rank's last stream + block table to rank 0 "
+                             "(all_gather of sizes, one group of point-to-point transfers), outside the timed region"}
+        except Exception as e:                        # reported, never fatal for the throughput line
+            gather_report = {"ms": None, "error": repr(e)[:200]}
     # ---- outside the timed region: round trip of the last output on every rank
     back = codec.decode(last)
     rt_ok = bool(torch.equal(back, x))
@@ -438,7 +459,7 @@ def main():
                        "input_bytes_job": n_job, "input_bytes_rank0": n, "compressed_bytes_job": c_job, "compressed_bytes_rank0": int(c),
                        "ratio": round(n_job / max(c_job, 1), 4), "gather_to_rank0": bool(gather),
                        "parallelism": f"blocks sharded over {world} GPU(s), {args.scaling} scaling"},
-            "ratio": round(n_job / max(c_job, 1), 4), "ratio_vs_ref": ratio_vs_ref, "roundtrip": rt_ok,
+            "ratio": round(n_job / max(c_job, 1), 4), "ratio_vs_ref": ratio_vs_ref, "roundtrip": rt_ok, "gather": gather_report,
             "roofline": roof, "cpu_baseline": cpu,
         }
         line.update(extras)
