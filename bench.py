@@ -19,6 +19,7 @@ line also carries
     ratio_vs_ref  own output size against the reference's shipped compress() output (persistent table,
                   deflate/deflate.c:47-63) on a sample,
     roundtrip     decode(encode(x)) == x, checked once outside the timed region,
+    decode_gbps   this rank's decoder on its last stream (one call incl. its synchronisation, outside the timed region),
     end_to_end    the same step with a pinned-host input and the stream copied back (PCIe inclusive).
 
 N > 1, --scaling weak (default): every rank encodes its own --bytes shard of independent blocks.
@@ -323,6 +324,12 @@ def main():
     back = codec.decode(last)
     rt_ok = bool(torch.equal(back, x))
     del back
+    torch.cuda.synchronize()
+    td0 = time.perf_counter()
+    back = codec.decode(last)                         # the decoders synchronise their stream themselves (status word)
+    torch.cuda.synchronize()
+    decode_gbps = round(n / (time.perf_counter() - td0) / 1e9, 2)
+    del back
     if dist is not None:
         f = torch.tensor([1 if rt_ok else 0], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(f, op=dist.ReduceOp.MIN)
@@ -459,7 +466,7 @@ def main():
                        "input_bytes_job": n_job, "input_bytes_rank0": n, "compressed_bytes_job": c_job, "compressed_bytes_rank0": int(c),
                        "ratio": round(n_job / max(c_job, 1), 4), "gather_to_rank0": bool(gather),
                        "parallelism": f"blocks sharded over {world} GPU(s), {args.scaling} scaling"},
-            "ratio": round(n_job / max(c_job, 1), 4), "ratio_vs_ref": ratio_vs_ref, "roundtrip": rt_ok, "gather": gather_report,
+            "ratio": round(n_job / max(c_job, 1), 4), "ratio_vs_ref": ratio_vs_ref, "roundtrip": rt_ok, "decode_gbps": decode_gbps, "gather": gather_report,
             "roofline": roof, "cpu_baseline": cpu,
         }
         line.update(extras)

@@ -16,6 +16,7 @@
 //   k_defh_encode   one workgroup per block over the token records k_lz_parse_emit left (mode H)
 //   k_defh_decode   one wave per block: record -> tokens -> bytes (LZ copy in LDS), no token stream in HBM
 #include "lz_common.h"
+#include "lz_decode.h"
 
 #define DEFH_NSYM     286
 #define DEFH_HDR      292u          // bytes before the packed words
@@ -220,11 +221,12 @@ void defh_launch_encode(const uint32_t *trec, uint32_t *slots, uint64_t *block_b
 // decode: one wave per block.  Every lane reads the same bits (uniform control flow); the LZ copy of a
 // match is spread over the lanes, the output block is staged in LDS like k_lz_decode.
 // ---------------------------------------------------------------------------------------------
+template <uint32_t RING>
 __global__ __launch_bounds__(64)
 void k_defh_decode(const uint8_t *__restrict__ stream, uint64_t stream_bytes, const uint64_t *__restrict__ block_bits, LzP P,
                    uint8_t *__restrict__ out, uint64_t n_total, uint32_t *__restrict__ err)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_out[LZ_MAX_BLOCK + 256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_ring[RING];
     __shared__ uint16_t s_lut[1 << DEFH_LUT_BITS];                     // symbol | length << 9; 0xFFFF = longer than the table
     __shared__ uint8_t  s_len[DEFH_NSYM + 2];
     __shared__ uint32_t s_code[DEFH_NSYM + 2], s_count[34], s_next[34];
@@ -240,7 +242,9 @@ void k_defh_decode(const uint8_t *__restrict__ stream, uint64_t stream_bytes, co
     if (bad) { if (lane == 0) atomicOr(err, 1u); return; }
     const uint32_t *rec = reinterpret_cast<const uint32_t *>(stream + (rb >> 3));
     const uint32_t ntok = rec[0];
-    const uint32_t nwords = (uint32_t)(((re - rb) >> 5) - DEFH_HDR / 4);
+    // n bytes of output need at most n tokens of at most 64 bits
+    const uint64_t words64 = ((re - rb) >> 5) - DEFH_HDR / 4;
+    const uint32_t nwords = words64 > 2ull * n + 2u ? 2u * n + 2u : (uint32_t)words64;
     const uint32_t *w = rec + DEFH_HDR / 4;
     for (uint32_t i = lane; i < (DEFH_NSYM + 2) / 4; i += 64) reinterpret_cast<uint32_t *>(s_len)[i] = rec[1 + i];
     __syncthreads();
@@ -265,16 +269,18 @@ void k_defh_decode(const uint8_t *__restrict__ stream, uint64_t stream_bytes, co
     if (__ballot(bad) != 0ull) { if (lane == 0) atomicOr(err, 1u); return; }
     __syncthreads();
 
+    // every control value below is wave-uniform: the bit buffer sits in SGPRs and is refilled from 64 record words held
+    // one per lane (lz_decode.h); the only memory on a token's critical path is its LUT cell
     const uint64_t nbits = (uint64_t)nwords * 32u;
+    BitsMsb br;
+    br.init(w, nwords, lane);
+    OutRing<RING> ring;
+    ring.init(s_ring, out + off, lane);
     uint64_t pos = 0;
     uint32_t o = 0;
-    auto peek32 = [&](uint64_t q) -> uint32_t {                        // 32 stream bits from bit q, MSB first; zero past the end
-        const uint64_t wi = q >> 5; const uint32_t sh = (uint32_t)(q & 31u);
-        const uint32_t a = wi < nwords ? w[wi] : 0u, c = wi + 1 < nwords ? w[wi + 1] : 0u;
-        return sh ? (a << sh) | (c >> (32u - sh)) : a;
-    };
     for (uint32_t t = 0; t < ntok && o < n; ++t) {
-        const uint32_t v = peek32(pos);
+        br.refill();
+        const uint32_t v = br.top32();
         uint32_t sym, l;
         const uint32_t e = s_lut[v >> (32 - DEFH_LUT_BITS)];
         if (e != 0xFFFFu) { sym = e & 511u; l = e >> 9; }
@@ -286,29 +292,30 @@ void k_defh_decode(const uint8_t *__restrict__ stream, uint64_t stream_bytes, co
             }
             if (sym == DEFH_NSYM) { bad = true; break; }
         }
-        pos += l;
+        br.skip(l); pos += l;
         if (sym < 256u) {
-            if (lane == 0) s_out[o] = (uint8_t)sym;
+            ring.put_literal(o, sym);
             o += 1;
         } else {
             const uint32_t cz = sym - 256u;
             if (cz < 1u || cz > 15u) { bad = true; break; }
-            const uint32_t nx = 15u - cz, x = peek32(pos);
+            br.refill();
+            const uint32_t nx = 15u - cz, x = br.top32();
             const uint32_t d = (1u << nx) + (nx ? x >> (32u - nx) : 0u);
             const uint32_t len = (x << nx) >> 27;
-            pos += nx + 5u;
-            if (d > o) { bad = true; break; }
+            br.skip(nx + 5u); pos += nx + 5u;
+            if (d > o || d > RING) { bad = true; break; }
             const uint32_t take = (o + len <= n) ? len : n - o;
-            for (uint32_t j = lane; j < take; j += 64) s_out[o + j] = s_out[o - d + (j % d)];
+            ring.copy(o, d, take);
             o += take;
         }
         if (pos > nbits) { bad = true; break; }
         __builtin_amdgcn_wave_barrier();
+        ring.advance(o);
     }
     if (o != n) bad = true;
-    if (bad && lane == 0) atomicOr(err, 1u);
-    __syncthreads();
-    if (!bad) for (uint32_t i = lane; i < n; i += 64) out[off + i] = s_out[i];
+    if (bad) { if (lane == 0) atomicOr(err, 1u); return; }
+    ring.finish(n);
 }
 
 mi_status lz_check_params(const mi_lz_params *p);
@@ -341,7 +348,11 @@ extern "C" mi_status mi_deflate_h_decode_dev(mi_ctx *ctx, const mi_lz_params *p,
     if (!err) return MI_ERR_HIP;
     {
         mi_prof_scope pr(ctx, "k_defh_decode", s, n);
-        hipLaunchKernelGGL(k_defh_decode, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, stream_bytes, d_block_bits, P, d_out, n, err);
+        // the ring is the window (a distance never exceeds it) or the block, whichever is smaller
+        const uint32_t W = 1u << P.wbits, need = W < P.block ? W : P.block;
+        if (need <= 16384u)      hipLaunchKernelGGL(k_defh_decode<16384u>, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, stream_bytes, d_block_bits, P, d_out, n, err);
+        else if (need <= 32768u) hipLaunchKernelGGL(k_defh_decode<32768u>, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, stream_bytes, d_block_bits, P, d_out, n, err);
+        else                     hipLaunchKernelGGL(k_defh_decode<65536u>, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, stream_bytes, d_block_bits, P, d_out, n, err);
     }
     uint32_t h_err = 0;
     MI_HIP(ctx, hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, s));

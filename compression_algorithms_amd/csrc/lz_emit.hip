@@ -11,7 +11,7 @@
 //                    same thing with 16/32-bit tokens)
 //   k_lz_concat      block streams -> one stream, bit-contiguous (a funnel-shift gather, one
 //                    thread per output dword)
-//   k_lz_decode      one wave per block; replaces lz77_decompress (lz77.c:347-377)
+//   (decoders: lz_decode.hip)
 #include "lz_common.h"
 #include "lz2.h"
 #include <stdlib.h>
@@ -370,7 +370,10 @@ void k_lz_scan_blocks(const uint64_t *bits, uint32_t nb, const uint64_t *__restr
                       uint64_t *excl_local /* may alias `bits`: scanned in place */, uint64_t *__restrict__ excl_global)
 {
     __shared__ uint64_t s_tmp[18];
-    const uint64_t v = threadIdx.x < nb ? bits[threadIdx.x] : 0;       // nb <= 1024 per batch
+    // PER consecutive blocks per thread (a batch holds up to 4096 blocks)
+    const uint32_t PER = (nb + 1023u) / 1024u, a = threadIdx.x * PER, b = a + PER < nb ? a + PER : nb;
+    uint64_t v = 0;
+    for (uint32_t i = a; i < b; ++i) v += bits[i];
     uint64_t inc = v;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -379,8 +382,10 @@ void k_lz_scan_blocks(const uint64_t *bits, uint32_t nb, const uint64_t *__restr
     __syncthreads();
     if (threadIdx.x == 0) { uint64_t run = 0; for (int w = 0; w < 16; ++w) { uint64_t t = s_tmp[w]; s_tmp[w] = run; run += t; } s_tmp[16] = run; }
     __syncthreads();
-    const uint64_t exc = s_tmp[wave] + inc - v, base = *base_bits;
-    if (threadIdx.x < nb) { excl_local[threadIdx.x] = exc; excl_global[threadIdx.x] = base + exc; }
+    uint64_t run = s_tmp[wave] + inc - v;
+    const uint64_t base = *base_bits;
+    for (uint32_t i = a; i < b; ++i) { const uint64_t x = bits[i]; excl_local[i] = run; excl_global[i] = base + run; run += x; }
+    __syncthreads();                                    // (in place: every thread has read its own range before anyone writes [nb])
     if (threadIdx.x == 0) { excl_local[nb] = s_tmp[16]; excl_global[nb] = base + s_tmp[16]; }
 }
 
@@ -443,52 +448,6 @@ __device__ __forceinline__ uint32_t stream_bits(const uint8_t *s, uint64_t nbyte
     return (uint32_t)(v >> (pos & 7u)) & ((1u << k) - 1u);
 }
 
-__global__ __launch_bounds__(64)
-void k_lz_decode(const uint8_t *__restrict__ stream, uint64_t stream_bytes, const uint64_t *__restrict__ block_bits, LzP P,
-                 uint8_t *__restrict__ out, uint64_t n_total, uint32_t *__restrict__ err)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t s_out[LZ_MAX_BLOCK + 256];
-    const uint32_t lane = threadIdx.x;
-    const uint64_t b = blockIdx.x;
-    const uint64_t off = b * (uint64_t)P.block;
-    const uint32_t n = (uint32_t)((n_total - off) < P.block ? (n_total - off) : P.block);
-    uint64_t pos = block_bits[b];
-    const uint64_t end = block_bits[b + 1];
-    uint32_t o = 0;
-    // the block's bit range must lie inside the stream (an untrusted table must not steer reads anywhere else)
-    bool bad = end < pos || end > stream_bytes * 8ull;
-    const uint32_t MB = P.deflate ? 32u : 1u + P.wbits + P.lbits;
-    while (!bad && o < n && pos < end) {
-        uint32_t flag, d = 0, len = 0, lit = 0;
-        if (P.deflate) {
-            const uint32_t t0 = stream_bits(stream, stream_bytes, pos, 16);
-            flag = t0 & 0xFFu;
-            if (flag > 1 || pos + (flag ? 32u : 16u) > end) { bad = true; break; }
-            if (flag == 0) { lit = t0 >> 8; pos += 16; }
-            else { const uint32_t t1 = stream_bits(stream, stream_bytes, pos + 16, 16); d = (t0 >> 8) | ((t1 & 0xFFu) << 8); len = t1 >> 8; pos += 32; }
-        } else {
-            flag = stream_bits(stream, stream_bytes, pos, 1);
-            if (pos + (flag ? MB : 9u) > end) { bad = true; break; }
-            if (!flag) { lit = stream_bits(stream, stream_bytes, pos + 1, 8); pos += 9; }
-            else { d = stream_bits(stream, stream_bytes, pos + 1, P.wbits); len = stream_bits(stream, stream_bytes, pos + 1 + P.wbits, P.lbits); pos += MB; }
-        }
-        if (!flag) {
-            if (lane == 0) s_out[o] = (uint8_t)lit;
-            o += 1;
-        } else {
-            if (d == 0 || d > o) { bad = true; break; }
-            const uint32_t take = (o + len <= n) ? len : n - o;
-            for (uint32_t j = lane; j < take; j += 64) s_out[o + j] = s_out[o - d + (j % d)];
-            o += take;
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (o != n) bad = true;
-    if (bad && lane == 0) atomicOr(err, 1u);
-    __syncthreads();
-    if (!bad) for (uint32_t i = lane; i < n; i += 64) out[off + i] = s_out[i];
-}
-
 // =============================================================================================
 // host side
 // =============================================================================================
@@ -513,8 +472,8 @@ void      lzw_carve(mi_ctx *ctx, uint32_t nb, uint32_t block, LzwScratch *sc);
 uint32_t  lzw_batch_blocks(uint64_t nblocks, uint32_t block);
 mi_status lzw_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb, const LzwScratch &sc, hipStream_t s);
 void      lzw_launch_parse_emit(const uint8_t *d_in, uint64_t n, const LzP &P, const LzwScratch &sc, uint64_t block0, uint32_t nb, hipStream_t s);
-void      lzw_launch_decode(const uint8_t *d_stream, uint64_t stream_bytes, const uint64_t *d_block_bits, const LzP &P, uint8_t *d_out,
-                            uint64_t n, uint64_t nblocks, uint32_t *err, hipStream_t s);
+void      lz_launch_decode(const uint8_t *d_stream, uint64_t stream_bytes, const uint64_t *d_block_bits, const LzP &P, uint8_t *d_out,
+                           uint64_t n, uint64_t nblocks, uint32_t *err, hipStream_t s);      // lz_decode.hip
 extern "C" uint64_t mi_deflate_h_bound_bytes(uint64_t n, const mi_lz_params *p);
 
 // mode_h = 0: the reference's token stream.  mode_h = 1: the same tokens, entropy coded per block (defh.hip); the
@@ -684,13 +643,9 @@ extern "C" mi_status mi_lz_decode_dev(mi_ctx *ctx, const mi_lz_params *p, const 
     const uint64_t nblocks = (n + P.block - 1) / P.block;
     uint32_t *err = mi_err_slot(ctx, s);
     if (!err) return MI_ERR_HIP;
-    if (P.block > LZ_MAX_BLOCK) {
-        if (((uintptr_t)d_out & 15u) != 0) return MI_ERR_ARG;             // 16-byte flushes of the decoder's ring
-        mi_prof_scope pr(ctx, "k_lzw_decode", s, n);
-        lzw_launch_decode(d_stream, stream_bytes, d_block_bits, P, d_out, n, nblocks, err, s);
-    } else {
+    {
         mi_prof_scope pr(ctx, "k_lz_decode", s, n);
-        hipLaunchKernelGGL(k_lz_decode, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, stream_bytes, d_block_bits, P, d_out, n, err);
+        lz_launch_decode(d_stream, stream_bytes, d_block_bits, P, d_out, n, nblocks, err, s);       // any block size
     }
     uint32_t h_err = 0;
     MI_HIP(ctx, hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, s));

@@ -618,7 +618,7 @@ mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t
 uint32_t lz_batch_blocks(uint64_t nblocks)
 {
     uint64_t cap = 1024;        // measured: 256 -> 9.2, 512 -> 9.9, 1024 -> 10.3 GB/s (the replay kernels' tails amortise)
-    if (const char *e = getenv("MI_LZ_BATCH")) { long v = atol(e); if (v >= 1 && v <= 1024) cap = (uint64_t)v; }
+    if (const char *e = getenv("MI_LZ_BATCH")) { long v = atol(e); if (v >= 1 && v <= 4096) cap = (uint64_t)v; }
     return (uint32_t)(nblocks < cap ? (nblocks ? nblocks : 1) : cap);
 }
 

@@ -17,7 +17,7 @@
 //   k_lzw_parse_emit    one workgroup per block walks its 64 KiB segments in order: match lengths from the bytes in HBM/L2,
 //                       the greedy chain by composed 64-position exit tables (as k_lz_parse_emit) entered at the offset the
 //                       previous segment left, tokens LSB-first (lz77.c:290-330) appended to the block's slot
-//   k_lzw_decode        one wave per block, a 128 KiB ring in LDS (a match reaches back < 64 KiB)
+//   (decoder: k_lz_decode_bits of lz_decode.hip, whose LDS ring is the window)
 // The table state lives in HBM and is touched through agent-scope atomics (the wave re-reads what it wrote a moment ago;
 // plain loads could hit stale lines of the CU's L1).  This path is exact, not fast: a cluster is a serial chain of HBM/L2
 // round trips.  It exists so that WINDOW_BITS 16 means what it says; DESIGN.md 6 says what would make it quick.
@@ -664,62 +664,6 @@ void k_lzw_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, L
 }
 
 // =============================================================================================
-// decode: one wave per block; the last 128 KiB of output live in an LDS ring (a match reaches back < 64 KiB)
-// =============================================================================================
-__device__ __forceinline__ uint32_t lzw_bits(const uint8_t *s, uint64_t nbytes, uint64_t pos, uint32_t k)   // k <= 25
-{
-    const uint64_t byte = pos >> 3;
-    uint64_t v = 0;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) if (byte + i < nbytes) v |= (uint64_t)s[byte + i] << (8 * i);
-    return (uint32_t)(v >> (pos & 7u)) & ((1u << k) - 1u);
-}
-
-__global__ __launch_bounds__(64)
-void k_lzw_decode(const uint8_t *__restrict__ stream, uint64_t stream_bytes, const uint64_t *__restrict__ block_bits, LzP P,
-                  uint8_t *__restrict__ out, uint64_t n_total, uint32_t *__restrict__ err)
-{
-    constexpr uint32_t RING = 131072u, RMASK = RING - 1u, HALF = 65536u;
-    __shared__ __attribute__((aligned(16))) uint8_t s_ring[RING];
-    const uint32_t lane = threadIdx.x;
-    const uint64_t b = blockIdx.x;
-    const uint64_t off = b * (uint64_t)P.block;
-    const uint32_t n = (uint32_t)((n_total - off) < P.block ? (n_total - off) : P.block);
-    uint64_t pos = block_bits[b];
-    const uint64_t end = block_bits[b + 1];
-    bool bad = end < pos || end > stream_bytes * 8ull;
-    const uint32_t MB = 1u + P.wbits + P.lbits, W = 1u << P.wbits;
-    uint32_t o = 0, flushed = 0;
-    while (!bad && o < n && pos < end) {
-        const uint32_t flag = lzw_bits(stream, stream_bytes, pos, 1);
-        if (pos + (flag ? MB : 9u) > end) { bad = true; break; }
-        if (!flag) {
-            if (lane == 0) s_ring[o & RMASK] = (uint8_t)lzw_bits(stream, stream_bytes, pos + 1, 8);
-            pos += 9; o += 1;
-        } else {
-            const uint32_t d = lzw_bits(stream, stream_bytes, pos + 1, P.wbits), len = lzw_bits(stream, stream_bytes, pos + 1 + P.wbits, P.lbits);
-            pos += MB;
-            if (d == 0 || d > o || d >= W) { bad = true; break; }
-            const uint32_t take = (o + len <= n) ? len : n - o;
-            for (uint32_t j = lane; j < take; j += 64) s_ring[(o + j) & RMASK] = s_ring[(o - d + (j % d)) & RMASK];
-            o += take;
-        }
-        __builtin_amdgcn_wave_barrier();
-        // position x's ring cell is rewritten by position x + RING, and nothing reaches back further than W - 1 < 64 KiB:
-        // the oldest half only has to be copied out before the write cursor comes round to it
-        while (o + 64u > flushed + RING) {
-            for (uint32_t i = lane * 16u; i < HALF; i += 64u * 16u)
-                *reinterpret_cast<uint4 *>(out + off + flushed + i) = *reinterpret_cast<const uint4 *>(&s_ring[(flushed + i) & RMASK]);
-            flushed += HALF;
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    if (o != n) bad = true;
-    if (bad) { if (lane == 0) atomicOr(err, 1u); return; }
-    for (uint32_t i = flushed + lane; i < n; i += 64) out[off + i] = s_ring[i & RMASK];
-}
-
-// =============================================================================================
 // host side
 // =============================================================================================
 size_t lzw_scratch_bytes(uint32_t nb, uint32_t block)
@@ -812,8 +756,3 @@ void lzw_launch_parse_emit(const uint8_t *d_in, uint64_t n, const LzP &P, const 
     hipLaunchKernelGGL(k_lzw_parse_emit, dim3(nb), dim3(1024), 0, s, d_in, n, P, sc, block0);
 }
 
-void lzw_launch_decode(const uint8_t *d_stream, uint64_t stream_bytes, const uint64_t *d_block_bits, const LzP &P, uint8_t *d_out,
-                       uint64_t n, uint64_t nblocks, uint32_t *err, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_lzw_decode, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, stream_bytes, d_block_bits, P, d_out, n, err);
-}
