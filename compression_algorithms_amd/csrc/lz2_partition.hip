@@ -19,23 +19,6 @@
 #include "lz_common.h"
 #include "lz2.h"
 
-struct AffMax { int32_t a, b; };                     // x -> max(x + a, b)
-__device__ __forceinline__ uint64_t am_pack(AffMax f) { return ((uint64_t)(uint32_t)f.a << 32) | (uint32_t)f.b; }
-__device__ __forceinline__ AffMax am_unpack(uint64_t v) { AffMax f; f.a = (int32_t)(v >> 32); f.b = (int32_t)(uint32_t)v; return f; }
-#define AM_NEG (-(1 << 28))
-// (second after first)
-__device__ __forceinline__ AffMax am_then(AffMax first, AffMax second)
-{
-    AffMax r;
-    r.a = first.a + second.a;
-    if (r.a < AM_NEG) r.a = AM_NEG;
-    int32_t t = first.b + second.a;
-    if (t < AM_NEG) t = AM_NEG;
-    r.b = t > second.b ? t : second.b;
-    return r;
-}
-struct OpAm { __device__ uint64_t operator()(uint64_t earlier, uint64_t later) const { return am_pack(am_then(am_unpack(earlier), am_unpack(later))); } };
-
 __global__ __launch_bounds__(1024)
 void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scratch sc, uint64_t block0)
 {

@@ -146,6 +146,24 @@ __device__ __forceinline__ T block_exclusive_scan(T v, Op op, T ident, T *s_tmp,
 struct OpAddU32 { __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a + b; } };
 struct OpMaxI32 { __device__ int32_t operator()(int32_t a, int32_t b) const { return a > b ? a : b; } };
 
+// ---- the overflow certificate's maps x -> max(x + a, b) (lz2_partition.hip, lzs.hip): composition is associative, not commutative
+struct AffMax { int32_t a, b; };                     // x -> max(x + a, b)
+__device__ __forceinline__ uint64_t am_pack(AffMax f) { return ((uint64_t)(uint32_t)f.a << 32) | (uint32_t)f.b; }
+__device__ __forceinline__ AffMax am_unpack(uint64_t v) { AffMax f; f.a = (int32_t)(v >> 32); f.b = (int32_t)(uint32_t)v; return f; }
+#define AM_NEG (-(1 << 28))
+// (second after first)
+__device__ __forceinline__ AffMax am_then(AffMax first, AffMax second)
+{
+    AffMax r;
+    r.a = first.a + second.a;
+    if (r.a < AM_NEG) r.a = AM_NEG;
+    int32_t t = first.b + second.a;
+    if (t < AM_NEG) t = AM_NEG;
+    r.b = t > second.b ? t : second.b;
+    return r;
+}
+struct OpAm { __device__ uint64_t operator()(uint64_t earlier, uint64_t later) const { return am_pack(am_then(am_unpack(earlier), am_unpack(later))); } };
+
 // ---- one stable LSD radix pass over n elements held by a workgroup of NWAVES waves ----------------
 // Wave w owns the contiguous segment [w*seg, (w+1)*seg): per-wave digit counts -> offsets by a
 // (digit-major, wave-minor) scan -> each wave scatters its segment in order, ranking the 64

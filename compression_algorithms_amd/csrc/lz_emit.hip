@@ -471,6 +471,7 @@ size_t    lzw_scratch_bytes(uint32_t nb, uint32_t block);
 void      lzw_carve(mi_ctx *ctx, uint32_t nb, uint32_t block, LzwScratch *sc);
 uint32_t  lzw_batch_blocks(uint64_t nblocks, uint32_t block);
 mi_status lzw_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb, const LzwScratch &sc, hipStream_t s);
+mi_status lzw_or_lzs_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb, const LzwScratch &sc, hipStream_t s);
 void      lzw_launch_parse_emit(const uint8_t *d_in, uint64_t n, const LzP &P, const LzwScratch &sc, uint64_t block0, uint32_t nb, hipStream_t s);
 void      lz_launch_decode(const uint8_t *d_stream, uint64_t stream_bytes, const uint64_t *d_block_bits, const LzP &P, uint8_t *d_out,
                            uint64_t n, uint64_t nblocks, uint32_t *err, hipStream_t s);      // lz_decode.hip
@@ -503,7 +504,7 @@ static mi_status lz_encode_impl(mi_ctx *ctx, const mi_lz_params *p, const uint8_
         if (nblocks == 0) { MI_HIP(ctx, hipMemsetAsync(d_block_bits, 0, 8, s)); return MI_OK; }
         for (uint64_t b0 = 0; b0 < nblocks; b0 += nbw) {
             const uint32_t nb = (uint32_t)((nblocks - b0) < nbw ? (nblocks - b0) : nbw);
-            st = lzw_find(ctx, P, d_in, n, b0, nb, ws, s);
+            st = lzw_or_lzs_find(ctx, P, d_in, n, b0, nb, ws, s);
             if (st) return st;
             { mi_prof_scope pr(ctx, "k_lzw_parse_emit", s, (uint64_t)nb * P.block);
               lzw_launch_parse_emit(d_in, n, P, ws, b0, nb, s); }

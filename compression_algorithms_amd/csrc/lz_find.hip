@@ -34,7 +34,6 @@ __device__ __forceinline__ void lz_sort_home_block(const uint8_t *__restrict__ i
     __shared__ uint32_t s_cnt[17][256];
     __shared__ int32_t  s_i32[18];
     __shared__ uint32_t s_u32[18];
-    __shared__ uint32_t s_rot;
 
     const int tid = threadIdx.x;
     const uint64_t off = (block0 + lb) * (uint64_t)P.block;
@@ -53,7 +52,6 @@ __device__ __forceinline__ void lz_sort_home_block(const uint8_t *__restrict__ i
         }
     }
     if (tid < 16) s_in[LZ_MAX_BLOCK + LZ_TAIL + tid] = 0;
-    if (tid == 0) s_rot = 0;
     __syncthreads();
 
     uint16_t *A = sc.posA + (size_t)lb * LZ_MAX_BLOCK;
@@ -657,7 +655,7 @@ extern "C" mi_status mi_lz_find_all_dev(mi_ctx *ctx, const mi_lz_params *p, cons
 size_t    lzw_scratch_bytes(uint32_t nb, uint32_t block);
 void      lzw_carve(mi_ctx *ctx, uint32_t nb, uint32_t block, LzwScratch *sc);
 uint32_t  lzw_batch_blocks(uint64_t nblocks, uint32_t block);
-mi_status lzw_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb, const LzwScratch &sc, hipStream_t s);
+mi_status lzw_or_lzs_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb, const LzwScratch &sc, hipStream_t s);
 
 // the same hook for blocks above 64 KiB (lz77 flavour, lzw.hip): 32-bit positions, 0xFFFFFFFF = none
 extern "C" mi_status mi_lz_find_all32_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_in, uint64_t n,
@@ -678,7 +676,7 @@ extern "C" mi_status mi_lz_find_all32_dev(mi_ctx *ctx, const mi_lz_params *p, co
     lzw_carve(ctx, nbw, P.block, &ws);
     for (uint64_t b0 = 0; b0 < nblocks; b0 += nbw) {
         const uint32_t nb = (uint32_t)((nblocks - b0) < nbw ? (nblocks - b0) : nbw);
-        st = lzw_find(ctx, P, d_in, n, b0, nb, ws, s);
+        st = lzw_or_lzs_find(ctx, P, d_in, n, b0, nb, ws, s);
         if (st) return st;
         for (uint32_t i = 0; i < nb; ++i) {
             const uint64_t off = (b0 + i) * (uint64_t)P.block;

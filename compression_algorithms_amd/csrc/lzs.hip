@@ -1,0 +1,621 @@
+// lzs.hip — the lz77 flavour on blocks above 64 KiB, sliced in TIME so that everything stays in LDS.
+//
+// lzw.hip clusters a whole block at once: 2^20 entries on 2^22 buckets are a 25 % load "of all time", clusters of 20 000
+// entries, serial chains of that length.  But at any moment the table only holds the last W = 2^wbits insertions — 1.5 %.
+// So a block is walked in sub-blocks of W positions.  Step k knows the table it starts from exactly: the W entries of
+// sub-block k-1, each ON THE SLOT step k-1 gave it.  During step k every one of them retires — entry t of the old
+// sub-block right after insertion t of the new one (lz77.c:70-76: insertion p clears the bucket insertion p-W recorded)
+// — and every new entry is inserted, none of them retired.  The events of a step are therefore
+//     e = 2 t      find() + insert of position kW + t
+//     e = 2 t + 1  clear the bucket recorded by position (k-1)W + t          (whoever sits there now)
+// in the order of e, and their table coordinates are known up front: an old entry's slot, a new entry's home bucket.
+// Treating an old entry as "inserted first, home = its slot" the isolation argument of DESIGN.md 2.1 holds unchanged: sort
+// the 2W events by coordinate, parking sweep -> clusters that never touch each other.  With 131 072 events on 2^22
+// buckets the clusters are those of a 64 KiB block (a frequent word's alive copies), not of a megabyte.
+//
+//   k_lzs_keys   mix32(word) of every position, once per block                      (the hash, lz77.c:13-41)
+//   k_lzs_part   per block and step: events -> parts of <= 4096 events that no cluster crosses (the overflow certificate
+//                of lz2_partition.hip over 32 768 groups), lists in event order
+//   k_lzs_find   per part, all in LDS: stable radix sort by coordinate, parking sweep, (cluster, time) order by cursor
+//                placement, replay — a LANE per cluster of <= 16 events (occupancy and occupants in three registers),
+//                a WAVE per larger one (64 buckets per probe step) — then find() results and the new entries' slots
+//                go out by position
+// Zero-filled ring: in step 0 one pseudo event clears bucket 0 after insertion W-1; an entry that a
+// clear removes early is carried into the next step as DEAD (it occupies nothing, its own clear still happens).
+// A step with a cluster above 4096 events (a run of one byte value) or more than 63 parts flags the block; the batch is
+// then redone by lzw.hip (whole-block clusters, any size).
+#include "lz_common.h"
+#include <stdlib.h>
+
+#define LZS_NG_BITS   15
+#define LZS_NG        (1u << LZS_NG_BITS)
+#define LZS_CAP       4096u
+#define LZS_THREADS   512
+#define LZS_NWAVES    (LZS_THREADS / 64)
+#define LZS_PARTBITS  6
+#define LZS_MAXPARTS  (1u << LZS_PARTBITS)        // digit 63 is the bin of the event ids that are not events
+#define LZS_LANE_MAX  16u
+#define LZS_DEAD      0x80000000u
+#define LZS_NONE      0xFFFFFFFFu
+// entry flags in LDS
+#define CF_OLD        (1u << 30)
+#define CF_DEAD       (1u << 31)
+#define CF_MASK       0x3FFFFFFFu
+#define RF_SLOT       0x0FFFu
+#define RF_OLD        0x1000u
+#define RF_DEAD       0x2000u
+#define ES_KILLED     0x8000u
+
+struct LzsMeta {
+    uint32_t nparts, fallback, pad[2];
+    uint32_t part_start[LZS_MAXPARTS], part_count[LZS_MAXPARTS], part_lo[LZS_MAXPARTS];
+};
+
+struct LzsScratch {
+    uint32_t *key;        // [nb][S] mix32(word) by position
+    uint32_t *slot;       // [nb][S] bucket an entry was inserted on | LZS_DEAD
+    uint32_t *cand;       // [nb][S] find() by position (LZS_NONE = none)
+    uint32_t *plist;      // [nb][S] event ids of the current step, grouped by part, event order inside a part
+    LzsMeta  *meta;       // [nb]
+    uint32_t *work;       // [nb * LZS_MAXPARTS] parts of the current step: block | part << 16
+    uint32_t *counters;   // [0..63] parts listed in step k, [64] flagged blocks
+    uint32_t  S;
+};
+
+__device__ __forceinline__ uint32_t lzs_word(const uint8_t *src, uint32_t p, uint32_t n)
+{
+    if (p + 8u <= n && ((((uintptr_t)src) & 3u) == 0)) {
+        const uint32_t *a = reinterpret_cast<const uint32_t *>(src + (p & ~3u));
+        const uint64_t v = (uint64_t)a[0] | ((uint64_t)a[1] << 32);
+        return (uint32_t)(v >> ((p & 3u) * 8u));
+    }
+    uint32_t w = 0;                                   // bytes past the block end read as zero
+    for (uint32_t k = 0; k < 4 && p + k < n; ++k) w |= (uint32_t)src[p + k] << (8 * k);
+    return w;
+}
+
+__global__ __launch_bounds__(256)
+void k_lzs_keys(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0)
+{
+    const uint32_t lb = blockIdx.y;
+    const uint64_t off = (block0 + lb) * (uint64_t)P.block;
+    const uint32_t n = (uint32_t)((n_total - off) < P.block ? (n_total - off) : P.block);
+    const uint8_t *src = in + off;
+    uint32_t *key = sc.key + (size_t)lb * sc.S;
+    for (uint32_t p = blockIdx.x * 256u + threadIdx.x; p < n; p += gridDim.x * 256u) key[p] = lz_mix32(lzs_word(src, p, n));
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc.meta[lb].fallback = 0; sc.meta[lb].nparts = 0; }
+}
+
+// =============================================================================================
+// stage 1: the events of one step of one block -> parts
+// =============================================================================================
+__global__ __launch_bounds__(1024)
+void k_lzs_part(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_t step)
+{
+    __shared__ uint32_t s_grp[LZS_NG];                // counts -> inclusive prefix; later the part of every event id (bytes)
+    __shared__ uint32_t s_safe[LZS_NG / 32];
+    __shared__ uint32_t s_cnt[17][LZS_MAXPARTS];
+    __shared__ uint64_t s_scan64[18];
+    __shared__ uint32_t s_scan32[18];
+    __shared__ uint32_t s_thr[LZS_MAXPARTS + 1];      // part k = coordinates in [s_thr[k], s_thr[k+1])
+    __shared__ uint32_t s_flag, s_K, s_wbase;
+
+    const int tid = threadIdx.x;
+    const uint32_t lb = blockIdx.x;
+    const uint64_t off = (block0 + lb) * (uint64_t)P.block;
+    const uint32_t n = (uint32_t)((n_total - off) < P.block ? (n_total - off) : P.block);
+    const uint32_t W = 1u << P.wbits, t0 = step * W;
+    LzsMeta *mt = sc.meta + lb;
+    if (t0 >= n || mt->fallback) { if (tid == 0) mt->nparts = 0; return; }
+    const uint32_t nnew = (n - t0) < W ? (n - t0) : W;
+    const uint32_t *key = sc.key + (size_t)lb * sc.S + t0;
+    const uint32_t *slot_old = sc.slot + (size_t)lb * sc.S + (t0 - (step ? W : 0u));
+    const uint32_t T = 1u << P.tbits, Tmask = T - 1u;
+    const uint32_t gshift = P.tbits - LZS_NG_BITS, Gw = 1u << gshift;
+    const uint32_t NE = 2u * W;                        // event id space
+    auto valid = [&](uint32_t e) -> bool {
+        const uint32_t t = e >> 1;
+        return (e & 1u) ? (step ? true : (t == W - 1u && nnew == W)) : (t < nnew);
+    };
+    auto coord = [&](uint32_t e) -> uint32_t {
+        const uint32_t t = e >> 1;
+        return (e & 1u) ? (step ? (slot_old[t] & ~LZS_DEAD) : 0u) : (key[t] & Tmask);
+    };
+    auto grp = [&](uint32_t c) -> uint32_t { const uint32_t g = c >> gshift; return g < LZS_NG ? g : LZS_NG - 1u; };   // slots past T: the last group
+
+    for (uint32_t i = tid; i < LZS_NG; i += 1024) s_grp[i] = 0;
+    for (uint32_t i = tid; i < LZS_NG / 32; i += 1024) s_safe[i] = 0;
+    if (tid == 0) s_flag = 0;
+    __syncthreads();
+    for (uint32_t e = tid; e < NE; e += 1024) if (valid(e)) atomicAdd(&s_grp[grp(coord(e))], 1u);
+    __syncthreads();
+
+    // ---- overflow certificate (lz2_partition.hip): out_g = max(in_g + c_g - Gw, c_g - 1, 0), a scan of x -> max(x + a, b) maps
+    constexpr uint32_t GPT = LZS_NG / 1024;
+    const uint32_t g0 = tid * GPT;
+    AffMax mine{0, AM_NEG};
+    for (uint32_t k = 0; k < GPT; ++k) {
+        const int32_t c = (int32_t)s_grp[g0 + k];
+        mine = am_then(mine, AffMax{c - (int32_t)Gw, c > 0 ? c - 1 : 0});
+    }
+    uint64_t tot64;
+    const uint64_t pre64 = block_exclusive_scan<uint64_t>(am_pack(mine), OpAm(), am_pack(AffMax{0, AM_NEG}), s_scan64, &tot64);
+    const AffMax pre = am_unpack(pre64);
+    {
+        int32_t x = pre.a > pre.b ? pre.a : pre.b;      // carry into group 0 is 0: nothing wraps (lz77.c:61)
+        if (x < 0) x = 0;
+        uint32_t safe_bits = 0;
+        for (uint32_t k = 0; k < GPT; ++k) {
+            const int32_t c = (int32_t)s_grp[g0 + k];
+            int32_t o = x + c - (int32_t)Gw;
+            const int32_t o2 = c > 0 ? c - 1 : 0;
+            o = o > o2 ? o : o2;
+            if (o < 0) o = 0;
+            if (o == 0) safe_bits |= 1u << k;
+            x = o;
+        }
+        s_safe[g0 >> 5] = safe_bits;                    // 32 groups per thread: one word each
+    }
+    {
+        uint32_t sum = 0;
+        for (uint32_t k = 0; k < GPT; ++k) sum += s_grp[g0 + k];
+        uint32_t tot;
+        uint32_t run = block_exclusive_scan<uint32_t>(sum, OpAddU32(), 0u, s_scan32, &tot);
+        for (uint32_t k = 0; k < GPT; ++k) { run += s_grp[g0 + k]; s_grp[g0 + k] = run; }
+    }
+    __syncthreads();
+    const uint32_t nev = s_grp[LZS_NG - 1];
+    auto is_safe = [&](uint32_t g) -> bool { return (s_safe[g >> 5] >> (g & 31u)) & 1u; };
+
+    // ---- greedy cuts: every part takes as many events as stage 2 holds, ending at the last certified group that fits
+    if (tid < 64) {
+        const uint32_t lane = (uint32_t)tid;
+        uint32_t k = 0, cur = 0, glo = 0;
+        bool bad = false;
+        if (lane == 0) s_thr[0] = 0;
+        while (nev - cur > LZS_CAP) {
+            const uint32_t limit = cur + LZS_CAP;
+            uint32_t lo = glo, hi = LZS_NG - 1;         // first group whose inclusive count exceeds the limit: a 64-way search
+            while (lo < hi) {
+                const uint32_t len = hi - lo, st = (len + 63u) / 64u;
+                const uint32_t pr = lo + lane * st;
+                const bool over = (pr < hi) && s_grp[pr] > limit;
+                const uint64_t mk = __ballot(over);
+                if (mk == 0ull) lo = lo + ((len - 1u) / st) * st + 1u;
+                else {
+                    const uint32_t j = (uint32_t)__builtin_ctzll(mk);
+                    hi = lo + j * st;
+                    if (j) lo = lo + (j - 1u) * st + 1u;
+                }
+            }
+            int32_t gr = -1;                            // last certified group before it, inside this part
+            for (int32_t g = (int32_t)lo - 1; g >= (int32_t)glo; g -= 64) {
+                const int32_t c = g - (int32_t)lane;
+                const uint64_t mk = __ballot(c >= (int32_t)glo && is_safe((uint32_t)c));
+                if (mk) { gr = g - (int32_t)__builtin_ctzll(mk); break; }
+            }
+            if (gr < (int32_t)glo || k + 3 > LZS_MAXPARTS) { bad = true; break; }     // one cluster above the capacity / too many parts
+            cur = s_grp[gr];
+            glo = (uint32_t)gr + 1u;
+            ++k;
+            if (lane == 0) s_thr[k] = glo << gshift;
+        }
+        if (lane == 0) {
+            s_thr[k + 1] = 0xFFFFFFFFu;                 // the last part takes everything above
+            s_K = k + 1;
+            if (bad) s_flag = 1;
+        }
+    }
+    __syncthreads();
+    const uint32_t K = s_K;                             // <= 63
+    if (tid < (int)K) {
+        auto cnt_below = [&](uint32_t h) -> uint32_t { return h == 0 ? 0u : (h == 0xFFFFFFFFu ? nev : s_grp[(h >> gshift) - 1u]); };
+        const uint32_t a = s_thr[tid], b = s_thr[tid + 1];
+        const uint32_t cnt = cnt_below(b) - cnt_below(a);
+        if (cnt > LZS_CAP) atomicOr(&s_flag, 1u);
+        mt->part_start[tid] = cnt_below(a);
+        mt->part_count[tid] = cnt;
+        mt->part_lo[tid] = a;
+    }
+    __syncthreads();
+    if (s_flag) {
+        if (tid == 0) { mt->fallback = 1; mt->nparts = 0; atomicAdd(&sc.counters[64], 1u); }
+        return;
+    }
+    if (tid == 0) { mt->nparts = K; s_wbase = atomicAdd(&sc.counters[step], K); }
+    __syncthreads();
+    if (tid < (int)K) sc.work[s_wbase + tid] = lb | ((uint32_t)tid << 16);
+
+    // ---- event ids -> part lists, event order kept: the part of every id (a binary search over <= 63 thresholds), then ONE
+    //      stable radix pass by part number; ids that are not events of this step go to a last bin that is not stored
+    uint8_t *part_in = reinterpret_cast<uint8_t *>(s_grp);          // [NE <= 131072] (the group array is dead: barrier above)
+    for (uint32_t e = tid; e < NE; e += 1024) {
+        uint32_t pk = LZS_MAXPARTS - 1u;
+        if (valid(e)) {
+            const uint32_t c = coord(e);
+            uint32_t lo = 0, hi = K - 1;                // last k with thr[k] <= c
+            while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (s_thr[mid] <= c) lo = mid; else hi = mid - 1; }
+            pk = lo;
+        }
+        part_in[e] = (uint8_t)pk;
+    }
+    __syncthreads();
+    uint32_t *plist = sc.plist + (size_t)lb * sc.S;
+    radix_pass_1024<LZS_PARTBITS, uint32_t>(NE, s_cnt,
+        [&](uint32_t i) { return i | ((uint32_t)part_in[i] << 24); },
+        [&](uint32_t e) { return e >> 24; },
+        [&](uint32_t j, uint32_t e) { if ((e >> 24) != LZS_MAXPARTS - 1u) plist[j] = e & 0xFFFFFFu; }, (P.flags & LZP_ARANK) != 0);
+}
+
+// =============================================================================================
+// stage 2: one part, in LDS
+// =============================================================================================
+// a cluster of <= 16 events [s, s + m) on one lane: 16 occupancy bits and sixteen 4-bit occupants in three registers
+__device__ __forceinline__ void lzs_replay_lane(const uint32_t *e_key, const uint16_t *e_rf, uint16_t *e_slot, uint16_t *cand_i, uint32_t s, uint32_t m)
+{
+    uint32_t mask = 0;
+    uint64_t tab = 0;
+    bool any_new = false;
+    for (uint32_t li = 0; li < m; ++li) {               // the table the step starts from: old entries that are still there
+        const uint32_t rf = e_rf[s + li];
+        if ((rf & (RF_OLD | RF_DEAD)) == RF_OLD) { const uint32_t b = (rf & RF_SLOT) - s; mask |= 1u << b; tab |= (uint64_t)li << (4u * b); }
+        any_new |= !(rf & RF_OLD);
+    }
+    if (!any_new) return;                               // nobody asks
+    for (uint32_t li = 0; li < m; ++li) {
+        const uint32_t i = s + li, rf = e_rf[i], b0 = (rf & RF_SLOT) - s;
+        if (rf & RF_OLD) {                              // clear the recorded bucket, whoever sits there (lz77.c:70-76)
+            if ((mask >> b0) & 1u) {
+                const uint32_t o = (uint32_t)(tab >> (4u * b0)) & 15u;
+                if (o != li && !(e_rf[s + o] & RF_OLD)) e_slot[s + o] |= ES_KILLED;
+                mask &= ~(1u << b0);
+            }
+        } else {
+            const uint32_t key = e_key[i];
+            uint32_t res = 0xFFFFu;
+            for (uint32_t b = b0; (mask >> b) & 1u; ++b) {                 // find(): lz77.c:94-108
+                const uint32_t o = (uint32_t)(tab >> (4u * b)) & 15u;
+                if (e_key[s + o] == key) { res = s + o; break; }
+            }
+            cand_i[i] = (uint16_t)res;
+            const uint32_t fb = b0 + (uint32_t)__builtin_ctz(~(mask >> b0));   // first fit, inside the cluster by the parking bound
+            mask |= 1u << fb;
+            tab = (tab & ~(15ull << (4u * fb))) | ((uint64_t)li << (4u * fb));
+            e_slot[i] = (uint16_t)(s + fb);
+        }
+    }
+}
+
+// a larger cluster on one wave: occ[slot] = entry + 1, 64 buckets per probe step
+__device__ __forceinline__ void lzs_replay_wave(const uint32_t *e_key, const uint16_t *e_rf, uint16_t *e_slot, uint16_t *cand_i, uint16_t *occ,
+                                                uint32_t s, uint32_t m, uint32_t lane)
+{
+    const uint32_t end = s + m;
+    for (uint32_t idx = s + lane; idx < end; idx += 64u) occ[idx] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t idx = s + lane; idx < end; idx += 64u) {
+        const uint32_t rf = e_rf[idx];
+        if ((rf & (RF_OLD | RF_DEAD)) == RF_OLD) occ[rf & RF_SLOT] = (uint16_t)(idx + 1u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i0 = s; i0 < end; i0 += 64u) {
+        const uint32_t my_rf = (i0 + lane < end) ? (uint32_t)e_rf[i0 + lane] : 0u;
+        const uint32_t my_key = (i0 + lane < end) ? e_key[i0 + lane] : 0u;
+        const uint32_t cnt = (end - i0) < 64u ? (end - i0) : 64u;
+        for (uint32_t l = 0; l < cnt; ++l) {
+            const uint32_t i = i0 + l;
+            const uint32_t rf = (uint32_t)__builtin_amdgcn_readlane((int)my_rf, (int)l), r = rf & RF_SLOT;
+            if (rf & RF_OLD) {
+                const uint32_t o = occ[r];
+                if (o) {
+                    if (o - 1u != i && lane == 0 && !(e_rf[o - 1u] & RF_OLD)) e_slot[o - 1u] |= ES_KILLED;
+                    if (lane == 0) occ[r] = 0;
+                }
+            } else {
+                const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)my_key, (int)l);
+                uint32_t found = 0xFFFFu, fe = 0;
+                bool searching = true;
+                for (uint32_t base = r;; base += 64u) {
+                    const uint32_t idx = base + lane;
+                    const uint32_t v = idx < end ? (uint32_t)occ[idx] : 0u;        // past the cluster: nobody's bucket
+                    const uint32_t k = v ? e_key[v - 1u] : 0u;
+                    const uint64_t be = __ballot(v == 0u), bmm = __ballot(v != 0u && k == key);
+                    if (searching && bmm) {
+                        const uint32_t fm = (uint32_t)__builtin_ctzll(bmm);
+                        if (!be || fm < (uint32_t)__builtin_ctzll(be)) { found = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)fm) - 1u; searching = false; }
+                    }
+                    if (be) { fe = base + (uint32_t)__builtin_ctzll(be); break; }
+                }
+                if (lane == 0) { cand_i[i] = (uint16_t)found; e_slot[i] = (uint16_t)(fe < end ? fe : r); if (fe < end) occ[fe] = (uint16_t)(i + 1u); }   // fe < end by the parking bound
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+__global__ __launch_bounds__(LZS_THREADS)
+void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_t step)
+{
+    __shared__ uint32_t s_key[LZS_CAP];                 // mix32(word) by event index j; later cand_i (u16, replay order)
+    __shared__ uint32_t s_c[LZS_CAP];                   // coordinate - part_lo | CF_OLD | CF_DEAD by j; later e_key (replay order)
+    __shared__ uint16_t s_j0[LZS_CAP], s_j1[LZS_CAP];   // sort ping-pong; later e_rf / the replay order -> j
+    __shared__ uint16_t s_g[LZS_CAP];                   // cluster number by j; later occ
+    __shared__ uint16_t s_r[LZS_CAP];                   // slot index by j; later e_slot (replay order)
+    __shared__ uint32_t s_cnt[LZS_NWAVES + 1][256];     // radix counters; later cluster cursors (u16, rows 0..7) and the wave list (row 8)
+    __shared__ int32_t  s_i32[18];
+    __shared__ uint64_t s_u64[18];
+    __shared__ uint32_t s_ngroups, s_nbig, s_bigcur;
+
+    const int tid = threadIdx.x;
+    const uint32_t nwork = sc.counters[step];
+    // XCD-aware order (lz2_find.hip): every XCD takes a contiguous eighth of the list, a block's parts share an L2
+    const uint32_t cpx = (nwork + 7u) >> 3, item_idx = (blockIdx.x & 7u) * cpx + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= cpx || item_idx >= nwork) return;
+    const uint32_t item = sc.work[item_idx];
+    const uint32_t lb = item & 0xFFFFu, part = item >> 16;
+    const LzsMeta *mt = sc.meta + lb;
+    const uint32_t m = mt->part_count[part];
+    if (m == 0) return;
+    const uint32_t pstart = mt->part_start[part], plo = mt->part_lo[part];
+    const uint32_t phi = (part + 1 < mt->nparts) ? mt->part_lo[part + 1] : 0xFFFFFFFFu;
+    const uint32_t W = 1u << P.wbits, t0 = step * W, Tmask = (1u << P.tbits) - 1u;
+    (void)n_total; (void)block0;
+    const uint32_t *plist = sc.plist + (size_t)lb * sc.S + pstart;
+    const uint32_t *key_new = sc.key + (size_t)lb * sc.S + t0;
+    const uint32_t *key_old = sc.key + (size_t)lb * sc.S + (t0 - (step ? W : 0u));
+    const uint32_t *slot_old = sc.slot + (size_t)lb * sc.S + (t0 - (step ? W : 0u));
+    uint32_t *slot_new = sc.slot + (size_t)lb * sc.S + t0;
+    uint32_t *cand = sc.cand + (size_t)lb * sc.S + t0;
+    const bool arank = (P.flags & LZP_ARANK) != 0;
+    constexpr uint32_t CH = LZS_CAP / LZS_THREADS;
+
+    // ---- gather: event ids (coalesced), then keys and slots of all of a thread's events together
+    {
+        uint32_t ge[CH], gk[CH], gs[CH];
+#pragma unroll
+        for (uint32_t c = 0; c < CH; ++c) { const uint32_t j = tid + c * LZS_THREADS; ge[c] = j < m ? plist[j] : 0u; }
+#pragma unroll
+        for (uint32_t c = 0; c < CH; ++c) {
+            const uint32_t j = tid + c * LZS_THREADS, t = ge[c] >> 1;
+            gk[c] = 0; gs[c] = LZS_DEAD;                 // step 0's only "old" event: clear bucket 0, nobody's entry
+            if (j < m) {
+                if (ge[c] & 1u) { if (step) { gk[c] = key_old[t]; gs[c] = slot_old[t]; } }
+                else gk[c] = key_new[t];
+            }
+        }
+#pragma unroll
+        for (uint32_t c = 0; c < CH; ++c) {
+            const uint32_t j = tid + c * LZS_THREADS;
+            if (j < m) {
+                s_key[j] = gk[c];
+                s_c[j] = (ge[c] & 1u) ? (((gs[c] & ~LZS_DEAD) - plo) | CF_OLD | ((gs[c] & LZS_DEAD) ? CF_DEAD : 0u)) : ((gk[c] & Tmask) - plo);
+            }
+        }
+    }
+    if (tid == 0) { s_nbig = 0; s_bigcur = 0; }
+    __syncthreads();
+    auto keyp = [&](uint32_t j) -> uint32_t { return s_c[j] & CF_MASK; };
+
+    // ---- stable sort of the event indices by coordinate: 8-bit passes over 16 or 24 bits -> s_j0
+    if (phi - plo > 65536u) {
+        radix_pass<LZS_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return i; },
+            [&](uint32_t e) { return keyp(e) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; }, arank);
+        radix_pass<LZS_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return (uint32_t)s_j0[i]; },
+            [&](uint32_t e) { return (keyp(e) >> 8) & 255u; }, [&](uint32_t d, uint32_t e) { s_j1[d] = (uint16_t)e; }, arank);
+        radix_pass<LZS_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return (uint32_t)s_j1[i]; },
+            [&](uint32_t e) { return (keyp(e) >> 16) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; }, arank);
+    } else {
+        radix_pass<LZS_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return i; },
+            [&](uint32_t e) { return keyp(e) & 255u; }, [&](uint32_t d, uint32_t e) { s_j1[d] = (uint16_t)e; }, arank);
+        radix_pass<LZS_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return (uint32_t)s_j1[i]; },
+            [&](uint32_t e) { return (keyp(e) >> 8) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; }, arank);
+    }
+
+    // ---- parking sweep over the sorted order: with g_k = coordinate_k - k, cluster heads are the weak prefix
+    //      maxima of g; a cluster of m' events owns exactly the m' consecutive slots [first index, first index + m')
+    const uint32_t k0 = tid * CH, k1 = (k0 + CH < m) ? k0 + CH : m;
+    uint16_t *cur16 = reinterpret_cast<uint16_t *>(&s_cnt[0][0]);     // per cluster: its first replay index, post-incremented by the placement
+    {
+        uint32_t rj[CH]; int32_t rh[CH];
+        int32_t mx = INT32_MIN;
+#pragma unroll
+        for (uint32_t c = 0; c < CH; ++c) {
+            const uint32_t k = k0 + c;
+            rj[c] = 0; rh[c] = 0;
+            if (k < k1) { rj[c] = s_j0[k]; rh[c] = (int32_t)keyp(rj[c]); const int32_t g = rh[c] - (int32_t)k; mx = g > mx ? g : mx; }
+        }
+        int32_t gmax_total;
+        const int32_t premax = block_exclusive_scan<int32_t>(mx, OpMaxI32(), INT32_MIN, s_i32, &gmax_total);
+        uint32_t nheads = 0; int32_t lasthead = -1;
+        {
+            int32_t run = premax;
+#pragma unroll
+            for (uint32_t c = 0; c < CH; ++c) {
+                const uint32_t k = k0 + c;
+                if (k < k1) {
+                    const int32_t g = rh[c] - (int32_t)k;
+                    const bool head = (k == 0) || (g >= run);
+                    run = g > run ? g : run;
+                    if (head) { ++nheads; lasthead = (int32_t)k; }
+                }
+            }
+        }
+        struct OpHeads {                                 // heads so far (sum) | last head index + 1 (max)
+            __device__ uint64_t operator()(uint64_t a, uint64_t b) const {
+                const uint64_t s0 = (a & 0xFFFFu) + (b & 0xFFFFu), a1 = a >> 16, b1 = b >> 16;
+                return s0 | ((a1 > b1 ? a1 : b1) << 16);
+            }
+        };
+        uint64_t tot2;
+        const uint64_t pre2 = block_exclusive_scan<uint64_t>((uint64_t)nheads | ((uint64_t)(lasthead + 1) << 16), OpHeads(), 0ull, s_u64, &tot2);
+        const uint32_t gid_base = (uint32_t)(pre2 & 0xFFFFu);
+        const int32_t gs_carry = (int32_t)(pre2 >> 16) - 1;
+        if (tid == 0) s_ngroups = (uint32_t)(tot2 & 0xFFFFu);
+        int32_t run = premax;
+        uint32_t cur_gs = 0, cur_gid = gid_base; int32_t cur_base = 0;
+        if (k0 < m && gs_carry >= 0) { cur_gs = (uint32_t)gs_carry; cur_base = (int32_t)keyp(s_j0[cur_gs]); cur_gid = gid_base - 1u; }
+        uint32_t seen = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < CH; ++c) {
+            const uint32_t k = k0 + c;
+            if (k < k1) {
+                const uint32_t j = rj[c];
+                const int32_t h = rh[c], g = h - (int32_t)k;
+                const bool head = (k == 0) || (g >= run);
+                run = g > run ? g : run;
+                if (head) { cur_gs = k; cur_base = h; cur_gid = gid_base + seen; ++seen; cur16[cur_gid] = (uint16_t)k; }
+                s_g[j] = (uint16_t)cur_gid;
+                s_r[j] = (uint16_t)(cur_gs + (uint32_t)(h - cur_base));
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t ngroups = s_ngroups;
+
+    // ---- (cluster, event) order: an entry's place is its cluster's cursor, post-incremented in event order (lz2_find.hip:
+    //      every cursor pair is advanced by one wave only; LDS is in order, returning adds are served in lane order)
+    if (arank) {
+        uint32_t *cur32 = &s_cnt[0][0];
+        const uint32_t wv = (uint32_t)tid >> 6, ln = (uint32_t)tid & 63u;
+        for (uint32_t j0 = 0; j0 < m; j0 += 256u) {
+            uint32_t gg[4], old[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) { const uint32_t j = j0 + 64u * u + ln; gg[u] = j < m ? (uint32_t)s_g[j] : 0xFFFFFFFFu; }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                old[u] = 0;
+                if (gg[u] != 0xFFFFFFFFu && ((gg[u] >> 1) % (uint32_t)LZS_NWAVES) == wv) old[u] = atomicAdd(&cur32[gg[u] >> 1], 1u << (16u * (gg[u] & 1u)));
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u)
+                if (gg[u] != 0xFFFFFFFFu && ((gg[u] >> 1) % (uint32_t)LZS_NWAVES) == wv) s_j1[(old[u] >> (16u * (gg[u] & 1u))) & 0xFFFFu] = (uint16_t)(j0 + 64u * u + ln);
+        }
+        __syncthreads();
+    } else {
+        // without the lane-order guarantee: two stable 6-bit passes by cluster number, then the cluster ends for the replay
+        __syncthreads();
+        radix_pass<LZS_NWAVES, 6, uint32_t>(m, s_cnt, [&](uint32_t i) { return i; },
+            [&](uint32_t e) { return (uint32_t)s_g[e] & 63u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; }, false);
+        radix_pass<LZS_NWAVES, 6, uint32_t>(m, s_cnt, [&](uint32_t i) { return (uint32_t)s_j0[i]; },
+            [&](uint32_t e) { return (uint32_t)s_g[e] >> 6; }, [&](uint32_t d, uint32_t e) { s_j1[d] = (uint16_t)e; }, false);
+        for (uint32_t i = tid; i < m; i += LZS_THREADS) {
+            const uint32_t g = s_g[s_j1[i]];
+            if (i + 1 == m || s_g[s_j1[i + 1]] != g) cur16[g] = (uint16_t)(i + 1u);
+        }
+        __syncthreads();
+    }
+    // cur16[g] is now the END of cluster g; it starts where g - 1 ends
+
+    // ---- permute into replay order
+    uint32_t *e_key = s_c;
+    uint16_t *e_rf = s_j0;
+    {
+        uint32_t rk[CH], rr[CH];
+#pragma unroll
+        for (uint32_t c = 0; c < CH; ++c) {
+            const uint32_t i = tid + c * LZS_THREADS;
+            rk[c] = 0; rr[c] = 0;
+            if (i < m) {
+                const uint32_t j = s_j1[i], cf = s_c[j];
+                rk[c] = s_key[j];
+                rr[c] = (uint32_t)s_r[j] | ((cf & CF_OLD) ? RF_OLD : 0u) | ((cf & CF_DEAD) ? RF_DEAD : 0u);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t c = 0; c < CH; ++c) {
+            const uint32_t i = tid + c * LZS_THREADS;
+            if (i < m) { e_key[i] = rk[c]; e_rf[i] = (uint16_t)rr[c]; }
+        }
+    }
+    uint16_t *cand_i = reinterpret_cast<uint16_t *>(s_key);
+    uint16_t *e_slot = s_r;
+    uint16_t *occ = s_g;
+    uint32_t *s_big = &s_cnt[LZS_NWAVES][0];             // <= 4096 / 17 clusters above the lane size: 240 words of the last row
+    __syncthreads();
+
+    // ---- replay: a lane per small cluster, the others listed for the waves
+    for (uint32_t g = tid; g < ngroups; g += LZS_THREADS) {
+        const uint32_t s = g ? (uint32_t)cur16[g - 1] : 0u, e = cur16[g];
+        const uint32_t cm = e - s;
+        if (cm <= LZS_LANE_MAX) lzs_replay_lane(e_key, e_rf, e_slot, cand_i, s, cm);
+        else s_big[atomicAdd(&s_nbig, 1u)] = s | (cm << 16);       // cm <= 4096: count - 1 in 12 bits
+    }
+    __syncthreads();
+    {
+        const uint32_t nbig = s_nbig, lane = (uint32_t)tid & 63u;
+        for (;;) {
+            uint32_t c = 0;
+            if (lane == 0) c = atomicAdd(&s_bigcur, 1u);
+            c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+            if (c >= nbig) break;
+            const uint32_t it = s_big[c];
+            lzs_replay_wave(e_key, e_rf, e_slot, cand_i, occ, it & 0xFFFFu, it >> 16, lane);
+        }
+    }
+    __syncthreads();
+
+    // ---- results out, by position: find() as a block position, the new entry's bucket for the next step
+    const uint32_t base_new = t0, base_old = t0 - (step ? W : 0u);
+    for (uint32_t i = tid; i < m; i += LZS_THREADS) {
+        const uint32_t rf = e_rf[i];
+        if (rf & RF_OLD) continue;
+        const uint32_t t = plist[s_j1[i]] >> 1;
+        const uint32_t sl = e_slot[i];
+        slot_new[t] = ((e_key[i] & Tmask) + ((sl & RF_SLOT) - (rf & RF_SLOT))) | ((sl & ES_KILLED) ? LZS_DEAD : 0u);
+        const uint32_t ci = cand_i[i];
+        uint32_t res = LZS_NONE;
+        if (ci != 0xFFFFu) { const uint32_t eo = plist[s_j1[ci]]; res = ((eo & 1u) ? base_old : base_new) + (eo >> 1); }
+        cand[t] = res;
+    }
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+void lzs_view(const LzwScratch &ws, uint32_t nb, LzsScratch *sc)
+{
+    // the sliced finder lives in the arrays of lzw.hip's workspace (which it never uses at the same time)
+    sc->key = ws.gid; sc->slot = ws.rd; sc->cand = ws.cand; sc->plist = ws.t_pos; sc->S = ws.S;
+    sc->meta = reinterpret_cast<LzsMeta *>(ws.eA);                       // nb x 784 B of nb x S x 8 B
+    sc->work = reinterpret_cast<uint32_t *>(ws.eB);                      // nb x 64 words
+    sc->counters = sc->work + (size_t)nb * LZS_MAXPARTS;
+}
+
+// at most 64 steps per block (their work counters), event ids below 2^17; MI_LZW_SLICED=0 keeps lzw.hip's whole-block path (A/B, tests)
+bool lzs_applicable(const LzP &P)
+{
+    const char *e = getenv("MI_LZW_SLICED");
+    if (e && e[0] == '0') return false;
+    const uint32_t W = 1u << P.wbits;
+    return !P.deflate && (P.block + W - 1u) / W <= 64u;
+}
+
+// every block of the batch, step by step; *flagged = blocks the sliced finder could not do (read back: one stream
+// synchronisation per batch)
+mi_status lzs_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
+                   const LzwScratch &ws, hipStream_t s, uint32_t *flagged)
+{
+    static_assert(sizeof(LzsMeta) <= 65536u * 8u, "the meta records live in one row of eA");
+    LzsScratch sc;
+    lzs_view(ws, nb, &sc);
+    const uint32_t W = 1u << P.wbits;
+    const uint32_t nsteps = (P.block + W - 1u) / W;
+    if (!lzs_applicable(P)) return MI_ERR_ARG;
+    const uint32_t chunks = (P.block + 256u * 16u - 1u) / (256u * 16u);
+    MI_HIP(ctx, hipMemsetAsync(sc.counters, 0, 65 * 4, s));
+    { mi_prof_scope p(ctx, "k_lzs_keys", s, (uint64_t)nb * P.block);
+      hipLaunchKernelGGL(k_lzs_keys, dim3(chunks, nb), dim3(256), 0, s, d_in, n, P, sc, block0); }
+    for (uint32_t k = 0; k < nsteps; ++k) {
+        { mi_prof_scope p(ctx, "k_lzs_part", s, (uint64_t)nb * W);
+          hipLaunchKernelGGL(k_lzs_part, dim3(nb), dim3(1024), 0, s, n, P, sc, block0, k); }
+        { mi_prof_scope p(ctx, "k_lzs_find", s, (uint64_t)nb * W);
+          hipLaunchKernelGGL(k_lzs_find, dim3(nb * LZS_MAXPARTS), dim3(LZS_THREADS), 0, s, n, P, sc, block0, k); }
+    }
+    MI_HIP(ctx, hipGetLastError());
+    uint32_t *h = reinterpret_cast<uint32_t *>(ctx->h_pinned);
+    MI_HIP(ctx, hipMemcpyAsync(h, sc.counters + 64, 4, hipMemcpyDeviceToHost, s));
+    MI_HIP(ctx, hipStreamSynchronize(s));
+    *flagged = *h;
+    return MI_OK;
+}

@@ -751,6 +751,22 @@ mi_status lzw_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, u
     return MI_OK;
 }
 
+// The time-sliced LDS-resident finder (lzs.hip) first; a batch with a block it had to flag (a cluster above its capacity: long
+// runs of one byte value) is redone here, whole-block clusters of any size.
+bool      lzs_applicable(const LzP &P);
+mi_status lzs_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
+                   const LzwScratch &ws, hipStream_t s, uint32_t *flagged);
+mi_status lzw_or_lzs_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb, const LzwScratch &sc, hipStream_t s)
+{
+    if (lzs_applicable(P)) {
+        uint32_t flagged = 0;
+        const mi_status st = lzs_find(ctx, P, d_in, n, block0, nb, sc, s, &flagged);
+        if (st) return st;
+        if (!flagged) return MI_OK;
+    }
+    return lzw_find(ctx, P, d_in, n, block0, nb, sc, s);
+}
+
 void lzw_launch_parse_emit(const uint8_t *d_in, uint64_t n, const LzP &P, const LzwScratch &sc, uint64_t block0, uint32_t nb, hipStream_t s)
 {
     hipLaunchKernelGGL(k_lzw_parse_emit, dim3(nb), dim3(1024), 0, s, d_in, n, P, sc, block0);
