@@ -26,6 +26,7 @@
 // then redone by lzw.hip (whole-block clusters, any size).
 #include "lz_common.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 #define LZS_NG_BITS   15
 #define LZS_NG        (1u << LZS_NG_BITS)
@@ -45,6 +46,10 @@
 #define RF_OLD        0x1000u
 #define RF_DEAD       0x2000u
 #define ES_KILLED     0x8000u
+#define RF_BIG        0x4000u                     // the event's cluster is replayed by k_lzs_big
+#define LZS_BIG_SMALL 512u                        // class 0: 17..512 events (4 KiB of LDS per wave), class 1: up to LZS_CAP (32 KiB)
+#define LZS_CTR_WORDS 512u                        // counters per group of blocks: [0..63] parts of step k, [128 + 4k ..] exports, [384 + 2k ..] replay cursors
+#define BI_EID        0x1FFFFu                    // big_info: event id | slot relative to the cluster << 17 | dead << 29
 
 struct LzsMeta {
     uint32_t nparts, fallback, pad[2];
@@ -58,8 +63,12 @@ struct LzsScratch {
     uint32_t *plist;      // [nb][S] event ids of the current step, grouped by part, event order inside a part
     LzsMeta  *meta;       // [nb]
     uint32_t *work;       // [nb * LZS_MAXPARTS] parts of the current step: block | part << 16
-    uint32_t *counters;   // [0..63] parts listed in step k, [64] flagged blocks
+    uint32_t *counters;   // [0..63] parts listed in step k, [64] flagged blocks, [128 + 4 k ..] step k: exported events, clusters of class 0 / 1
+    uint32_t *big_key, *big_info;   // [nb * S] events of the exported clusters of the current step, (cluster, event) order
+    uint64_t *big_desc[2];          // per class: first event | count << 32 | block << 48
+    uint32_t *flag_count; // flagged blocks of the whole batch
     uint32_t  S;
+    uint64_t *dbg;        // phase cycle counters of k_lzs_find (MI_LZ_DEBUG=1), else NULL
 };
 
 __device__ __forceinline__ uint32_t lzs_word(const uint8_t *src, uint32_t p, uint32_t n)
@@ -219,7 +228,7 @@ void k_lzs_part(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     }
     __syncthreads();
     if (s_flag) {
-        if (tid == 0) { mt->fallback = 1; mt->nparts = 0; atomicAdd(&sc.counters[64], 1u); }
+        if (tid == 0) { mt->fallback = 1; mt->nparts = 0; atomicAdd(sc.flag_count, 1u); }
         return;
     }
     if (tid == 0) { mt->nparts = K; s_wbase = atomicAdd(&sc.counters[step], K); }
@@ -286,53 +295,6 @@ __device__ __forceinline__ void lzs_replay_lane(const uint32_t *e_key, const uin
     }
 }
 
-// a larger cluster on one wave: occ[slot] = entry + 1, 64 buckets per probe step
-__device__ __forceinline__ void lzs_replay_wave(const uint32_t *e_key, const uint16_t *e_rf, uint16_t *e_slot, uint16_t *cand_i, uint16_t *occ,
-                                                uint32_t s, uint32_t m, uint32_t lane)
-{
-    const uint32_t end = s + m;
-    for (uint32_t idx = s + lane; idx < end; idx += 64u) occ[idx] = 0;
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t idx = s + lane; idx < end; idx += 64u) {
-        const uint32_t rf = e_rf[idx];
-        if ((rf & (RF_OLD | RF_DEAD)) == RF_OLD) occ[rf & RF_SLOT] = (uint16_t)(idx + 1u);
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t i0 = s; i0 < end; i0 += 64u) {
-        const uint32_t my_rf = (i0 + lane < end) ? (uint32_t)e_rf[i0 + lane] : 0u;
-        const uint32_t my_key = (i0 + lane < end) ? e_key[i0 + lane] : 0u;
-        const uint32_t cnt = (end - i0) < 64u ? (end - i0) : 64u;
-        for (uint32_t l = 0; l < cnt; ++l) {
-            const uint32_t i = i0 + l;
-            const uint32_t rf = (uint32_t)__builtin_amdgcn_readlane((int)my_rf, (int)l), r = rf & RF_SLOT;
-            if (rf & RF_OLD) {
-                const uint32_t o = occ[r];
-                if (o) {
-                    if (o - 1u != i && lane == 0 && !(e_rf[o - 1u] & RF_OLD)) e_slot[o - 1u] |= ES_KILLED;
-                    if (lane == 0) occ[r] = 0;
-                }
-            } else {
-                const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)my_key, (int)l);
-                uint32_t found = 0xFFFFu, fe = 0;
-                bool searching = true;
-                for (uint32_t base = r;; base += 64u) {
-                    const uint32_t idx = base + lane;
-                    const uint32_t v = idx < end ? (uint32_t)occ[idx] : 0u;        // past the cluster: nobody's bucket
-                    const uint32_t k = v ? e_key[v - 1u] : 0u;
-                    const uint64_t be = __ballot(v == 0u), bmm = __ballot(v != 0u && k == key);
-                    if (searching && bmm) {
-                        const uint32_t fm = (uint32_t)__builtin_ctzll(bmm);
-                        if (!be || fm < (uint32_t)__builtin_ctzll(be)) { found = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)fm) - 1u; searching = false; }
-                    }
-                    if (be) { fe = base + (uint32_t)__builtin_ctzll(be); break; }
-                }
-                if (lane == 0) { cand_i[i] = (uint16_t)found; e_slot[i] = (uint16_t)(fe < end ? fe : r); if (fe < end) occ[fe] = (uint16_t)(i + 1u); }   // fe < end by the parking bound
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-}
-
 __global__ __launch_bounds__(LZS_THREADS)
 void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_t step)
 {
@@ -344,7 +306,8 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     __shared__ uint32_t s_cnt[LZS_NWAVES + 1][256];     // radix counters; later cluster cursors (u16, rows 0..7) and the wave list (row 8)
     __shared__ int32_t  s_i32[18];
     __shared__ uint64_t s_u64[18];
-    __shared__ uint32_t s_ngroups, s_nbig, s_bigcur;
+    __shared__ uint32_t s_ngroups, s_nbig;
+    __shared__ uint16_t s_bigm[LZS_CAP / (LZS_LANE_MAX + 1u) + 2];   // sizes of the clusters this part exports
 
     const int tid = threadIdx.x;
     const uint32_t nwork = sc.counters[step];
@@ -360,6 +323,8 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     const uint32_t phi = (part + 1 < mt->nparts) ? mt->part_lo[part + 1] : 0xFFFFFFFFu;
     const uint32_t W = 1u << P.wbits, t0 = step * W, Tmask = (1u << P.tbits) - 1u;
     (void)n_total; (void)block0;
+    long long tk = clock64();
+#define LZS_TICK(k) do { if (sc.dbg && tid == 0) { long long t2 = clock64(); atomicAdd((unsigned long long *)&sc.dbg[k], (unsigned long long)(t2 - tk)); tk = t2; } } while (0)
     const uint32_t *plist = sc.plist + (size_t)lb * sc.S + pstart;
     const uint32_t *key_new = sc.key + (size_t)lb * sc.S + t0;
     const uint32_t *key_old = sc.key + (size_t)lb * sc.S + (t0 - (step ? W : 0u));
@@ -392,9 +357,10 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
             }
         }
     }
-    if (tid == 0) { s_nbig = 0; s_bigcur = 0; }
+    if (tid == 0) s_nbig = 0;
     __syncthreads();
     auto keyp = [&](uint32_t j) -> uint32_t { return s_c[j] & CF_MASK; };
+    LZS_TICK(0);
 
     // ---- stable sort of the event indices by coordinate: 8-bit passes over 16 or 24 bits -> s_j0
     if (phi - plo > 65536u) {
@@ -411,6 +377,7 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
             [&](uint32_t e) { return (keyp(e) >> 8) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; }, arank);
     }
 
+    LZS_TICK(1);
     // ---- parking sweep over the sorted order: with g_k = coordinate_k - k, cluster heads are the weak prefix
     //      maxima of g; a cluster of m' events owns exactly the m' consecutive slots [first index, first index + m')
     const uint32_t k0 = tid * CH, k1 = (k0 + CH < m) ? k0 + CH : m;
@@ -471,6 +438,7 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     }
     __syncthreads();
     const uint32_t ngroups = s_ngroups;
+    LZS_TICK(2);
 
     // ---- (cluster, event) order: an entry's place is its cluster's cursor, post-incremented in event order (lz2_find.hip:
     //      every cursor pair is advanced by one wave only; LDS is in order, returning adds are served in lane order)
@@ -505,6 +473,7 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
         __syncthreads();
     }
     // cur16[g] is now the END of cluster g; it starts where g - 1 ends
+    LZS_TICK(3);
 
     // ---- permute into replay order
     uint32_t *e_key = s_c;
@@ -530,36 +499,69 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     }
     uint16_t *cand_i = reinterpret_cast<uint16_t *>(s_key);
     uint16_t *e_slot = s_r;
-    uint16_t *occ = s_g;
     uint32_t *s_big = &s_cnt[LZS_NWAVES][0];             // <= 4096 / 17 clusters above the lane size: 240 words of the last row
     __syncthreads();
+    LZS_TICK(4);
 
     // ---- replay: a lane per small cluster, the others listed for the waves
     for (uint32_t g = tid; g < ngroups; g += LZS_THREADS) {
         const uint32_t s = g ? (uint32_t)cur16[g - 1] : 0u, e = cur16[g];
         const uint32_t cm = e - s;
         if (cm <= LZS_LANE_MAX) lzs_replay_lane(e_key, e_rf, e_slot, cand_i, s, cm);
-        else s_big[atomicAdd(&s_nbig, 1u)] = s | (cm << 16);       // cm <= 4096: count - 1 in 12 bits
+        else { const uint32_t q = atomicAdd(&s_nbig, 1u); s_big[q] = s | (cm << 16); s_bigm[q] = (uint16_t)cm; }
     }
     __syncthreads();
+    LZS_TICK(5);
+    if (sc.dbg && tid == 0) { atomicAdd((unsigned long long *)&sc.dbg[8], 1ull); atomicAdd((unsigned long long *)&sc.dbg[9], (unsigned long long)m);
+                              atomicAdd((unsigned long long *)&sc.dbg[10], (unsigned long long)ngroups); atomicAdd((unsigned long long *)&sc.dbg[11], (unsigned long long)s_nbig);
+                              uint32_t be = 0, h[3] = {0, 0, 0};
+                              for (uint32_t c = 0; c < s_nbig; ++c) { const uint32_t cm = s_big[c] >> 16; be += cm; h[0] += cm <= 32 ? cm : 0; h[1] += cm <= 64 ? cm : 0; h[2] += cm <= 128 ? cm : 0; }
+                              atomicAdd((unsigned long long *)&sc.dbg[12], (unsigned long long)be);
+                              for (int q = 0; q < 3; ++q) atomicAdd((unsigned long long *)&sc.dbg[13 + q], (unsigned long long)h[q]); }
+    // ---- larger clusters leave for k_lzs_big (a wave each, little LDS, many per CU): in here the workgroup would wait for
+    //      its longest chain — measured: 74 % of this kernel.  One reservation per part (events, clusters per class).
     {
-        const uint32_t nbig = s_nbig, lane = (uint32_t)tid & 63u;
-        for (;;) {
-            uint32_t c = 0;
-            if (lane == 0) c = atomicAdd(&s_bigcur, 1u);
-            c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-            if (c >= nbig) break;
-            const uint32_t it = s_big[c];
-            lzs_replay_wave(e_key, e_rf, e_slot, cand_i, occ, it & 0xFFFFu, it >> 16, lane);
+        const uint32_t nbig = s_nbig;
+        if (nbig) {
+            __shared__ uint32_t s_ebase, s_dbase[2];
+            if (tid == 0) {
+                uint32_t ev = 0, n0 = 0, n1 = 0;
+                for (uint32_t c = 0; c < nbig; ++c) { const uint32_t cm = s_big[c] >> 16; ev += cm; if (cm <= LZS_BIG_SMALL) ++n0; else ++n1; }
+                uint32_t *ctr = sc.counters + 128 + 4 * step;
+                s_ebase = atomicAdd(&ctr[0], ev);
+                s_dbase[0] = n0 ? atomicAdd(&ctr[1], n0) : 0u;
+                s_dbase[1] = n1 ? atomicAdd(&ctr[2], n1) : 0u;
+                uint32_t run = s_ebase, d0 = s_dbase[0], d1 = s_dbase[1];
+                for (uint32_t c = 0; c < nbig; ++c) {
+                    const uint32_t it = s_big[c], cm = it >> 16;
+                    const uint64_t d = (uint64_t)run | ((uint64_t)cm << 32) | ((uint64_t)lb << 48);
+                    if (cm <= LZS_BIG_SMALL) sc.big_desc[0][d0++] = d; else sc.big_desc[1][d1++] = d;
+                    s_big[c] = (it & 0xFFFFu) | ((run - s_ebase) << 16);              // start in replay order | offset in the reservation (< 4096)
+                    run += cm;
+                }
+            }
+            __syncthreads();
+            const uint32_t ebase = s_ebase;
+            const uint32_t wv = (uint32_t)tid >> 6, ln = (uint32_t)tid & 63u;
+            for (uint32_t c = wv; c < nbig; c += LZS_NWAVES) {                         // a wave per cluster: coalesced records
+                const uint32_t cs = s_big[c] & 0xFFFFu, ob = s_big[c] >> 16, cm = s_bigm[c];
+                for (uint32_t idx = ln; idx < cm; idx += 64u) {
+                    const uint32_t i = cs + idx, rf = e_rf[i];
+                    const uint32_t eid = plist[s_j1[i]];
+                    sc.big_key[ebase + ob + idx] = e_key[i];
+                    sc.big_info[ebase + ob + idx] = eid | (((rf & RF_SLOT) - cs) << 17) | ((rf & RF_DEAD) ? (1u << 29) : 0u);
+                    e_rf[i] = (uint16_t)(rf | RF_BIG);
+                }
+            }
         }
     }
     __syncthreads();
-
+    LZS_TICK(6);
     // ---- results out, by position: find() as a block position, the new entry's bucket for the next step
     const uint32_t base_new = t0, base_old = t0 - (step ? W : 0u);
     for (uint32_t i = tid; i < m; i += LZS_THREADS) {
         const uint32_t rf = e_rf[i];
-        if (rf & RF_OLD) continue;
+        if (rf & (RF_OLD | RF_BIG)) continue;
         const uint32_t t = plist[s_j1[i]] >> 1;
         const uint32_t sl = e_slot[i];
         slot_new[t] = ((e_key[i] & Tmask) + ((sl & RF_SLOT) - (rf & RF_SLOT))) | ((sl & ES_KILLED) ? LZS_DEAD : 0u);
@@ -567,6 +569,99 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
         uint32_t res = LZS_NONE;
         if (ci != 0xFFFFu) { const uint32_t eo = plist[s_j1[ci]]; res = ((eo & 1u) ? base_old : base_new) + (eo >> 1); }
         cand[t] = res;
+    }
+    LZS_TICK(7);
+}
+
+// =============================================================================================
+// stage 3: a wave per exported cluster (17 .. LZS_CAP events)
+// =============================================================================================
+#define LZS_EMPTY 0xFFFFFFFFu
+template <uint32_t CAPB>
+__global__ __launch_bounds__(64)
+void k_lzs_big(LzP P, LzsScratch sc, uint32_t step, uint32_t cls)
+{
+    __shared__ uint32_t s_okey[CAPB], s_oeid[CAPB];      // per slot of the cluster: the occupant's mixed word / event id
+    const uint32_t lane = threadIdx.x;
+    const uint32_t W = 1u << P.wbits, t0 = step * W, Tmask = (1u << P.tbits) - 1u;
+    const uint32_t base_new = t0, base_old = t0 - (step ? W : 0u);
+    const uint32_t count = sc.counters[128 + 4 * step + 1 + cls];
+    // clusters are handed out by a cursor (a static stride left waves with twice the average chain), FETCH at a time: one
+    // returning atomic per cluster on one address cost more than the replays (91 k clusters per step: 34 -> 45 ms)
+    uint32_t *cursor = &sc.counters[384 + 2 * step + cls];
+    constexpr uint32_t FETCH = CAPB > 1024u ? 1u : 8u;
+    uint32_t have = 0, next = 0;
+    for (;;) {
+        if (have == 0) {
+            uint32_t c0 = 0;
+            if (lane == 0) c0 = atomicAdd(cursor, FETCH);
+            next = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0);
+            have = FETCH;
+        }
+        const uint32_t ci = next++;
+        --have;
+        if (ci >= count) break;
+        const uint64_t d = sc.big_desc[cls][ci];
+        const uint32_t first = (uint32_t)d, m = (uint32_t)(d >> 32) & 0xFFFFu, lb = (uint32_t)(d >> 48);
+        const uint32_t *key = sc.big_key + first, *info = sc.big_info + first;
+        uint32_t *slot_new = sc.slot + (size_t)lb * sc.S + t0;
+        uint32_t *cand = sc.cand + (size_t)lb * sc.S + t0;
+        for (uint32_t idx = lane; idx < m; idx += 64u) s_oeid[idx] = LZS_EMPTY;
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t idx = lane; idx < m; idx += 64u) {                   // the table the step starts from
+            const uint32_t inf = info[idx];
+            if ((inf & 1u) && !((inf >> 29) & 1u)) { const uint32_t r = (inf >> 17) & 0xFFFu; s_oeid[r] = inf & BI_EID; s_okey[r] = key[idx]; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t n_key = lane < m ? key[lane] : 0u, n_inf = lane < m ? info[lane] : 0u;
+        for (uint32_t i0 = 0; i0 < m; i0 += 64u) {
+            const uint32_t my_key = n_key, my_inf = n_inf;
+            if (i0 + 64u + lane < m) { n_key = key[i0 + 64u + lane]; n_inf = info[i0 + 64u + lane]; }    // in flight during these 64
+            const uint32_t cnt = (m - i0) < 64u ? (m - i0) : 64u;
+            // bit l set: event l is a find + insert (or lies past the end): runs of clears between them are one parallel step
+            const uint64_t m_new = __ballot(lane >= cnt || !(my_inf & 1u));
+            uint32_t l = 0;
+            while (l < cnt) {
+                const uint64_t rest = m_new >> l;
+                const uint32_t run = rest ? (uint32_t)__builtin_ctzll(rest) : 64u - l;
+                if (run) {                                                 // clear the recorded buckets, whoever sits there (lz77.c:70-76)
+                    if (lane >= l && lane < l + run) {
+                        const uint32_t r = (my_inf >> 17) & 0xFFFu, o = s_oeid[r];
+                        if (o != LZS_EMPTY) {
+                            if (o != (my_inf & BI_EID) && !(o & 1u)) atomicOr(&slot_new[o >> 1], LZS_DEAD);    // a new entry removed early
+                            s_oeid[r] = LZS_EMPTY;
+                        }
+                    }
+                    l += run;
+                    __builtin_amdgcn_wave_barrier();
+                    continue;
+                }
+                const uint32_t inf = (uint32_t)__builtin_amdgcn_readlane((int)my_inf, (int)l), kw = (uint32_t)__builtin_amdgcn_readlane((int)my_key, (int)l);
+                const uint32_t r = (inf >> 17) & 0xFFFu, eid = inf & BI_EID;
+                uint32_t found = LZS_EMPTY, fe = 0;
+                bool searching = true;
+                for (uint32_t base = r;; base += 64u) {                    // find() and first fit: 64 buckets per step (lz77.c:55-108)
+                    const uint32_t idx = base + lane;
+                    const uint32_t v = idx < m ? s_oeid[idx] : LZS_EMPTY;  // past the cluster: nobody's bucket
+                    const uint32_t k = idx < m ? s_okey[idx] : 0u;
+                    const uint64_t be = __ballot(v == LZS_EMPTY), bmm = __ballot(v != LZS_EMPTY && k == kw);
+                    if (searching && bmm) {
+                        const uint32_t fm = (uint32_t)__builtin_ctzll(bmm);
+                        if (!be || fm < (uint32_t)__builtin_ctzll(be)) { found = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)fm); searching = false; }
+                    }
+                    if (be) { fe = base + (uint32_t)__builtin_ctzll(be); break; }
+                }
+                if (lane == 0) {
+                    const uint32_t t = eid >> 1;
+                    cand[t] = found == LZS_EMPTY ? LZS_NONE : ((found & 1u) ? base_old : base_new) + (found >> 1);
+                    if (fe < m) { s_okey[fe] = kw; s_oeid[fe] = eid; }     // fe < m by the parking bound
+                    __hip_atomic_store(&slot_new[t], (kw & Tmask) + (fe - r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (an early clear ORs LZS_DEAD into it later)
+                }
+                l += 1u;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -579,7 +674,11 @@ void lzs_view(const LzwScratch &ws, uint32_t nb, LzsScratch *sc)
     sc->key = ws.gid; sc->slot = ws.rd; sc->cand = ws.cand; sc->plist = ws.t_pos; sc->S = ws.S;
     sc->meta = reinterpret_cast<LzsMeta *>(ws.eA);                       // nb x 784 B of nb x S x 8 B
     sc->work = reinterpret_cast<uint32_t *>(ws.eB);                      // nb x 64 words
-    sc->counters = sc->work + (size_t)nb * LZS_MAXPARTS;
+    sc->counters = sc->work + (size_t)nb * LZS_MAXPARTS;                 // four groups x LZS_CTR_WORDS ([64] of the first: flagged blocks)
+    sc->flag_count = sc->counters + 64;
+    sc->dbg = getenv("MI_LZ_DEBUG") ? reinterpret_cast<uint64_t *>(sc->counters + 4 * LZS_CTR_WORDS) : nullptr;
+    sc->big_key = ws.t_mix; sc->big_info = ws.slot_of;                   // nb x S words each: a step has at most nb x S events
+    sc->big_desc[0] = ws.clist[0]; sc->big_desc[1] = ws.clist[1];        // nb x S / 2 + 64 each (a cluster has >= 17 events)
 }
 
 // at most 64 steps per block (their work counters), event ids below 2^17; MI_LZW_SLICED=0 keeps lzw.hip's whole-block path (A/B, tests)
@@ -591,31 +690,78 @@ bool lzs_applicable(const LzP &P)
     return !P.deflate && (P.block + W - 1u) / W <= 64u;
 }
 
-// every block of the batch, step by step; *flagged = blocks the sliced finder could not do (read back: one stream
-// synchronisation per batch)
+// Every block of the batch, step by step.  A step is a chain part -> find -> wave replays whose last link waits for the longest
+// cluster, and the next step needs every slot of this one: so the batch is cut into two groups of blocks that walk
+// their steps independently on the context's streams — one group's serial chains run beside another's sorts.
+// *flagged = blocks the sliced finder could not do (read back: one stream synchronisation per batch).
 mi_status lzs_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
                    const LzwScratch &ws, hipStream_t s, uint32_t *flagged)
 {
     static_assert(sizeof(LzsMeta) <= 65536u * 8u, "the meta records live in one row of eA");
-    LzsScratch sc;
-    lzs_view(ws, nb, &sc);
+    if (!lzs_applicable(P)) return MI_ERR_ARG;
+    LzsScratch all;
+    lzs_view(ws, nb, &all);
     const uint32_t W = 1u << P.wbits;
     const uint32_t nsteps = (P.block + W - 1u) / W;
-    if (!lzs_applicable(P)) return MI_ERR_ARG;
     const uint32_t chunks = (P.block + 256u * 16u - 1u) / (256u * 16u);
-    MI_HIP(ctx, hipMemsetAsync(sc.counters, 0, 65 * 4, s));
-    { mi_prof_scope p(ctx, "k_lzs_keys", s, (uint64_t)nb * P.block);
-      hipLaunchKernelGGL(k_lzs_keys, dim3(chunks, nb), dim3(256), 0, s, d_in, n, P, sc, block0); }
-    for (uint32_t k = 0; k < nsteps; ++k) {
-        { mi_prof_scope p(ctx, "k_lzs_part", s, (uint64_t)nb * W);
-          hipLaunchKernelGGL(k_lzs_part, dim3(nb), dim3(1024), 0, s, n, P, sc, block0, k); }
-        { mi_prof_scope p(ctx, "k_lzs_find", s, (uint64_t)nb * W);
-          hipLaunchKernelGGL(k_lzs_find, dim3(nb * LZS_MAXPARTS), dim3(LZS_THREADS), 0, s, n, P, sc, block0, k); }
+    // group g walks its steps on st[g]; the few long chains of a step (clusters above 512 events) run beside the many short
+    // ones on the group's second stream ax[g] (a launch lasts as long as its longest chain)
+    const bool multi = ctx->side && ctx->parse && ctx->fb;
+    hipStream_t st[2] = {s, multi ? ctx->side : s}, ax[2] = {multi ? ctx->parse : s, multi ? ctx->fb : s};
+    const char *eg = getenv("MI_LZS_GROUPS");
+    uint32_t G = eg ? (uint32_t)atoi(eg) : 2u;
+    if (G < 1u || G > 2u) G = 2u;
+    if (G > nb || !multi) G = 1;
+    MI_HIP(ctx, hipMemsetAsync(all.counters, 0, (size_t)LZS_CTR_WORDS * 4 * 4 + 16 * 8, s));
+    MI_HIP(ctx, hipEventRecord(ctx->ev_fork, s));
+    LzsScratch sg[2]; uint32_t lo[3];
+    for (uint32_t g = 0; g <= G; ++g) lo[g] = (uint32_t)(((uint64_t)nb * g) / G);
+    for (uint32_t g = 0; g < G; ++g) {
+        if (g) MI_HIP(ctx, hipStreamWaitEvent(st[g], ctx->ev_fork, 0));
+        LzsScratch &q = sg[g];
+        q = all;
+        const size_t o = (size_t)lo[g] * all.S;
+        q.key += o; q.slot += o; q.cand += o; q.plist += o; q.big_key += o; q.big_info += o;
+        q.meta += lo[g]; q.work += (size_t)lo[g] * LZS_MAXPARTS; q.counters += (size_t)g * LZS_CTR_WORDS;
+        q.big_desc[0] += o / 2; q.big_desc[1] += o / 2;
+        q.flag_count = all.counters + 64;                 // one count of flagged blocks for the whole batch
+        const uint32_t nbg = lo[g + 1] - lo[g];
+        mi_prof_scope p(ctx, "k_lzs_keys", st[g], (uint64_t)nbg * P.block);
+        hipLaunchKernelGGL(k_lzs_keys, dim3(chunks, nbg), dim3(256), 0, st[g], d_in, n, P, q, block0 + lo[g]);
     }
+    for (uint32_t k = 0; k < nsteps; ++k) {
+        for (uint32_t g = 0; g < G; ++g) {
+            const uint32_t nbg = lo[g + 1] - lo[g];
+            const LzsScratch &q = sg[g];
+            { mi_prof_scope p(ctx, "k_lzs_part", st[g], (uint64_t)nbg * W);
+              hipLaunchKernelGGL(k_lzs_part, dim3(nbg), dim3(1024), 0, st[g], n, P, q, block0 + lo[g], k); }
+            { mi_prof_scope p(ctx, "k_lzs_find", st[g], (uint64_t)nbg * W);
+              hipLaunchKernelGGL(k_lzs_find, dim3(nbg * LZS_MAXPARTS), dim3(LZS_THREADS), 0, st[g], n, P, q, block0 + lo[g], k); }
+            if (ax[g] != st[g]) { MI_HIP(ctx, hipEventRecord(ctx->ev_find[g], st[g])); MI_HIP(ctx, hipStreamWaitEvent(ax[g], ctx->ev_find[g], 0)); }
+            { mi_prof_scope p(ctx, "k_lzs_big<4096>", ax[g], (uint64_t)nbg * W);
+              hipLaunchKernelGGL(k_lzs_big<LZS_CAP>, dim3((unsigned)ctx->num_cu * 4u), dim3(64), 0, ax[g], P, q, k, 1u); }
+            { mi_prof_scope p(ctx, "k_lzs_big<512>", st[g], (uint64_t)nbg * W);
+              hipLaunchKernelGGL(k_lzs_big<LZS_BIG_SMALL>, dim3((unsigned)ctx->num_cu * 32u), dim3(64), 0, st[g], P, q, k, 0u); }
+            if (ax[g] != st[g]) { MI_HIP(ctx, hipEventRecord(ctx->ev_done[g], ax[g])); MI_HIP(ctx, hipStreamWaitEvent(st[g], ctx->ev_done[g], 0)); }
+        }
+    }
+    for (uint32_t g = 1; g < G; ++g) { MI_HIP(ctx, hipEventRecord(ctx->ev_replay[g - 1], st[g])); MI_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_replay[g - 1], 0)); }
+    const LzsScratch &sc = all;
     MI_HIP(ctx, hipGetLastError());
     uint32_t *h = reinterpret_cast<uint32_t *>(ctx->h_pinned);
-    MI_HIP(ctx, hipMemcpyAsync(h, sc.counters + 64, 4, hipMemcpyDeviceToHost, s));
+    MI_HIP(ctx, hipMemcpyAsync(h, sc.flag_count, 4, hipMemcpyDeviceToHost, s));
     MI_HIP(ctx, hipStreamSynchronize(s));
     *flagged = *h;
+    if (sc.dbg) {                                        // development aid: phase shares of k_lzs_find on stderr
+        uint64_t v[16];
+        if (hipMemcpy(v, sc.dbg, sizeof v, hipMemcpyDeviceToHost) == hipSuccess && v[8]) {
+            static const char *nm[8] = {"gather", "sort", "sweep", "place", "permute", "lane replay", "export", "out"};
+            double tot = 0; for (int k = 0; k < 8; ++k) tot += (double)v[k];
+            fprintf(stderr, "k_lzs_find: %llu parts, %.0f events, %.1f clusters, %.2f wave clusters with %.0f events per part; %.0f cycles per part; flagged %u\n",
+                    (unsigned long long)v[8], (double)v[9] / v[8], (double)v[10] / v[8], (double)v[11] / v[8], (double)v[12] / v[8], tot / v[8], *flagged);
+            fprintf(stderr, "   exported events per part in clusters <= 32: %.0f, <= 64: %.0f, <= 128: %.0f\n", (double)v[13] / v[8], (double)v[14] / v[8], (double)v[15] / v[8]);
+            for (int k = 0; k < 8; ++k) fprintf(stderr, "   %-12s %5.1f %%  %8.0f cycles/part\n", nm[k], 100.0 * v[k] / tot, (double)v[k] / v[8]);
+        }
+    }
     return MI_OK;
 }

@@ -12,3 +12,8 @@ print('   ', d['roofline'].get('all_kernels_ms_per_step'))
 PY
   done
 done
+for g in 1; do
+  MI_LZS_GROUPS=$g python bench.py --workload lz77w16-1m --bytes 100000000 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/r2/sl_g$g.json 2>/dev/null
+  python -c "
+import json; d=json.load(open('gpurun_out/r2/sl_g$g.json')); print('1m groups=$g', d['value'], d['ms_per_step'], d['roundtrip'])"
+done
