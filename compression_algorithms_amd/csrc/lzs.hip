@@ -475,11 +475,19 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     // cur16[g] is now the END of cluster g; it starts where g - 1 ends
     LZS_TICK(3);
 
-    // ---- permute into replay order
+    // ---- permute into replay order; the event ids come back from the list here (all of a thread's loads in flight together)
+    //      so that nothing after this point waits for a dependent global load
     uint32_t *e_key = s_c;
     uint16_t *e_rf = s_j0;
+    uint16_t *cand_i = reinterpret_cast<uint16_t *>(s_key);              // s_key is dead after the permutation: results ...
+    uint16_t *e_t = cand_i + LZS_CAP;                                    // ... and the time of every event, replay order
     {
-        uint32_t rk[CH], rr[CH];
+        uint32_t rk[CH], rr[CH], rt[CH];
+#pragma unroll
+        for (uint32_t c = 0; c < CH; ++c) {
+            const uint32_t i = tid + c * LZS_THREADS;
+            rt[c] = i < m ? plist[s_j1[i]] >> 1 : 0u;
+        }
 #pragma unroll
         for (uint32_t c = 0; c < CH; ++c) {
             const uint32_t i = tid + c * LZS_THREADS;
@@ -494,49 +502,76 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
 #pragma unroll
         for (uint32_t c = 0; c < CH; ++c) {
             const uint32_t i = tid + c * LZS_THREADS;
-            if (i < m) { e_key[i] = rk[c]; e_rf[i] = (uint16_t)rr[c]; }
+            if (i < m) { e_key[i] = rk[c]; e_rf[i] = (uint16_t)rr[c]; e_t[i] = (uint16_t)rt[c]; }
         }
     }
-    uint16_t *cand_i = reinterpret_cast<uint16_t *>(s_key);
     uint16_t *e_slot = s_r;
-    uint32_t *s_big = &s_cnt[LZS_NWAVES][0];             // <= 4096 / 17 clusters above the lane size: 240 words of the last row
+    uint16_t *lane_list = s_g;                            // cluster numbers are dead: clusters of 2..16 events, largest class first
+    uint32_t *s_big = &s_cnt[LZS_NWAVES][0];              // <= 4096 / 17 clusters above the lane size: 240 words of the last row
+    __shared__ uint32_t s_ccnt[4], s_cbase[4], s_ebase, s_dbase[2];
+    if (tid < 4) s_ccnt[tid] = 0;
     __syncthreads();
     LZS_TICK(4);
 
-    // ---- replay: a lane per small cluster, the others listed for the waves
-    for (uint32_t g = tid; g < ngroups; g += LZS_THREADS) {
-        const uint32_t s = g ? (uint32_t)cur16[g - 1] : 0u, e = cur16[g];
-        const uint32_t cm = e - s;
-        if (cm <= LZS_LANE_MAX) lzs_replay_lane(e_key, e_rf, e_slot, cand_i, s, cm);
-        else { const uint32_t q = atomicAdd(&s_nbig, 1u); s_big[q] = s | (cm << 16); s_bigm[q] = (uint16_t)cm; }
+    // ---- classify the clusters: singletons are answered on the spot, 2..16 events go to four size classes (a wave whose
+    //      lanes hold clusters of one class does not wait for one long lane), larger ones are listed for export
+    constexpr uint32_t GPT = LZS_CAP / LZS_THREADS;      // clusters per thread, at most
+    uint32_t my_cls[GPT], my_rank[GPT];
+#pragma unroll
+    for (uint32_t c = 0; c < GPT; ++c) {
+        const uint32_t g = tid + c * LZS_THREADS;
+        my_cls[c] = 4u; my_rank[c] = 0;
+        if (g < ngroups) {
+            const uint32_t cs = g ? (uint32_t)cur16[g - 1] : 0u, cm = (uint32_t)cur16[g] - cs;
+            if (cm == 1u) { if (!(e_rf[cs] & RF_OLD)) { cand_i[cs] = 0xFFFFu; e_slot[cs] = (uint16_t)cs; } }     // nobody to find, its home is free
+            else if (cm <= LZS_LANE_MAX) { my_cls[c] = cm > 8u ? 0u : cm > 4u ? 1u : cm > 2u ? 2u : 3u; my_rank[c] = atomicAdd(&s_ccnt[my_cls[c]], 1u); }
+            else { const uint32_t q = atomicAdd(&s_nbig, 1u); s_big[q] = cs | (cm << 16); s_bigm[q] = (uint16_t)cm; }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int c = 0; c < 4; ++c) { s_cbase[c] = run; run += s_ccnt[c]; }
+        // one reservation per part for what it exports (events, clusters per class): the returns are not needed before the
+        // lane replay is over
+        const uint32_t nbig = s_nbig;
+        uint32_t ev = 0, n0 = 0, n1 = 0;
+        for (uint32_t c = 0; c < nbig; ++c) { const uint32_t cm = s_bigm[c]; ev += cm; if (cm <= LZS_BIG_SMALL) ++n0; else ++n1; }
+        uint32_t *ctr = sc.counters + 128 + 4 * step;
+        s_ebase = nbig ? atomicAdd(&ctr[0], ev) : 0u;
+        s_dbase[0] = n0 ? atomicAdd(&ctr[1], n0) : 0u;
+        s_dbase[1] = n1 ? atomicAdd(&ctr[2], n1) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t c = 0; c < GPT; ++c) if (my_cls[c] < 4u) lane_list[s_cbase[my_cls[c]] + my_rank[c]] = (uint16_t)(tid + c * LZS_THREADS);
+    __syncthreads();
+    const uint32_t nlane = s_cbase[3] + s_ccnt[3];
+    for (uint32_t q = tid; q < nlane; q += LZS_THREADS) {
+        const uint32_t g = lane_list[q];
+        const uint32_t cs = g ? (uint32_t)cur16[g - 1] : 0u;
+        lzs_replay_lane(e_key, e_rf, e_slot, cand_i, cs, (uint32_t)cur16[g] - cs);
     }
     __syncthreads();
     LZS_TICK(5);
     if (sc.dbg && tid == 0) { atomicAdd((unsigned long long *)&sc.dbg[8], 1ull); atomicAdd((unsigned long long *)&sc.dbg[9], (unsigned long long)m);
                               atomicAdd((unsigned long long *)&sc.dbg[10], (unsigned long long)ngroups); atomicAdd((unsigned long long *)&sc.dbg[11], (unsigned long long)s_nbig);
                               uint32_t be = 0, h[3] = {0, 0, 0};
-                              for (uint32_t c = 0; c < s_nbig; ++c) { const uint32_t cm = s_big[c] >> 16; be += cm; h[0] += cm <= 32 ? cm : 0; h[1] += cm <= 64 ? cm : 0; h[2] += cm <= 128 ? cm : 0; }
+                              for (uint32_t c = 0; c < s_nbig; ++c) { const uint32_t cm = s_bigm[c]; be += cm; h[0] += cm <= 32 ? cm : 0; h[1] += cm <= 64 ? cm : 0; h[2] += cm <= 128 ? cm : 0; }
                               atomicAdd((unsigned long long *)&sc.dbg[12], (unsigned long long)be);
                               for (int q = 0; q < 3; ++q) atomicAdd((unsigned long long *)&sc.dbg[13 + q], (unsigned long long)h[q]); }
     // ---- larger clusters leave for k_lzs_big (a wave each, little LDS, many per CU): in here the workgroup would wait for
-    //      its longest chain — measured: 74 % of this kernel.  One reservation per part (events, clusters per class).
+    //      its longest chain — measured: 74 % of this kernel
     {
         const uint32_t nbig = s_nbig;
         if (nbig) {
-            __shared__ uint32_t s_ebase, s_dbase[2];
             if (tid == 0) {
-                uint32_t ev = 0, n0 = 0, n1 = 0;
-                for (uint32_t c = 0; c < nbig; ++c) { const uint32_t cm = s_big[c] >> 16; ev += cm; if (cm <= LZS_BIG_SMALL) ++n0; else ++n1; }
-                uint32_t *ctr = sc.counters + 128 + 4 * step;
-                s_ebase = atomicAdd(&ctr[0], ev);
-                s_dbase[0] = n0 ? atomicAdd(&ctr[1], n0) : 0u;
-                s_dbase[1] = n1 ? atomicAdd(&ctr[2], n1) : 0u;
                 uint32_t run = s_ebase, d0 = s_dbase[0], d1 = s_dbase[1];
                 for (uint32_t c = 0; c < nbig; ++c) {
-                    const uint32_t it = s_big[c], cm = it >> 16;
+                    const uint32_t cm = s_bigm[c];
                     const uint64_t d = (uint64_t)run | ((uint64_t)cm << 32) | ((uint64_t)lb << 48);
                     if (cm <= LZS_BIG_SMALL) sc.big_desc[0][d0++] = d; else sc.big_desc[1][d1++] = d;
-                    s_big[c] = (it & 0xFFFFu) | ((run - s_ebase) << 16);              // start in replay order | offset in the reservation (< 4096)
+                    s_big[c] = (s_big[c] & 0xFFFFu) | ((run - s_ebase) << 16);        // start in replay order | offset in the reservation (< 4096)
                     run += cm;
                 }
             }
@@ -547,9 +582,8 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
                 const uint32_t cs = s_big[c] & 0xFFFFu, ob = s_big[c] >> 16, cm = s_bigm[c];
                 for (uint32_t idx = ln; idx < cm; idx += 64u) {
                     const uint32_t i = cs + idx, rf = e_rf[i];
-                    const uint32_t eid = plist[s_j1[i]];
                     sc.big_key[ebase + ob + idx] = e_key[i];
-                    sc.big_info[ebase + ob + idx] = eid | (((rf & RF_SLOT) - cs) << 17) | ((rf & RF_DEAD) ? (1u << 29) : 0u);
+                    sc.big_info[ebase + ob + idx] = ((uint32_t)e_t[i] << 1) | ((rf & RF_OLD) ? 1u : 0u) | (((rf & RF_SLOT) - cs) << 17) | ((rf & RF_DEAD) ? (1u << 29) : 0u);
                     e_rf[i] = (uint16_t)(rf | RF_BIG);
                 }
             }
@@ -562,12 +596,12 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     for (uint32_t i = tid; i < m; i += LZS_THREADS) {
         const uint32_t rf = e_rf[i];
         if (rf & (RF_OLD | RF_BIG)) continue;
-        const uint32_t t = plist[s_j1[i]] >> 1;
+        const uint32_t t = e_t[i];
         const uint32_t sl = e_slot[i];
         slot_new[t] = ((e_key[i] & Tmask) + ((sl & RF_SLOT) - (rf & RF_SLOT))) | ((sl & ES_KILLED) ? LZS_DEAD : 0u);
         const uint32_t ci = cand_i[i];
         uint32_t res = LZS_NONE;
-        if (ci != 0xFFFFu) { const uint32_t eo = plist[s_j1[ci]]; res = ((eo & 1u) ? base_old : base_new) + (eo >> 1); }
+        if (ci != 0xFFFFu) res = ((e_rf[ci] & RF_OLD) ? base_old : base_new) + (uint32_t)e_t[ci];
         cand[t] = res;
     }
     LZS_TICK(7);
@@ -586,6 +620,9 @@ void k_lzs_big(LzP P, LzsScratch sc, uint32_t step, uint32_t cls)
     const uint32_t W = 1u << P.wbits, t0 = step * W, Tmask = (1u << P.tbits) - 1u;
     const uint32_t base_new = t0, base_old = t0 - (step ? W : 0u);
     const uint32_t count = sc.counters[128 + 4 * step + 1 + cls];
+    // the long chains are the step's critical path: their waves go first whenever they can issue (the short-chain class
+    // runs beside them with 32 waves per CU and saturates the scalar unit)
+    if (CAPB > 1024u) __builtin_amdgcn_s_setprio(3);
     // clusters are handed out by a cursor (a static stride left waves with twice the average chain), FETCH at a time: one
     // returning atomic per cluster on one address cost more than the replays (91 k clusters per step: 34 -> 45 ms)
     uint32_t *cursor = &sc.counters[384 + 2 * step + cls];
@@ -606,14 +643,16 @@ void k_lzs_big(LzP P, LzsScratch sc, uint32_t step, uint32_t cls)
         const uint32_t *key = sc.big_key + first, *info = sc.big_info + first;
         uint32_t *slot_new = sc.slot + (size_t)lb * sc.S + t0;
         uint32_t *cand = sc.cand + (size_t)lb * sc.S + t0;
+        // the first 64 records serve the set-up pass and the first round of the replay: one load round for most clusters
+        uint32_t n_key = lane < m ? key[lane] : 0u, n_inf = lane < m ? info[lane] : 0u;
         for (uint32_t idx = lane; idx < m; idx += 64u) s_oeid[idx] = LZS_EMPTY;
         __builtin_amdgcn_wave_barrier();
         for (uint32_t idx = lane; idx < m; idx += 64u) {                   // the table the step starts from
-            const uint32_t inf = info[idx];
-            if ((inf & 1u) && !((inf >> 29) & 1u)) { const uint32_t r = (inf >> 17) & 0xFFFu; s_oeid[r] = inf & BI_EID; s_okey[r] = key[idx]; }
+            uint32_t inf = n_inf, kw = n_key;
+            if (idx >= 64u) { inf = info[idx]; kw = key[idx]; }
+            if ((inf & 1u) && !((inf >> 29) & 1u)) { const uint32_t r = (inf >> 17) & 0xFFFu; s_oeid[r] = inf & BI_EID; s_okey[r] = kw; }
         }
         __builtin_amdgcn_wave_barrier();
-        uint32_t n_key = lane < m ? key[lane] : 0u, n_inf = lane < m ? info[lane] : 0u;
         for (uint32_t i0 = 0; i0 < m; i0 += 64u) {
             const uint32_t my_key = n_key, my_inf = n_inf;
             if (i0 + 64u + lane < m) { n_key = key[i0 + 64u + lane]; n_inf = info[i0 + 64u + lane]; }    // in flight during these 64

@@ -125,3 +125,46 @@ def test_whole_buffer_fixture_of_round_1(golden_dir):
         s[: len(raw)] = raw
         assert nb == e[f"lz77_w{wb}_whole"]["bits"] and _sha(s) == e[f"lz77_w{wb}_whole"]["sha256"], wb
         assert np.array_equal(lz.decompress(st).cpu().numpy(), sample)
+
+
+# ---- the time-sliced finder (lzs.hip) against the oracle on every input family, and against the whole-block finder
+@pytest.mark.parametrize("kind", ["text", "lowent", "phrases", "runs", "pages"])
+@pytest.mark.parametrize("wbits,block", [(16, 131072), (16, 262144), (14, 131072)])
+def test_sliced_finder_families(kind, wbits, block):
+    import test_fuzz_gpu as F
+    seed = 7000 + block // 1000 + wbits
+    data = F._family(kind, seed, int(2.3 * block))
+    _check_find(data, wbits, block)
+
+
+@pytest.mark.parametrize("wbits", [16, 14])
+def test_sliced_equals_whole_block_finder(wbits, monkeypatch):
+    """1 MiB blocks (16 / 64 steps): lzs.hip (sub-blocks of W positions, old entries pre-placed) and lzw.hip (one cluster
+    structure for the whole block) must agree position by position; the first block also against the oracle"""
+    from compression_algorithms_amd import lz
+    from oracle import orc
+    data = synth.enwik_like(1_500_000, seed=77).numpy()
+    p = lz.params("lz77", wbits, 1 << 20)
+    monkeypatch.setenv("MI_LZW_SLICED", "0")
+    whole = lz.find_all32(data, p).cpu().numpy().view(np.uint32)
+    monkeypatch.setenv("MI_LZW_SLICED", "1")
+    sliced = lz.find_all32(data, p).cpu().numpy().view(np.uint32)
+    bad = np.flatnonzero(whole != sliced)
+    assert bad.size == 0, (bad.size, bad[:5], whole[bad[:5]], sliced[bad[:5]])
+    want = orc.find_all(data[: 1 << 20], wbits, wbits + 6, False)
+    assert np.array_equal(sliced[: 1 << 20], want)
+
+
+def test_sliced_finder_dead_entries_cross_steps():
+    """a word whose home is bucket 0, repeated every few thousand positions over five windows: the clear of bucket 0 at
+    insertion W-1 removes one copy early, whose own retirement then removes a LATER copy early, and so on through every
+    step (an entry removed early is carried into the next step as dead)"""
+    from oracle import orc
+    w = next(c for c in range(1, 1 << 26) if orc.home(c, 22) == 0)
+    word = np.frombuffer(int(w).to_bytes(4, "little"), dtype=np.uint8)
+    rng = np.random.default_rng(31)
+    data = rng.integers(1, 255, 330_000, dtype=np.uint8)
+    for at in range(50, 329_000, 3001):
+        data[at:at + 4] = word
+    _check_find(data, 16, 1 << 20)
+    _check_stream(data, 16, 1 << 20)
