@@ -74,8 +74,8 @@ DESC = {
     "deflate": "deflate tokeniser alone (LZ77, W=32 KiB, len<=31, the reference's byte tokens, mode T), independent 64 KiB blocks",
     "lz77w16": "lz77 (W=64 KiB, len<=15, bit-packed), independent 64 KiB blocks",
     "lz77w14": "lz77 (W=16 KiB, len<=15, bit-packed), independent 64 KiB blocks",
-    "lz77w16-256k": "lz77 (W=64 KiB, len<=15, bit-packed), independent 256 KiB blocks: the window slides (HBM-resident finder)",
-    "lz77w16-1m": "lz77 (W=64 KiB, len<=15, bit-packed), independent 1 MiB blocks: the window slides (HBM-resident finder)",
+    "lz77w16-256k": "lz77 (W=64 KiB, len<=15, bit-packed), independent 256 KiB blocks: the window slides (time-sliced finder, lzs.hip)",
+    "lz77w16-1m": "lz77 (W=64 KiB, len<=15, bit-packed), independent 1 MiB blocks: the window slides (time-sliced finder, lzs.hip)",
     "huffman": "whole-buffer Huffman, one tree",
     "fse": "FSE/tANS table_log 8, independent 64 KiB blocks x 64 sub-streams",
 }

@@ -19,7 +19,8 @@
  * more than any earlier call of the context did; after a first call of the largest size a context will see, the encoders
  * neither allocate nor synchronise.  One encode per context may be in flight at a time (the workspace is shared; use one
  * context per concurrent stream).  The LZ encoders fork onto three internal streams of the context and join back into
- * `stream` with events before they return control of it.
+ * `stream` with events before they return control of it.  One exception: the lz77 flavour on blocks above 64 KiB
+ * synchronises `stream` once per batch of <= 256 MiB (it reads back whether a block needs the whole-block finder).
  * Decoders (*_decode_dev) synchronise `stream` before returning: MI_ERR_CORRUPT is decided on the device.  They take the
  * readable length of the stream and never read outside it, whatever an (untrusted) offset table says; every decode call
  * uses its own device status word, so decodes on different streams of one context do not interfere.
