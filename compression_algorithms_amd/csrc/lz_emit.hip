@@ -365,13 +365,14 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
 // single-workgroup exclusive scan of the batch's block bit counts; also publishes the global
 // exclusive offsets (base + local) to the caller's array
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024)
+__global__ __launch_bounds__(256)
 void k_lz_scan_blocks(const uint64_t *bits, uint32_t nb, const uint64_t *__restrict__ base_bits,
                       uint64_t *excl_local /* may alias `bits`: scanned in place */, uint64_t *__restrict__ excl_global)
 {
-    __shared__ uint64_t s_tmp[18];
-    // PER consecutive blocks per thread (a batch holds up to 4096 blocks)
-    const uint32_t PER = (nb + 1023u) / 1024u, a = threadIdx.x * PER, b = a + PER < nb ? a + PER : nb;
+    // one small workgroup (it sits between two LDS-hungry kernels of its stream and must find a free slot quickly):
+    // PER consecutive blocks per thread, a batch holds up to 4096 blocks
+    __shared__ uint64_t s_tmp[6];
+    const uint32_t PER = (nb + 255u) / 256u, a = threadIdx.x * PER, b = a + PER < nb ? a + PER : nb;
     uint64_t v = 0;
     for (uint32_t i = a; i < b; ++i) v += bits[i];
     uint64_t inc = v;
@@ -380,13 +381,13 @@ void k_lz_scan_blocks(const uint64_t *bits, uint32_t nb, const uint64_t *__restr
     for (int o = 1; o < 64; o <<= 1) { uint64_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
     if (lane == 63) s_tmp[wave] = inc;
     __syncthreads();
-    if (threadIdx.x == 0) { uint64_t run = 0; for (int w = 0; w < 16; ++w) { uint64_t t = s_tmp[w]; s_tmp[w] = run; run += t; } s_tmp[16] = run; }
+    if (threadIdx.x == 0) { uint64_t run = 0; for (int w = 0; w < 4; ++w) { uint64_t t = s_tmp[w]; s_tmp[w] = run; run += t; } s_tmp[4] = run; }
     __syncthreads();
     uint64_t run = s_tmp[wave] + inc - v;
     const uint64_t base = *base_bits;
     for (uint32_t i = a; i < b; ++i) { const uint64_t x = bits[i]; excl_local[i] = run; excl_global[i] = base + run; run += x; }
     __syncthreads();                                    // (in place: every thread has read its own range before anyone writes [nb])
-    if (threadIdx.x == 0) { excl_local[nb] = s_tmp[16]; excl_global[nb] = base + s_tmp[16]; }
+    if (threadIdx.x == 0) { excl_local[nb] = s_tmp[4]; excl_global[nb] = base + s_tmp[4]; }
 }
 
 __global__ void k_lz_advance(uint64_t *base_bits, const uint64_t *excl_local, uint32_t nb) { *base_bits += excl_local[nb]; }
@@ -508,7 +509,7 @@ static mi_status lz_encode_impl(mi_ctx *ctx, const mi_lz_params *p, const uint8_
             if (st) return st;
             { mi_prof_scope pr(ctx, "k_lzw_parse_emit", s, (uint64_t)nb * P.block);
               lzw_launch_parse_emit(d_in, n, P, ws, b0, nb, s); }
-            hipLaunchKernelGGL(k_lz_scan_blocks, dim3(1), dim3(1024), 0, s, ws.block_bits, nb, base_bits_w, ws.block_bits, d_block_bits + b0);
+            hipLaunchKernelGGL(k_lz_scan_blocks, dim3(1), dim3(256), 0, s, ws.block_bits, nb, base_bits_w, ws.block_bits, d_block_bits + b0);
             { mi_prof_scope pr(ctx, "k_lz_concat", s, (uint64_t)nb * P.block);
               const uint64_t typw = (uint64_t)nb * (P.block / 4 + 64);
               hipLaunchKernelGGL(k_lz_concat, dim3((unsigned)((typw + 255) / 256 < 65535 ? (typw + 255) / 256 : 65535)), dim3(256), 0, s, ws.slot, ws.block_bits, nb,
@@ -549,7 +550,7 @@ static mi_status lz_encode_impl(mi_ctx *ctx, const mi_lz_params *p, const uint8_
             mi_prof_scope ph(ctx, "k_defh_encode", sp, (uint64_t)nb * P.block);
             defh_launch_encode(trec, sc[k].slot, sc[k].block_bits, nb, sp);
         }
-        hipLaunchKernelGGL(k_lz_scan_blocks, dim3(1), dim3(1024), 0, sp, sc[k].block_bits, nb, base_bits, excl_local, d_block_bits + b0);
+        hipLaunchKernelGGL(k_lz_scan_blocks, dim3(1), dim3(256), 0, sp, sc[k].block_bits, nb, base_bits, excl_local, d_block_bits + b0);
         {
             mi_prof_scope pr(ctx, "k_lz_concat", sp, (uint64_t)nb * P.block);
             const uint64_t typw = (uint64_t)nb * (P.block / 4 + 64);   // about one output byte per input byte; the kernel strides

@@ -557,7 +557,7 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     if (sc.dbg && tid == 0) { atomicAdd((unsigned long long *)&sc.dbg[8], 1ull); atomicAdd((unsigned long long *)&sc.dbg[9], (unsigned long long)m);
                               atomicAdd((unsigned long long *)&sc.dbg[10], (unsigned long long)ngroups); atomicAdd((unsigned long long *)&sc.dbg[11], (unsigned long long)s_nbig);
                               uint32_t be = 0, h[3] = {0, 0, 0};
-                              for (uint32_t c = 0; c < s_nbig; ++c) { const uint32_t cm = s_bigm[c]; be += cm; h[0] += cm <= 32 ? cm : 0; h[1] += cm <= 64 ? cm : 0; h[2] += cm <= 128 ? cm : 0; }
+                              for (uint32_t c = 0; c < s_nbig; ++c) { const uint32_t cm = s_bigm[c]; be += cm; h[0] += cm > 512 ? cm : 0; h[1] += cm > 1024 ? cm : 0; h[2] += cm > 2048 ? cm : 0; }
                               atomicAdd((unsigned long long *)&sc.dbg[12], (unsigned long long)be);
                               for (int q = 0; q < 3; ++q) atomicAdd((unsigned long long *)&sc.dbg[13 + q], (unsigned long long)h[q]); }
     // ---- larger clusters leave for k_lzs_big (a wave each, little LDS, many per CU): in here the workgroup would wait for
@@ -615,7 +615,9 @@ template <uint32_t CAPB>
 __global__ __launch_bounds__(64)
 void k_lzs_big(LzP P, LzsScratch sc, uint32_t step, uint32_t cls)
 {
+    constexpr uint32_t BW = CAPB / 32u;
     __shared__ uint32_t s_okey[CAPB], s_oeid[CAPB];      // per slot of the cluster: the occupant's mixed word / event id
+    __shared__ uint32_t s_bm[BW];                        // occupancy, one bit per slot
     const uint32_t lane = threadIdx.x;
     const uint32_t W = 1u << P.wbits, t0 = step * W, Tmask = (1u << P.tbits) - 1u;
     const uint32_t base_new = t0, base_old = t0 - (step ? W : 0u);
@@ -645,12 +647,15 @@ void k_lzs_big(LzP P, LzsScratch sc, uint32_t step, uint32_t cls)
         uint32_t *cand = sc.cand + (size_t)lb * sc.S + t0;
         // the first 64 records serve the set-up pass and the first round of the replay: one load round for most clusters
         uint32_t n_key = lane < m ? key[lane] : 0u, n_inf = lane < m ? info[lane] : 0u;
-        for (uint32_t idx = lane; idx < m; idx += 64u) s_oeid[idx] = LZS_EMPTY;
+        for (uint32_t idx = lane; idx < BW; idx += 64u) s_bm[idx] = 0;
         __builtin_amdgcn_wave_barrier();
         for (uint32_t idx = lane; idx < m; idx += 64u) {                   // the table the step starts from
             uint32_t inf = n_inf, kw = n_key;
             if (idx >= 64u) { inf = info[idx]; kw = key[idx]; }
-            if ((inf & 1u) && !((inf >> 29) & 1u)) { const uint32_t r = (inf >> 17) & 0xFFFu; s_oeid[r] = inf & BI_EID; s_okey[r] = kw; }
+            if ((inf & 1u) && !((inf >> 29) & 1u)) {
+                const uint32_t r = (inf >> 17) & 0xFFFu;
+                s_oeid[r] = inf & BI_EID; s_okey[r] = kw; atomicOr(&s_bm[r >> 5], 1u << (r & 31u));
+            }
         }
         __builtin_amdgcn_wave_barrier();
         for (uint32_t i0 = 0; i0 < m; i0 += 64u) {
@@ -665,10 +670,11 @@ void k_lzs_big(LzP P, LzsScratch sc, uint32_t step, uint32_t cls)
                 const uint32_t run = rest ? (uint32_t)__builtin_ctzll(rest) : 64u - l;
                 if (run) {                                                 // clear the recorded buckets, whoever sits there (lz77.c:70-76)
                     if (lane >= l && lane < l + run) {
-                        const uint32_t r = (my_inf >> 17) & 0xFFFu, o = s_oeid[r];
-                        if (o != LZS_EMPTY) {
+                        const uint32_t r = (my_inf >> 17) & 0xFFFu, bit = 1u << (r & 31u);
+                        if (s_bm[r >> 5] & bit) {
+                            const uint32_t o = s_oeid[r];
                             if (o != (my_inf & BI_EID) && !(o & 1u)) atomicOr(&slot_new[o >> 1], LZS_DEAD);    // a new entry removed early
-                            s_oeid[r] = LZS_EMPTY;
+                            atomicAnd(&s_bm[r >> 5], ~bit);
                         }
                     }
                     l += run;
@@ -677,23 +683,41 @@ void k_lzs_big(LzP P, LzsScratch sc, uint32_t step, uint32_t cls)
                 }
                 const uint32_t inf = (uint32_t)__builtin_amdgcn_readlane((int)my_inf, (int)l), kw = (uint32_t)__builtin_amdgcn_readlane((int)my_key, (int)l);
                 const uint32_t r = (inf >> 17) & 0xFFFu, eid = inf & BI_EID;
-                uint32_t found = LZS_EMPTY, fe = 0;
-                bool searching = true;
-                for (uint32_t base = r;; base += 64u) {                    // find() and first fit: 64 buckets per step (lz77.c:55-108)
-                    const uint32_t idx = base + lane;
-                    const uint32_t v = idx < m ? s_oeid[idx] : LZS_EMPTY;  // past the cluster: nobody's bucket
-                    const uint32_t k = idx < m ? s_okey[idx] : 0u;
-                    const uint64_t be = __ballot(v == LZS_EMPTY), bmm = __ballot(v != LZS_EMPTY && k == kw);
-                    if (searching && bmm) {
-                        const uint32_t fm = (uint32_t)__builtin_ctzll(bmm);
-                        if (!be || fm < (uint32_t)__builtin_ctzll(be)) { found = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)fm); searching = false; }
+                // first fit: the occupancy words from r's on, one per lane (2048 buckets per look) — a frequent word's live
+                // copies fill hundreds of buckets above its home, and walking them 64 at a time was the chain's cost.
+                // The first 64 buckets' occupants are read in the same breath: the word's own copy usually sits right there.
+                const uint32_t wbase = r >> 5;
+                uint32_t wv = (wbase + lane < BW) ? s_bm[wbase + lane] : 0u;                  // past the array: nobody's buckets
+                const uint32_t idx0 = r + lane;
+                uint32_t v = idx0 < CAPB ? s_oeid[idx0] : 0u, k = idx0 < CAPB ? s_okey[idx0] : 0u;
+                if (lane == 0) wv |= (1u << (r & 31u)) - 1u;                                   // buckets below the home do not count
+                uint32_t fe;
+                {
+                    uint64_t bf = __ballot(wv != 0xFFFFFFFFu);
+                    uint32_t wb = wbase;
+                    while (!bf) {                                                              // (more than 2048 occupied buckets in a row)
+                        wb += 64u;
+                        wv = (wb + lane < BW) ? s_bm[wb + lane] : 0u;
+                        bf = __ballot(wv != 0xFFFFFFFFu);
                     }
-                    if (be) { fe = base + (uint32_t)__builtin_ctzll(be); break; }
+                    const uint32_t fl = (uint32_t)__builtin_ctzll(bf);
+                    const uint32_t fw = ~(uint32_t)__builtin_amdgcn_readlane((int)wv, (int)fl);
+                    fe = ((wb + fl) << 5) + (uint32_t)__builtin_ctz(fw);
+                }
+                // find(): the first occupant of [r, fe) that holds this word (every bucket in there is occupied)
+                uint32_t found = LZS_EMPTY;
+                for (uint32_t base = r;;) {
+                    const uint64_t bmm = __ballot(base + lane < fe && k == kw);
+                    if (bmm) { found = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_ctzll(bmm)); break; }
+                    base += 64u;
+                    if (base >= fe) break;
+                    const uint32_t idx = base + lane;
+                    v = idx < CAPB ? s_oeid[idx] : 0u; k = idx < CAPB ? s_okey[idx] : 0u;
                 }
                 if (lane == 0) {
                     const uint32_t t = eid >> 1;
                     cand[t] = found == LZS_EMPTY ? LZS_NONE : ((found & 1u) ? base_old : base_new) + (found >> 1);
-                    if (fe < m) { s_okey[fe] = kw; s_oeid[fe] = eid; }     // fe < m by the parking bound
+                    if (fe < m) { s_okey[fe] = kw; s_oeid[fe] = eid; atomicOr(&s_bm[fe >> 5], 1u << (fe & 31u)); }     // fe < m by the parking bound
                     __hip_atomic_store(&slot_new[t], (kw & Tmask) + (fe - r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (an early clear ORs LZS_DEAD into it later)
                 }
                 l += 1u;
@@ -798,7 +822,7 @@ mi_status lzs_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, u
             double tot = 0; for (int k = 0; k < 8; ++k) tot += (double)v[k];
             fprintf(stderr, "k_lzs_find: %llu parts, %.0f events, %.1f clusters, %.2f wave clusters with %.0f events per part; %.0f cycles per part; flagged %u\n",
                     (unsigned long long)v[8], (double)v[9] / v[8], (double)v[10] / v[8], (double)v[11] / v[8], (double)v[12] / v[8], tot / v[8], *flagged);
-            fprintf(stderr, "   exported events per part in clusters <= 32: %.0f, <= 64: %.0f, <= 128: %.0f\n", (double)v[13] / v[8], (double)v[14] / v[8], (double)v[15] / v[8]);
+            fprintf(stderr, "   exported events per part in clusters > 512: %.0f, > 1024: %.0f, > 2048: %.0f\n", (double)v[13] / v[8], (double)v[14] / v[8], (double)v[15] / v[8]);
             for (int k = 0; k < 8; ++k) fprintf(stderr, "   %-12s %5.1f %%  %8.0f cycles/part\n", nm[k], 100.0 * v[k] / tot, (double)v[k] / v[8]);
         }
     }
