@@ -769,7 +769,7 @@ mi_status lzs_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, u
     const uint32_t chunks = (P.block + 256u * 16u - 1u) / (256u * 16u);
     // group g walks its steps on st[g]; the few long chains of a step (clusters above 512 events) run beside the many short
     // ones on the group's second stream ax[g] (a launch lasts as long as its longest chain)
-    const bool multi = ctx->side && ctx->parse && ctx->fb;
+    const bool multi = ctx->side && ctx->parse && ctx->fb && !getenv("MI_LZS_SERIAL");       // MI_LZS_SERIAL=1: one stream (per-kernel times)
     hipStream_t st[2] = {s, multi ? ctx->side : s}, ax[2] = {multi ? ctx->parse : s, multi ? ctx->fb : s};
     const char *eg = getenv("MI_LZS_GROUPS");
     uint32_t G = eg ? (uint32_t)atoi(eg) : 2u;
