@@ -20,3 +20,4 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES" \
   rocprofv3 --pmc $grp --output-format csv -d "$OUT/g$i" -- python3 bench.py $ARGS > "$OUT/bench_g$i.json" 2> "$OUT/g$i.log" || { echo "pass $i failed"; tail -3 "$OUT/g$i.log"; }
 done
 python3 scripts/summarise_pmc.py "$OUT" "$TAG"
+rm -rf "$OUT"/g[0-9]*          # raw counter CSVs: tens of MiB per pass; the summary under gpurun_out/profiles/ is what is kept
