@@ -271,12 +271,12 @@ void k_defh_decode(const uint8_t *__restrict__ stream, uint64_t stream_bytes, co
 
     // every control value below is wave-uniform: the bit buffer sits in SGPRs and is refilled from 64 record words held
     // one per lane (lz_decode.h); the only memory on a token's critical path is its LUT cell
-    const uint64_t nbits = (uint64_t)nwords * 32u;
+    const uint32_t nbits = nwords * 32u;                               // nwords <= 2 n + 2
     BitsMsb br;
     br.init(w, nwords, lane);
     OutRing<RING> ring;
     ring.init(s_ring, out + off, lane);
-    uint64_t pos = 0;
+    uint32_t pos = 0;
     uint32_t o = 0;
     for (uint32_t t = 0; t < ntok && o < n; ++t) {
         br.refill();

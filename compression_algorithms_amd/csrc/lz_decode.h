@@ -23,7 +23,7 @@ struct WaveWords {
     // dword i (wave-uniform, consumed in increasing order)
     __device__ __forceinline__ uint32_t get(uint32_t i)
     {
-        if (i - base >= 64u) { base += 64u; cur = nxt; nxt = load(base + 64u + lane); }
+        if (__builtin_expect(i - base >= 64u, 0)) { base += 64u; cur = nxt; nxt = load(base + 64u + lane); }
         return (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(i - base));
     }
 };
@@ -38,13 +38,14 @@ struct BitsLsb {
         const uint32_t bit0 = (uint32_t)(A & 31u);
         const uint64_t words = (bit0 + nbits + 31u) >> 5;
         w.init(reinterpret_cast<const uint32_t *>((uintptr_t)((A >> 5) << 2)), words > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)words, lane);
-        buf = 0; have = 0; widx = 0;
-        refill();
-        buf >>= bit0; have -= bit0;
+        buf = (uint64_t)w.get(0) | ((uint64_t)w.get(1) << 32);
+        have = 64u - bit0; widx = 2;
+        buf >>= bit0;
     }
+    // a token takes at most 32 bits: one word per refill keeps more than 32 unread bits in the buffer
     __device__ __forceinline__ void refill()
     {
-        while (have <= 32u) { buf |= (uint64_t)w.get(widx) << have; have += 32u; ++widx; }
+        if (have <= 32u) { buf |= (uint64_t)w.get(widx) << have; have += 32u; ++widx; }
     }
     __device__ __forceinline__ uint32_t peek(uint32_t k) const { return (uint32_t)buf & ((1u << k) - 1u); }      // k <= 31
     __device__ __forceinline__ void skip(uint32_t k) { buf >>= k; have -= k; }
@@ -57,12 +58,13 @@ struct BitsMsb {
     __device__ __forceinline__ void init(const uint32_t *words, uint32_t nwords, uint32_t lane)
     {
         w.init(words, nwords, lane);
-        buf = 0; have = 0; widx = 0;
-        refill();
+        buf = ((uint64_t)w.get(0) << 32) | (uint64_t)w.get(1);
+        have = 64u; widx = 2;
     }
+    // called before every read of at most 32 bits: one word per refill keeps more than 32 unread bits in the buffer
     __device__ __forceinline__ void refill()
     {
-        while (have <= 32u) { buf |= (uint64_t)w.get(widx) << (32u - have); have += 32u; ++widx; }
+        if (have <= 32u) { buf |= (uint64_t)w.get(widx) << (32u - have); have += 32u; ++widx; }
     }
     __device__ __forceinline__ uint32_t top32() const { return (uint32_t)(buf >> 32); }
     __device__ __forceinline__ void skip(uint32_t k) { buf <<= k; have -= k; }
@@ -103,7 +105,7 @@ struct OutRing {
     }
     __device__ __forceinline__ void advance(uint32_t o)
     {
-        while (o - flushed >= CH) { copy_out(flushed, flushed + CH); flushed += CH; }
+        if (__builtin_expect(o - flushed >= CH, 0)) { copy_out(flushed, flushed + CH); flushed += CH; }     // a token adds < CH bytes
     }
     __device__ __forceinline__ void finish(uint32_t n) { copy_out(flushed, n); }
 };
