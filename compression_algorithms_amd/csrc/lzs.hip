@@ -48,7 +48,9 @@
 #define ES_KILLED     0x8000u
 #define RF_BIG        0x4000u                     // the event's cluster is replayed by k_lzs_big
 #define LZS_BIG_SMALL 512u                        // class 0: 17..512 events (4 KiB of LDS per wave), class 1: up to LZS_CAP (32 KiB)
-#define LZS_CTR_WORDS 512u                        // counters per group of blocks: [0..63] parts of step k, [128 + 4k ..] exports, [384 + 2k ..] replay cursors
+#define LZS_CTR_WORDS 1024u                       // counters per group of blocks: [0..63] parts of step k, [128 + 8k ..] exports, [768 + 2k ..] replay cursors
+#define LZS_NCLS      4u                          // export classes: 0: 17..32 and 1: 33..64 events (a lane per cluster), 2: 65..512 and 3: up to LZS_CAP (a wave per cluster)
+#define LZS_MID_MAX   64u
 #define BI_EID        0x1FFFFu                    // big_info: event id | slot relative to the cluster << 17 | dead << 29
 
 struct LzsMeta {
@@ -63,9 +65,9 @@ struct LzsScratch {
     uint32_t *plist;      // [nb][S] event ids of the current step, grouped by part, event order inside a part
     LzsMeta  *meta;       // [nb]
     uint32_t *work;       // [nb * LZS_MAXPARTS] parts of the current step: block | part << 16
-    uint32_t *counters;   // [0..63] parts listed in step k, [64] flagged blocks, [128 + 4 k ..] step k: exported events, clusters of class 0 / 1
+    uint32_t *counters;   // [0..63] parts listed in step k, [64] flagged blocks, [128 + 8 k ..] step k: exported events, clusters of class 0..3
     uint32_t *big_key, *big_info;   // [nb * S] events of the exported clusters of the current step, (cluster, event) order
-    uint64_t *big_desc[2];          // per class: first event | count << 32 | block << 48
+    uint64_t *big_desc[LZS_NCLS];   // per class: first event | count << 32 | block << 48
     uint32_t *flag_count; // flagged blocks of the whole batch
     uint32_t  S;
     uint64_t *dbg;        // phase cycle counters of k_lzs_find (MI_LZ_DEBUG=1), else NULL
@@ -295,8 +297,15 @@ __device__ __forceinline__ void lzs_replay_lane(const uint32_t *e_key, const uin
     }
 }
 
+// use_mid = 0: everything up to 512 events goes to the wave replay (few blocks per step: two more launches on the step's
+// latency chain cost more than they save)
+__host__ __device__ __forceinline__ uint32_t lzs_export_class(uint32_t cm, uint32_t use_mid)
+{
+    return (use_mid && cm <= LZS_MID_MAX) ? (cm <= 32u ? 0u : 1u) : cm <= LZS_BIG_SMALL ? 2u : 3u;
+}
+
 __global__ __launch_bounds__(LZS_THREADS)
-void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_t step)
+void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_t step, uint32_t use_mid)
 {
     __shared__ uint32_t s_key[LZS_CAP];                 // mix32(word) by event index j; later cand_i (u16, replay order)
     __shared__ uint32_t s_c[LZS_CAP];                   // coordinate - part_lo | CF_OLD | CF_DEAD by j; later e_key (replay order)
@@ -508,7 +517,7 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     uint16_t *e_slot = s_r;
     uint16_t *lane_list = s_g;                            // cluster numbers are dead: clusters of 2..16 events, largest class first
     uint32_t *s_big = &s_cnt[LZS_NWAVES][0];              // <= 4096 / 17 clusters above the lane size: 240 words of the last row
-    __shared__ uint32_t s_ccnt[4], s_cbase[4], s_ebase, s_dbase[2];
+    __shared__ uint32_t s_ccnt[4], s_cbase[4], s_ebase, s_dbase[LZS_NCLS];
     if (tid < 4) s_ccnt[tid] = 0;
     __syncthreads();
     LZS_TICK(4);
@@ -535,12 +544,11 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
         // one reservation per part for what it exports (events, clusters per class): the returns are not needed before the
         // lane replay is over
         const uint32_t nbig = s_nbig;
-        uint32_t ev = 0, n0 = 0, n1 = 0;
-        for (uint32_t c = 0; c < nbig; ++c) { const uint32_t cm = s_bigm[c]; ev += cm; if (cm <= LZS_BIG_SMALL) ++n0; else ++n1; }
-        uint32_t *ctr = sc.counters + 128 + 4 * step;
+        uint32_t ev = 0, nc[LZS_NCLS] = {0, 0, 0, 0};
+        for (uint32_t c = 0; c < nbig; ++c) { const uint32_t cm = s_bigm[c]; ev += cm; ++nc[lzs_export_class(cm, use_mid)]; }
+        uint32_t *ctr = sc.counters + 128 + 8 * step;
         s_ebase = nbig ? atomicAdd(&ctr[0], ev) : 0u;
-        s_dbase[0] = n0 ? atomicAdd(&ctr[1], n0) : 0u;
-        s_dbase[1] = n1 ? atomicAdd(&ctr[2], n1) : 0u;
+        for (uint32_t q = 0; q < LZS_NCLS; ++q) s_dbase[q] = nc[q] ? atomicAdd(&ctr[1 + q], nc[q]) : 0u;
     }
     __syncthreads();
 #pragma unroll
@@ -566,11 +574,10 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
         const uint32_t nbig = s_nbig;
         if (nbig) {
             if (tid == 0) {
-                uint32_t run = s_ebase, d0 = s_dbase[0], d1 = s_dbase[1];
+                uint32_t run = s_ebase, dn[LZS_NCLS] = {s_dbase[0], s_dbase[1], s_dbase[2], s_dbase[3]};
                 for (uint32_t c = 0; c < nbig; ++c) {
-                    const uint32_t cm = s_bigm[c];
-                    const uint64_t d = (uint64_t)run | ((uint64_t)cm << 32) | ((uint64_t)lb << 48);
-                    if (cm <= LZS_BIG_SMALL) sc.big_desc[0][d0++] = d; else sc.big_desc[1][d1++] = d;
+                    const uint32_t cm = s_bigm[c], q = lzs_export_class(cm, use_mid);
+                    sc.big_desc[q][dn[q]++] = (uint64_t)run | ((uint64_t)cm << 32) | ((uint64_t)lb << 48);
                     s_big[c] = (s_big[c] & 0xFFFFu) | ((run - s_ebase) << 16);        // start in replay order | offset in the reservation (< 4096)
                     run += cm;
                 }
@@ -607,10 +614,95 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     LZS_TICK(7);
 }
 
-// =============================================================================================
-// stage 3: a wave per exported cluster (17 .. LZS_CAP events)
-// =============================================================================================
 #define LZS_EMPTY 0xFFFFFFFFu
+// =============================================================================================
+// stage 3a: a LANE per exported cluster of 17..64 events (64 clusters per wave).  The wave replay below spends ~75 CU-cycles
+// of scalar issue per event; here an event is a few dozen vector instructions shared by 64 clusters.  Per lane: occupancy
+// in one 64-bit register, per slot {occupant's mixed word, event id} in LDS (word-interleaved over the lanes: no bank
+// conflicts), records four at a time (16-byte loads, the next four in flight).
+// =============================================================================================
+template <uint32_t CAPM>
+__global__ __launch_bounds__(64)
+void k_lzs_mid(LzP P, LzsScratch sc, uint32_t step, uint32_t cls)
+{
+    __shared__ uint32_t s_okey[CAPM * 64u], s_oeid[CAPM * 64u];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t W = 1u << P.wbits, t0 = step * W, Tmask = (1u << P.tbits) - 1u;
+    const uint32_t base_new = t0, base_old = t0 - (step ? W : 0u);
+    const uint32_t count = sc.counters[128 + 8 * step + 1 + cls];
+    for (uint32_t wg = blockIdx.x; wg * 64u < count; wg += gridDim.x) {
+        const uint32_t ci = wg * 64u + lane;
+        uint32_t first = 0, m = 0, lb = 0;
+        if (ci < count) { const uint64_t d = sc.big_desc[cls][ci]; first = (uint32_t)d; m = (uint32_t)(d >> 32) & 0xFFFFu; lb = (uint32_t)(d >> 48); }
+        uint32_t *slot_new = sc.slot + (size_t)lb * sc.S + t0;
+        uint32_t *cand = sc.cand + (size_t)lb * sc.S + t0;
+        // aligned groups of four records covering [first, first + m)
+        const uint32_t g0 = first >> 2, skip = first & 3u, ng = m ? (skip + m + 3u) >> 2 : 0u;
+        const uint4 *vk = reinterpret_cast<const uint4 *>(sc.big_key) + g0, *vi = reinterpret_cast<const uint4 *>(sc.big_info) + g0;
+        uint64_t mask = 0;
+        auto word_of = [](const uint4 &v, uint32_t k) -> uint32_t { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; };
+        // ---- the table the step starts from: old entries that are still there
+        {
+            uint4 nk = make_uint4(0, 0, 0, 0), ni = nk;
+            if (ng) { nk = vk[0]; ni = vi[0]; }
+            for (uint32_t g = 0; __ballot(g < ng) != 0ull; ++g) {
+                const uint4 ck = nk, cinf = ni;
+                if (g + 1 < ng) { nk = vk[g + 1]; ni = vi[g + 1]; }
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    const uint32_t idx = g * 4u + k;
+                    if (g < ng && idx >= skip && idx < skip + m) {
+                        const uint32_t inf = word_of(cinf, k);
+                        if ((inf & 1u) && !((inf >> 29) & 1u)) {
+                            const uint32_t r = (inf >> 17) & 0xFFFu;
+                            mask |= 1ull << r;
+                            s_okey[r * 64u + lane] = word_of(ck, k); s_oeid[r * 64u + lane] = inf & BI_EID;
+                        }
+                    }
+                }
+            }
+        }
+        // ---- the events in order
+        {
+            uint4 nk = make_uint4(0, 0, 0, 0), ni = nk;
+            if (ng) { nk = vk[0]; ni = vi[0]; }
+            for (uint32_t g = 0; __ballot(g < ng) != 0ull; ++g) {
+                const uint4 ck = nk, cinf = ni;
+                if (g + 1 < ng) { nk = vk[g + 1]; ni = vi[g + 1]; }
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    const uint32_t idx = g * 4u + k;
+                    if (g < ng && idx >= skip && idx < skip + m) {
+                        const uint32_t inf = word_of(cinf, k), kw = word_of(ck, k);
+                        const uint32_t r = (inf >> 17) & 0xFFFu, eid = inf & BI_EID;
+                        if (inf & 1u) {                                    // clear the recorded bucket, whoever sits there (lz77.c:70-76)
+                            if ((mask >> r) & 1ull) {
+                                const uint32_t o = s_oeid[r * 64u + lane];
+                                if (o != eid && !(o & 1u)) atomicOr(&slot_new[o >> 1], LZS_DEAD);     // a new entry removed early
+                                mask &= ~(1ull << r);
+                            }
+                        } else {
+                            const uint64_t above = ~(mask >> r);           // first fit, inside the cluster by the parking bound
+                            const uint32_t fe = r + (uint32_t)__builtin_ctzll(above);
+                            uint32_t found = LZS_EMPTY;
+                            for (uint32_t b = r; b < fe; ++b)              // find(): the first occupant of [r, fe) with this word
+                                if (s_okey[b * 64u + lane] == kw) { found = s_oeid[b * 64u + lane]; break; }
+                            const uint32_t t = eid >> 1;
+                            cand[t] = found == LZS_EMPTY ? LZS_NONE : ((found & 1u) ? base_old : base_new) + (found >> 1);
+                            if (fe < CAPM) { mask |= 1ull << fe; s_okey[fe * 64u + lane] = kw; s_oeid[fe * 64u + lane] = eid; }
+                            __hip_atomic_store(&slot_new[t], (kw & Tmask) + (fe - r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// =============================================================================================
+// stage 3: a wave per exported cluster (65 .. LZS_CAP events)
+// =============================================================================================
 template <uint32_t CAPB>
 __global__ __launch_bounds__(64)
 void k_lzs_big(LzP P, LzsScratch sc, uint32_t step, uint32_t cls)
@@ -621,13 +713,13 @@ void k_lzs_big(LzP P, LzsScratch sc, uint32_t step, uint32_t cls)
     const uint32_t lane = threadIdx.x;
     const uint32_t W = 1u << P.wbits, t0 = step * W, Tmask = (1u << P.tbits) - 1u;
     const uint32_t base_new = t0, base_old = t0 - (step ? W : 0u);
-    const uint32_t count = sc.counters[128 + 4 * step + 1 + cls];
+    const uint32_t count = sc.counters[128 + 8 * step + 1 + cls];
     // the long chains are the step's critical path: their waves go first whenever they can issue (the short-chain class
     // runs beside them with 32 waves per CU and saturates the scalar unit)
     if (CAPB > 1024u) __builtin_amdgcn_s_setprio(3);
     // clusters are handed out by a cursor (a static stride left waves with twice the average chain), FETCH at a time: one
     // returning atomic per cluster on one address cost more than the replays (91 k clusters per step: 34 -> 45 ms)
-    uint32_t *cursor = &sc.counters[384 + 2 * step + cls];
+    uint32_t *cursor = &sc.counters[768 + 2 * step + (cls & 1u)];
     constexpr uint32_t FETCH = CAPB > 1024u ? 1u : 8u;
     uint32_t have = 0, next = 0;
     for (;;) {
@@ -741,7 +833,7 @@ void lzs_view(const LzwScratch &ws, uint32_t nb, LzsScratch *sc)
     sc->flag_count = sc->counters + 64;
     sc->dbg = getenv("MI_LZ_DEBUG") ? reinterpret_cast<uint64_t *>(sc->counters + 4 * LZS_CTR_WORDS) : nullptr;
     sc->big_key = ws.t_mix; sc->big_info = ws.slot_of;                   // nb x S words each: a step has at most nb x S events
-    sc->big_desc[0] = ws.clist[0]; sc->big_desc[1] = ws.clist[1];        // nb x S / 2 + 64 each (a cluster has >= 17 events)
+    for (uint32_t q = 0; q < LZS_NCLS; ++q) sc->big_desc[q] = ws.clist[q];  // nb x S / 2 + 64 each (a cluster has >= 17 events)
 }
 
 // at most 64 steps per block (their work counters), event ids below 2^17; MI_LZW_SLICED=0 keeps lzw.hip's whole-block path (A/B, tests)
@@ -786,7 +878,7 @@ mi_status lzs_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, u
         const size_t o = (size_t)lo[g] * all.S;
         q.key += o; q.slot += o; q.cand += o; q.plist += o; q.big_key += o; q.big_info += o;
         q.meta += lo[g]; q.work += (size_t)lo[g] * LZS_MAXPARTS; q.counters += (size_t)g * LZS_CTR_WORDS;
-        q.big_desc[0] += o / 2; q.big_desc[1] += o / 2;
+        for (uint32_t c = 0; c < LZS_NCLS; ++c) q.big_desc[c] += o / 2;
         q.flag_count = all.counters + 64;                 // one count of flagged blocks for the whole batch
         const uint32_t nbg = lo[g + 1] - lo[g];
         mi_prof_scope p(ctx, "k_lzs_keys", st[g], (uint64_t)nbg * P.block);
@@ -796,15 +888,24 @@ mi_status lzs_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, u
         for (uint32_t g = 0; g < G; ++g) {
             const uint32_t nbg = lo[g + 1] - lo[g];
             const LzsScratch &q = sg[g];
+            // the lane-per-cluster kernels pay when a step has enough clusters to fill them (MI_LZS_MID=0/1 forces it: A/B)
+            const char *em = getenv("MI_LZS_MID");
+            const uint32_t use_mid = em ? (uint32_t)(em[0] == '1') : (uint32_t)((uint64_t)nbg * W >= (6u << 20));
             { mi_prof_scope p(ctx, "k_lzs_part", st[g], (uint64_t)nbg * W);
               hipLaunchKernelGGL(k_lzs_part, dim3(nbg), dim3(1024), 0, st[g], n, P, q, block0 + lo[g], k); }
             { mi_prof_scope p(ctx, "k_lzs_find", st[g], (uint64_t)nbg * W);
-              hipLaunchKernelGGL(k_lzs_find, dim3(nbg * LZS_MAXPARTS), dim3(LZS_THREADS), 0, st[g], n, P, q, block0 + lo[g], k); }
+              hipLaunchKernelGGL(k_lzs_find, dim3(nbg * LZS_MAXPARTS), dim3(LZS_THREADS), 0, st[g], n, P, q, block0 + lo[g], k, use_mid); }
             if (ax[g] != st[g]) { MI_HIP(ctx, hipEventRecord(ctx->ev_find[g], st[g])); MI_HIP(ctx, hipStreamWaitEvent(ax[g], ctx->ev_find[g], 0)); }
             { mi_prof_scope p(ctx, "k_lzs_big<4096>", ax[g], (uint64_t)nbg * W);
-              hipLaunchKernelGGL(k_lzs_big<LZS_CAP>, dim3((unsigned)ctx->num_cu * 4u), dim3(64), 0, ax[g], P, q, k, 1u); }
+              hipLaunchKernelGGL(k_lzs_big<LZS_CAP>, dim3((unsigned)ctx->num_cu * 4u), dim3(64), 0, ax[g], P, q, k, 3u); }
+            if (use_mid) {
+                { mi_prof_scope p(ctx, "k_lzs_mid<64>", ax[g], (uint64_t)nbg * W);
+                  hipLaunchKernelGGL(k_lzs_mid<64u>, dim3((unsigned)ctx->num_cu * 4u), dim3(64), 0, ax[g], P, q, k, 1u); }
+                { mi_prof_scope p(ctx, "k_lzs_mid<32>", ax[g], (uint64_t)nbg * W);
+                  hipLaunchKernelGGL(k_lzs_mid<32u>, dim3((unsigned)ctx->num_cu * 8u), dim3(64), 0, ax[g], P, q, k, 0u); }
+            }
             { mi_prof_scope p(ctx, "k_lzs_big<512>", st[g], (uint64_t)nbg * W);
-              hipLaunchKernelGGL(k_lzs_big<LZS_BIG_SMALL>, dim3((unsigned)ctx->num_cu * 32u), dim3(64), 0, st[g], P, q, k, 0u); }
+              hipLaunchKernelGGL(k_lzs_big<LZS_BIG_SMALL>, dim3((unsigned)ctx->num_cu * 32u), dim3(64), 0, st[g], P, q, k, 2u); }
             if (ax[g] != st[g]) { MI_HIP(ctx, hipEventRecord(ctx->ev_done[g], ax[g])); MI_HIP(ctx, hipStreamWaitEvent(st[g], ctx->ev_done[g], 0)); }
         }
     }
