@@ -168,3 +168,26 @@ def test_sliced_finder_dead_entries_cross_steps():
         data[at:at + 4] = word
     _check_find(data, 16, 1 << 20)
     _check_stream(data, 16, 1 << 20)
+
+
+def test_ballot_ranking_fallback_of_the_finders(monkeypatch):
+    """a context whose self-check of lane-ordered LDS atomics failed (forced: MI_LZ_NO_ARANK=1 at creation) ranks with ballots
+    in every radix scatter and sorts by cluster with two radix passes instead of the cursor placement: same results"""
+    from compression_algorithms_amd import lz
+    from compression_algorithms_amd.context import Context
+    from oracle import orc
+    monkeypatch.setenv("MI_LZ_NO_ARANK", "1")
+    ctx = Context(0)
+    try:
+        data = synth.enwik_like(300_000, seed=51).numpy()
+        p = lz.params("lz77", 16, 131072)
+        got = lz.find_all32(data, p, ctx).cpu().numpy().view(np.uint32)
+        for at in range(0, len(data), 131072):
+            assert np.array_equal(got[at:at + 131072], orc.find_all(data[at:at + 131072], 16, 22, False))
+        p = lz.params("deflate")
+        got = lz.find_all(data, p, ctx).cpu().numpy().view(np.uint16)
+        for at in range(0, len(data), 65536):
+            want = orc.find_all(data[at:at + 65536], 15, 20, True)
+            assert np.array_equal(got[at:at + 65536], np.where(want == 0xFFFFFFFF, 0xFFFF, want).astype(np.uint16))
+    finally:
+        ctx.close()
