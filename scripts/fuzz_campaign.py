@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A longer randomized parity campaign than tests/test_fuzz_gpu.py (development aid; run on an MI355X):
-    python scripts/fuzz_campaign.py [cases] [first_seed]
+    python scripts/fuzz_campaign.py [cases] [first_seed] [wide]
+"wide": every case is the lz77 flavour on blocks of 128 KiB .. 1 MiB (the time-sliced finder, its fallback on runs/pages).
 Every case: a random input family / length / block size / flavour; find() at every position against the oracle's literal
 table, the stream round trip, and for deflate the token stream against the oracle.  Prints one line per failure."""
 import os
@@ -17,6 +18,7 @@ from oracle import orc
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
 kinds = ["text", "lowent", "phrases", "runs", "pages"]
 fails = 0
 t0 = time.time()
@@ -30,6 +32,10 @@ for i in range(cases):
     if i % 10 == 9 and flavour == "lz77":
         block = [131072, 262144][int(rng.integers(0, 2))]
         n = int(rng.integers(block, 3 * block))
+    if wide:
+        flavour, wbits = "lz77", [14, 16, 16][int(rng.integers(0, 3))]
+        block = [131072, 262144, 524288, 1048576, 196608][int(rng.integers(0, 5))]
+        n = int(rng.integers(block // 2, int(2.2 * block)))
     data = F._family(kind, seed, n)
     p = lz.params(flavour, wbits, block)
     try:
