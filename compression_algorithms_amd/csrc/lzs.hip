@@ -842,7 +842,8 @@ bool lzs_applicable(const LzP &P)
     const char *e = getenv("MI_LZW_SLICED");
     if (e && e[0] == '0') return false;
     const uint32_t W = 1u << P.wbits;
-    return !P.deflate && (P.block + W - 1u) / W <= 64u;
+    // (coordinates relative to a part are sorted as 24-bit keys: a 2^24-bucket table plus the slots past its end would not fit)
+    return !P.deflate && P.tbits <= 23u && (P.block + W - 1u) / W <= 64u;
 }
 
 // Every block of the batch, step by step.  A step is a chain part -> find -> wave replays whose last link waits for the longest
