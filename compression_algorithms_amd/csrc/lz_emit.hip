@@ -477,6 +477,8 @@ void      lzw_launch_parse_emit(const uint8_t *d_in, uint64_t n, const LzP &P, c
 void      lz_launch_decode(const uint8_t *d_stream, uint64_t stream_bytes, const uint64_t *d_block_bits, const LzP &P, uint8_t *d_out,
                            uint64_t n, uint64_t nblocks, uint32_t *err, hipStream_t s);      // lz_decode.hip
 extern "C" uint64_t mi_deflate_h_bound_bytes(uint64_t n, const mi_lz_params *p);
+mi_status mi_encode_host_pipelined(mi_ctx *ctx, const mi_lz_params *p, int mode_h, const uint8_t *h_in, uint64_t n,
+                                   uint8_t *h_out, uint64_t cap_bytes, uint64_t *h_block_bits, bool *done);
 
 // mode_h = 0: the reference's token stream.  mode_h = 1: the same tokens, entropy coded per block (defh.hip); the
 // per-block records are word aligned, so the same scan / concatenate kernels place them.
@@ -616,6 +618,11 @@ extern "C" mi_status mi_lz_encode(mi_ctx *ctx, const mi_lz_params *p, const uint
     const uint64_t nblocks = p->block ? (n + p->block - 1) / p->block : 0;
     const uint64_t bound = mi_lz_bound_bytes(n, p);
     if (cap_bytes < bound) return MI_ERR_CAPACITY;
+    if (lz_check_params(p) == MI_OK && p->deflate) {       // byte tokens: chunks overlap their transfers with the encoder (host_api.hip)
+        bool done = false;
+        const mi_status ps = mi_encode_host_pipelined(ctx, p, 0, h_in, n, h_out, cap_bytes, h_block_bits, &done);
+        if (ps || done) return ps;
+    }
     uint8_t *d_in = nullptr, *d_out = nullptr; uint64_t *d_bits = nullptr;
     mi_status st = MI_OK;
     hipStream_t s = mi_host_stream(ctx);

@@ -350,3 +350,34 @@ def test_lz77_one_large_block_is_the_reference_stream(golden_dir, monkeypatch):
         out = L.lz77_decompress(bs, len(sample), C.byref(dsz))
         assert np.array_equal(np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(len(sample),)), sample)
     L.mi_lz77_set_window_bits(14)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode_h", [False, True])
+@pytest.mark.parametrize("chunk_blocks,n", [(3, 1_000_001), (1, 200_000), (4, 4 * 65536 * 3), (7, 65536 * 7 + 1)])
+def test_host_buffer_encoders_in_chunks(mode_h, chunk_blocks, n, monkeypatch):
+    """mi_lz_encode / mi_deflate_h_encode on host buffers larger than a chunk: transfers overlap the encoder chunk by chunk
+    (host_api.hip); stream and block table must equal the one-shot device path bit for bit, whatever the chunk size"""
+    import ctypes as C
+    from compression_algorithms_amd import lz, synth
+    from compression_algorithms_amd.context import default_context
+    ctx = default_context()
+    data = synth.enwik_like(n, seed=91).numpy()
+    p = lz.params("deflate")
+    ref = lz.compress_h(data, p) if mode_h else lz.compress(data, p)
+    ref_bits = ref.block_bits.cpu().numpy().astype(np.uint64)
+    ref_bytes = np.frombuffer(ref.tobytes(), dtype=np.uint8)
+    monkeypatch.setenv("MI_HOST_CHUNK_BLOCKS", str(chunk_blocks))
+    ctx.L.mi_deflate_h_bound_bytes.restype = C.c_uint64
+    cap = (int(ctx.L.mi_deflate_h_bound_bytes(C.c_uint64(n), C.byref(p))) if mode_h else lz.bound_bytes(n, p)) + 64
+    out = np.zeros(cap, np.uint8)
+    bits = np.zeros(len(ref_bits), np.uint64)
+    fn = ctx.L.mi_deflate_h_encode if mode_h else ctx.L.mi_lz_encode
+    rc = fn(ctx.h, C.byref(p), C.c_void_p(data.ctypes.data), C.c_uint64(n), C.c_void_p(out.ctypes.data), C.c_uint64(cap), C.c_void_p(bits.ctypes.data))
+    assert rc == 0
+    assert np.array_equal(bits, ref_bits)
+    assert np.array_equal(out[: len(ref_bytes)], ref_bytes)
+    # too small an output buffer: refused, nothing written past it
+    small = np.zeros(len(ref_bytes) // 2, np.uint8)
+    rc = fn(ctx.h, C.byref(p), C.c_void_p(data.ctypes.data), C.c_uint64(n), C.c_void_p(small.ctypes.data), C.c_uint64(len(small)), C.c_void_p(bits.ctypes.data))
+    assert rc == 4                                                      # MI_ERR_CAPACITY
