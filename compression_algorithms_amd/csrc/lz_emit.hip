@@ -270,23 +270,59 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
         // token passes by anyway, and handed to k_defh_encode at the end of the block's slot: it no longer reads the
         // token records twice.
         uint32_t *trec = trec_all + (size_t)lb * LZ_MAX_BLOCK;
-        for (uint32_t i = tid; i < 288u; i += 1024u) stage[i] = 0;
-        __syncthreads();
-        for (uint32_t t = tid; t < ntok; t += 1024u) {
-            const uint32_t c = chunk_of(t), o = select_bit(s_tok[c], t - tb[c]), p = c * 64u + o;
-            uint32_t rec, sym;
-            if ((s_mat[c] >> o) & 1ull) {
-                const uint32_t mbefore = mb[c] + (uint32_t)__popcll(s_mat[c] & ((1ull << o) - 1ull));
-                const uint32_t d = lists ? (uint32_t)md[mbefore] : p - cand[p];
-                rec = 0x80000000u | ((uint32_t)s_L[p] << 16) | d;
-                sym = 256u + ((uint32_t)__builtin_clz(d & 0xFFFFu) - 16u);
-            } else { rec = src[p]; sym = rec; }
-            atomicAdd(&stage[sym], 1u);
-            trec[t] = rec;
+        // eight copies of the tally (a pair of waves each): the frequent symbols of a text serialise on one LDS address
+        constexpr uint32_t NH = 8u, HS = 288u;
+        static_assert(NH * HS <= TPR * 1024u, "the tallies live in the staging window");
+        for (uint32_t i = tid; i < NH * HS; i += 1024u) stage[i] = 0;
+        // a literal token's byte goes where its length (0) was: the chunk's 64 bytes come in as four coalesced 16-byte loads
+        // instead of one dependent byte load per literal inside the walk
+        {
+            const uint64_t lit = my_tok & ~my_mat;
+            const uint32_t p0 = (uint32_t)tid * 64u;
+            if (lit) {
+                const bool v16 = (((uintptr_t)src) & 15u) == 0 && p0 + 64u <= n;
+#pragma unroll
+                for (uint32_t k4 = 0; k4 < 4u; ++k4) {
+                    uint32_t w[4] = {0, 0, 0, 0};
+                    if (v16) { const uint4 v = *reinterpret_cast<const uint4 *>(src + p0 + 16u * k4); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+                    else { for (uint32_t j = 0; j < 16u; ++j) if (p0 + 16u * k4 + j < n) w[j >> 2] |= (uint32_t)src[p0 + 16u * k4 + j] << (8u * (j & 3u)); }
+#pragma unroll
+                    for (uint32_t j = 0; j < 16u; ++j)
+                        if ((lit >> (16u * k4 + j)) & 1ull) s_L[p0 + 16u * k4 + j] = (uint8_t)(w[j >> 2] >> (8u * (j & 3u)));
+                }
+            }
         }
         __syncthreads();
-        for (uint32_t i = tid; i < 288u; i += 1024u) slot[LZ_DEFH_HIST_AT + i] = stage[i];
+        // POSITION-driven: thread c walks the token starts of its own chunk (it knows how many tokens and matches lie before
+        // it) — no token -> chunk search, no bit selection, nothing but LDS on the walk
+        {
+            uint64_t tk = my_tok;
+            uint32_t t = tbase, mi = mbase;
+            const uint32_t p0 = (uint32_t)tid * 64u;
+            uint32_t *hist = stage + ((uint32_t)tid >> 7) * HS;
+            while (tk) {
+                const uint32_t o = (uint32_t)__builtin_ctzll(tk), p = p0 + o;
+                tk &= tk - 1ull;
+                uint32_t rec = s_L[p], sym = rec;                         // a literal's byte, or a match's length
+                if ((my_mat >> o) & 1ull) {
+                    const uint32_t d = lists ? (uint32_t)md[mi] : p - cand[p];
+                    ++mi;
+                    rec = 0x80000000u | (rec << 16) | d;
+                    sym = 256u + ((uint32_t)__builtin_clz(d & 0xFFFFu) - 16u);
+                }
+                atomicAdd(&hist[sym], 1u);
+                trec[t++] = rec;
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < 288u; i += 1024u) {
+            uint32_t v = 0;
+            for (uint32_t h = 0; h < NH; ++h) v += stage[h * HS + i];
+            slot[LZ_DEFH_HIST_AT + i] = v;
+        }
         if (tid == 0) sc.block_bits[lb] = ntok;
+        PE_TICK(6);
+        if (s2.dbg && tid == 0) atomicAdd((unsigned long long *)&s2.dbg[31], 1ull);
         return;
     }
     // a token's fields; a literal's byte comes from global memory (the block's LDS copy is long overwritten), so the

@@ -17,7 +17,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 268435456
 ctx = Context(0)
 x = synth.enwik_like(n, seed=12345, device="cuda")
 p = lz.params("deflate")
-lz.compress(x, p, ctx)
+(lz.compress_h if os.environ.get("MI_PHASE_MODE_H") else lz.compress)(x, p, ctx)
 torch.cuda.synchronize()
 out = (C.c_uint64 * 32)()
 ctx.L.mi_lz_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
