@@ -16,11 +16,6 @@
 #include "lz2.h"
 #include <stdlib.h>
 
-__device__ __forceinline__ uint32_t select_bit(uint64_t m, uint32_t r)   // index of the r-th set bit
-{
-    for (uint32_t k = 0; k < r; ++k) m &= m - 1;
-    return (uint32_t)__builtin_ctzll(m);
-}
 
 __global__ __launch_bounds__(1024)
 void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, LzScratch sc, Lz2Scratch s2, int use_v2,
@@ -34,7 +29,6 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     __shared__ uint8_t  s_sexit[32][32];
     __shared__ uint8_t  s_sentry[32];
     __shared__ uint32_t s_scan[18];
-    __shared__ uint64_t s_q0, s_q1;
 
     const int tid = threadIdx.x;
     const uint32_t lb = blockIdx.x;
@@ -240,14 +234,9 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     uint32_t *stage = mb + 1026;                                   // [TPR * 1024 + 16]
     constexpr uint32_t TPR = 4;                                   // tokens per thread and emit round
     uint16_t *md = reinterpret_cast<uint16_t *>(stage + TPR * 1024 + 16);   // [<= 16384] distance of the k-th match token
-    uint16_t *tch = md + 16384;                                    // [<= 1024] chunk that holds token 64 * k
     tb[tid] = tbase; mb[tid] = mbase;
     if (tid == 0) { tb[1024] = ntok; mb[1024] = nmat; }
-    // token -> chunk without a binary search: every 64th token's chunk is tabulated (a chunk holds <= 64 tokens, so it
-    // covers at most one multiple of 64), the rest is a walk of a few chunks from there
-    for (uint32_t mlt = (tbase + 63u) & ~63u; mlt < tbase + (uint32_t)__popcll(my_tok); mlt += 64u) tch[mlt >> 6] = (uint16_t)tid;
     __syncthreads();
-    auto chunk_of = [&](uint32_t t) -> uint32_t { uint32_t c = tch[t >> 6]; while (tb[c + 1] <= t) ++c; return c; };
     if (lists) {
         auto put = [&](uint32_t p, uint32_t c) {
             const uint32_t ch = p >> 6, o = p & 63u;
@@ -325,67 +314,63 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
         if (s2.dbg && tid == 0) atomicAdd((unsigned long long *)&s2.dbg[31], 1ull);
         return;
     }
-    // a token's fields; a literal's byte comes from global memory (the block's LDS copy is long overwritten), so the
-    // lookups and byte loads of round r+1 are issued before round r goes through its barriers
-    struct Tok { uint64_t q; uint32_t v, nbits, byte; bool valid, lit; };
-    auto look = [&](uint32_t t, Tok &k) {
-        k.q = 0; k.v = 0; k.nbits = 0; k.byte = 0; k.lit = false;
-        k.valid = t < ntok;
-        if (k.valid) {
-            const uint32_t c = chunk_of(t), o = select_bit(s_tok[c], t - tb[c]);   // last chunk with tb[c] <= t
-            const uint32_t p = c * 64u + o;
-            const uint64_t below = (1ull << o) - 1ull;
-            const uint32_t mbefore = mb[c] + (uint32_t)__popcll(s_mat[c] & below);
-            k.q = (uint64_t)(t - mbefore) * LB + (uint64_t)mbefore * MB;
-            if ((s_mat[c] >> o) & 1ull) {
-                const uint32_t d = lists ? (uint32_t)md[mbefore] : p - cand[p], l = s_L[p];
-                k.v = P.deflate ? (1u | (d << 8) | (l << 24)) : (1u | (d << 1) | (l << (1u + P.wbits)));
-                k.nbits = MB;
-            } else {
-                k.lit = true; k.byte = src[p];
-                k.nbits = LB;
+    // The packed formats, POSITION-driven like the records above: thread c walks the token starts of its own chunk; the bit
+    // position of its first token follows from the token and match counts before it.  The output goes through an LDS window
+    // of 4096 words per round (tokens are OR-ed in, LSB first: bit i of the stream is bit i%8 of byte i/8, lz77.c:144-174);
+    // bit positions grow with the chunk number, so a thread takes part in the one or two rounds its chunk's range meets and
+    // resumes where it stopped.  A literal's byte is parked where its length (0) was: four coalesced 16-byte loads per chunk
+    // instead of a dependent byte load per literal.  (The token-driven loop this replaces — token -> chunk search, r-th set
+    // bit, scattered byte loads, four tokens per thread and round — cost 117 k cycles per block.)
+    {
+        const uint64_t lit = my_tok & ~my_mat;
+        const uint32_t p0 = (uint32_t)tid * 64u;
+        if (lit) {
+            const bool v16 = (((uintptr_t)src) & 15u) == 0 && p0 + 64u <= n;
+#pragma unroll
+            for (uint32_t k4 = 0; k4 < 4u; ++k4) {
+                uint32_t w[4] = {0, 0, 0, 0};
+                if (v16) { const uint4 v = *reinterpret_cast<const uint4 *>(src + p0 + 16u * k4); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+                else { for (uint32_t j = 0; j < 16u; ++j) if (p0 + 16u * k4 + j < n) w[j >> 2] |= (uint32_t)src[p0 + 16u * k4 + j] << (8u * (j & 3u)); }
+#pragma unroll
+                for (uint32_t j = 0; j < 16u; ++j)
+                    if ((lit >> (16u * k4 + j)) & 1ull) s_L[p0 + 16u * k4 + j] = (uint8_t)(w[j >> 2] >> (8u * (j & 3u)));
             }
         }
-    };
-    Tok cur[TPR], nxt[TPR];
-#pragma unroll
-    for (uint32_t u = 0; u < TPR; ++u) look(u * 1024u + (uint32_t)tid, cur[u]);
-    for (uint32_t t0 = 0; t0 < ntok; t0 += TPR * 1024u) {
-#pragma unroll
-        for (uint32_t u = 0; u < TPR; ++u) look(t0 + (TPR + u) * 1024u + (uint32_t)tid, nxt[u]);
-        uint64_t q[TPR]; uint32_t v[TPR], nbits[TPR];
-        bool valid[TPR];
-#pragma unroll
-        for (uint32_t u = 0; u < TPR; ++u) {
-            const uint32_t t = t0 + u * 1024u + tid;
-            valid[u] = cur[u].valid; q[u] = cur[u].q; nbits[u] = cur[u].nbits;
-            v[u] = cur[u].lit ? (P.deflate ? (cur[u].byte << 8) : (cur[u].byte << 1)) : cur[u].v;
-            if (valid[u]) {
-                if (u == 0 && tid == 0) s_q0 = q[0];
-                if (t == ntok - 1 || (u == TPR - 1 && tid == 1023)) s_q1 = q[u] + nbits[u];
+    }
+    {
+        constexpr uint32_t WW = TPR * 1024u;                              // window words per round (stage holds WW + 16)
+        const uint64_t total = (uint64_t)(ntok - nmat) * LB + (uint64_t)nmat * MB;
+        uint64_t tk = my_tok;
+        uint64_t q = (uint64_t)(tbase - mbase) * LB + (uint64_t)mbase * MB;   // bit position of this chunk's first token
+        uint32_t mi = mbase;
+        const uint32_t p0 = (uint32_t)tid * 64u;
+        for (uint64_t w0 = 0; (w0 << 5) < total; w0 += WW) {
+            for (uint32_t i = tid; i < WW + 2u; i += 1024u) stage[i] = (i == 0) ? carry : 0u;
+            __syncthreads();
+            const uint64_t hi = (w0 + WW) << 5;
+            while (tk && q < hi) {
+                const uint32_t o = (uint32_t)__builtin_ctzll(tk), p = p0 + o;
+                tk &= tk - 1ull;
+                uint32_t v = s_L[p], nbits = LB;                           // a literal's byte, or a match's length
+                if ((my_mat >> o) & 1ull) {
+                    const uint32_t d = lists ? (uint32_t)md[mi] : p - cand[p];
+                    ++mi;
+                    v = P.deflate ? (1u | (d << 8) | (v << 24)) : (1u | (d << 1) | (v << (1u + P.wbits)));
+                    nbits = MB;
+                } else v = P.deflate ? (v << 8) : (v << 1);
+                const uint32_t rel = (uint32_t)(q - (w0 << 5)), wi = rel >> 5, sh = rel & 31u;
+                atomicOr(&stage[wi], v << sh);
+                if (sh + nbits > 32u) atomicOr(&stage[wi + 1], v >> (32u - sh));
+                q += nbits;
             }
+            __syncthreads();
+            // complete words of this window: all of them, or up to the stream's last complete word
+            const uint64_t endw = (total >> 5) < w0 + WW ? (total >> 5) : w0 + WW;
+            const uint32_t ncomplete = (uint32_t)(endw - w0);
+            for (uint32_t i = tid; i < ncomplete; i += 1024u) slot[w0 + i] = stage[i];
+            carry = stage[ncomplete];
+            __syncthreads();
         }
-        __syncthreads();
-        const uint64_t q0 = s_q0, q1 = s_q1;
-        const uint64_t w0 = q0 >> 5;
-        const uint32_t nwords = (uint32_t)(((q1 + 31) >> 5) - w0);
-        for (uint32_t i = tid; i < nwords + 1; i += 1024u) stage[i] = (i == 0) ? carry : 0u;
-        __syncthreads();
-#pragma unroll
-        for (uint32_t u = 0; u < TPR; ++u) {
-            if (valid[u]) {
-                const uint32_t rel = (uint32_t)(q[u] - (w0 << 5)), wi = rel >> 5, sh = rel & 31u;
-                atomicOr(&stage[wi], v[u] << sh);
-                if (sh + nbits[u] > 32u) atomicOr(&stage[wi + 1], v[u] >> (32u - sh));
-            }
-        }
-        __syncthreads();
-        const uint32_t ncomplete = (uint32_t)((q1 >> 5) - w0);
-        for (uint32_t i = tid; i < ncomplete; i += 1024u) slot[w0 + i] = stage[i];
-        carry = stage[ncomplete];
-        __syncthreads();
-#pragma unroll
-        for (uint32_t u = 0; u < TPR; ++u) cur[u] = nxt[u];
     }
     PE_TICK(6);
     if (s2.dbg && tid == 0) atomicAdd((unsigned long long *)&s2.dbg[31], 1ull);
