@@ -67,7 +67,9 @@ struct Lz2Scratch {
     uint16_t     *cand;         // [nb][65536] find() result aligned with plist (own position = pending: see bigcand)
     Lz2BlockMeta *meta;         // [nb]
     uint32_t     *fallback_count, *fallback_list;    // blocks the first pipeline has to do
-    uint32_t     *work_count, *work;                 // parts of the batch, appended by the partition: block | part << 16
+    uint32_t     *work_count;
+    uint64_t     *work;                              // parts of the batch, appended by the partition: block | part << 16 | entries << 24 | list start << 40
+                                                     // (k_lz2_find starts its list loads from the item alone: one dependent round trip less)
     uint16_t     *bigpos, *bigrs, *bigpid, *bigcand; // [nb][LZ2_BIG_STRIDE] entries of exported clusters, (cluster, time) order
     Lz2BigDesc   *desc[LZ2_NCLASS];                  // per class: [nb * capacity of the class]
     uint32_t     *big_count;                         // [LZ2_NCLASS]

@@ -151,16 +151,17 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     const uint32_t nwork = *sc.work_count;
     const uint32_t cpx = (nwork + 7u) >> 3, item_idx = (blockIdx.x & 7u) * cpx + (blockIdx.x >> 3);
     if ((blockIdx.x >> 3) >= cpx || item_idx >= nwork) return;
-    const uint32_t item = sc.work[item_idx];
-    const uint32_t lb = item & 0xFFFFu, part = item >> 16;
+    const uint64_t item = sc.work[item_idx];
+    const uint32_t lb = (uint32_t)item & 0xFFFFu, part = (uint32_t)(item >> 16) & 0xFFu;
     Lz2BlockMeta *mt = sc.meta + lb;
     long long tk = clock64();
 #define LZ2_TICK(k) do { if (sc.dbg && tid == 0) { long long t2 = clock64(); atomicAdd((unsigned long long *)&sc.dbg[k], (unsigned long long)(t2 - tk)); tk = t2; } \
                          if ((k) < 7 && sc.stop_phase == (uint32_t)(k) + 1u) return; } while (0)     /* stop_phase: per-phase counter runs (scripts/phase_pmc.sh) */
-    if (mt->fallback || part >= mt->nparts) return;
-    const uint32_t m = mt->part_count[part];
+    // (only parts of blocks that did not fall back are listed; the list position and length ride in the item, so the list
+    //  loads below do not wait for the block's meta record)
+    const uint32_t m = (uint32_t)(item >> 24) & 0xFFFFu;
     if (m == 0) return;
-    const uint32_t pstart = mt->part_start[part], base = mt->base;
+    const uint32_t pstart = (uint32_t)(item >> 40), base = mt->base;
     const uint64_t off = (block0 + lb) * (uint64_t)P.block;
     const uint32_t nblk = mt->n;
     const uint8_t *src = in + off;
@@ -736,7 +737,7 @@ static uint32_t lz2_class_cap(uint32_t c)
 
 size_t lz2_scratch_bytes(uint32_t nb)
 {
-    return (size_t)nb * (LZ_MAX_BLOCK * 2 * 2 + LZ2_BIG_STRIDE * 2 * 4 + sizeof(Lz2BlockMeta) + 4 + 4 * LZ2_MAXPARTS + 3 * LZ2_DESC_SMALL * sizeof(Lz2BigDesc)) + 16 * 256 + 4096;
+    return (size_t)nb * (LZ_MAX_BLOCK * 2 * 2 + LZ2_BIG_STRIDE * 2 * 4 + sizeof(Lz2BlockMeta) + 4 + 8 * LZ2_MAXPARTS + 3 * LZ2_DESC_SMALL * sizeof(Lz2BigDesc)) + 16 * 256 + 4096;
 }
 
 void lz2_carve(mi_carver &cv, uint32_t nb, Lz2Scratch *sc)
@@ -753,7 +754,7 @@ void lz2_carve(mi_carver &cv, uint32_t nb, Lz2Scratch *sc)
     for (uint32_t c = 0; c < LZ2_NCLASS; ++c) sc->desc[c] = cv.take<Lz2BigDesc>((size_t)nb * lz2_class_cap(c));
     sc->big_count = sc->fallback_count + 16;
     sc->work_count = sc->fallback_count + 32;            // zeroed with the other counters by stage 1
-    sc->work = cv.take<uint32_t>((size_t)nb * LZ2_MAXPARTS);
+    sc->work = cv.take<uint64_t>((size_t)nb * LZ2_MAXPARTS);
     sc->dbg = getenv("MI_LZ_DEBUG") ? cv.take<uint64_t>(32) : nullptr;
     sc->wave_min = LZ2_WAVE;
     sc->stop_phase = getenv("MI_LZ_STOP_PHASE") ? (uint32_t)atoi(getenv("MI_LZ_STOP_PHASE")) : 0u;

@@ -195,7 +195,9 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
         __shared__ uint32_t s_wbase;
         if (tid == 0) s_wbase = atomicAdd(sc.work_count, K);
         __syncthreads();
-        if (tid < (int)K) sc.work[s_wbase + tid] = lb | ((uint32_t)tid << 16);
+        if (tid < (int)K) {
+            sc.work[s_wbase + tid] = (uint64_t)lb | ((uint64_t)tid << 16) | ((uint64_t)mt->part_count[tid] << 24) | ((uint64_t)mt->part_start[tid] << 40);
+        }
     }
 
     // ---- positions -> part lists, time order kept: ONE stable radix pass over the whole block by part number.  The part of
