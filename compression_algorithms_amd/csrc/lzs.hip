@@ -64,7 +64,7 @@ struct LzsScratch {
     uint32_t *cand;       // [nb][S] find() by position (LZS_NONE = none)
     uint32_t *plist;      // [nb][S] event ids of the current step, grouped by part, event order inside a part
     LzsMeta  *meta;       // [nb]
-    uint32_t *work;       // [nb * LZS_MAXPARTS] parts of the current step: block | part << 16
+    uint64_t *work;       // [nb * LZS_MAXPARTS] parts of the current step: block | part << 16 | events << 24 | list start << 40
     uint32_t *counters;   // [0..63] parts listed in step k, [64] flagged blocks, [128 + 8 k ..] step k: exported events, clusters of class 0..3
     uint32_t *big_key, *big_info;   // [nb * S] events of the exported clusters of the current step, (cluster, event) order
     uint64_t *big_desc[LZS_NCLS];   // per class: first event | count << 32 | block << 48
@@ -235,7 +235,7 @@ void k_lzs_part(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     }
     if (tid == 0) { mt->nparts = K; s_wbase = atomicAdd(&sc.counters[step], K); }
     __syncthreads();
-    if (tid < (int)K) sc.work[s_wbase + tid] = lb | ((uint32_t)tid << 16);
+    if (tid < (int)K) sc.work[s_wbase + tid] = (uint64_t)lb | ((uint64_t)tid << 16) | ((uint64_t)mt->part_count[tid] << 24) | ((uint64_t)mt->part_start[tid] << 40);
 
     // ---- event ids -> part lists, event order kept: the part of every id (a binary search over <= 63 thresholds), then ONE
     //      stable radix pass by part number; ids that are not events of this step go to a last bin that is not stored
@@ -323,12 +323,12 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     // XCD-aware order (lz2_find.hip): every XCD takes a contiguous eighth of the list, a block's parts share an L2
     const uint32_t cpx = (nwork + 7u) >> 3, item_idx = (blockIdx.x & 7u) * cpx + (blockIdx.x >> 3);
     if ((blockIdx.x >> 3) >= cpx || item_idx >= nwork) return;
-    const uint32_t item = sc.work[item_idx];
-    const uint32_t lb = item & 0xFFFFu, part = item >> 16;
+    const uint64_t item = sc.work[item_idx];             // list position and length ride in the item: the list loads do not wait for the meta record
+    const uint32_t lb = (uint32_t)item & 0xFFFFu, part = (uint32_t)(item >> 16) & 0xFFu;
     const LzsMeta *mt = sc.meta + lb;
-    const uint32_t m = mt->part_count[part];
+    const uint32_t m = (uint32_t)(item >> 24) & 0xFFFFu;
     if (m == 0) return;
-    const uint32_t pstart = mt->part_start[part], plo = mt->part_lo[part];
+    const uint32_t pstart = (uint32_t)(item >> 40), plo = mt->part_lo[part];
     const uint32_t phi = (part + 1 < mt->nparts) ? mt->part_lo[part + 1] : 0xFFFFFFFFu;
     const uint32_t W = 1u << P.wbits, t0 = step * W, Tmask = (1u << P.tbits) - 1u;
     (void)n_total; (void)block0;
@@ -828,8 +828,8 @@ void lzs_view(const LzwScratch &ws, uint32_t nb, LzsScratch *sc)
     // the sliced finder lives in the arrays of lzw.hip's workspace (which it never uses at the same time)
     sc->key = ws.gid; sc->slot = ws.rd; sc->cand = ws.cand; sc->plist = ws.t_pos; sc->S = ws.S;
     sc->meta = reinterpret_cast<LzsMeta *>(ws.eA);                       // nb x 784 B of nb x S x 8 B
-    sc->work = reinterpret_cast<uint32_t *>(ws.eB);                      // nb x 64 words
-    sc->counters = sc->work + (size_t)nb * LZS_MAXPARTS;                 // four groups x LZS_CTR_WORDS ([64] of the first: flagged blocks)
+    sc->work = reinterpret_cast<uint64_t *>(ws.eB);                      // nb x 64 items
+    sc->counters = reinterpret_cast<uint32_t *>(sc->work + (size_t)nb * LZS_MAXPARTS);                 // four groups x LZS_CTR_WORDS ([64] of the first: flagged blocks)
     sc->flag_count = sc->counters + 64;
     sc->dbg = getenv("MI_LZ_DEBUG") ? reinterpret_cast<uint64_t *>(sc->counters + 4 * LZS_CTR_WORDS) : nullptr;
     sc->big_key = ws.t_mix; sc->big_info = ws.slot_of;                   // nb x S words each: a step has at most nb x S events
