@@ -368,7 +368,8 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     LZ2_TICK(2);
     // ---- sort time indices by cluster number (they start in time order): identity -> j0 -> j1
     //      (cluster numbers are < LZ2_CAP <= 4096: two 6-bit passes, fewer ballots and a shorter offset scan than 8 + 8)
-    static_assert(LZ2_CAP <= 4096, "cluster numbers must fit 12 bits");
+    static_assert(LZ2_CAP <= 8192, "cluster numbers must fit 13 bits");
+    constexpr int GB2 = LZ2_CAP > 4096 ? 7 : 6;          // bits of the second cluster-number pass
     static_assert(2 * LZ2_CAP <= sizeof(uint32_t) * (LZ2_NWAVES + 1) * 256, "the cluster cursors live in the radix counters");
     if (arank) {
         // ONE pass, no counting: the sweep left every cluster's first replay index as a 16-bit cursor; an entry's place is its
@@ -396,7 +397,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     } else {
         radix_pass<LZ2_NWAVES, 6, uint32_t>(m, s_cnt, [&](uint32_t i) { return i; },
             [&](uint32_t e) { return (uint32_t)s_g[e] & 63u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; }, arank);
-        radix_pass<LZ2_NWAVES, 6, uint32_t>(m, s_cnt, [&](uint32_t i) { return (uint32_t)s_j0[i]; },
+        radix_pass<LZ2_NWAVES, GB2, uint32_t>(m, s_cnt, [&](uint32_t i) { return (uint32_t)s_j0[i]; },
             [&](uint32_t e) { return (uint32_t)s_g[e] >> 6; }, [&](uint32_t d, uint32_t e) { s_j1[d] = (uint16_t)e; }, arank);
     }
 
