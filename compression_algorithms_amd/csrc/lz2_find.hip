@@ -327,6 +327,9 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
                 prev_h = h;
                 s_g[j] = (uint16_t)cur_gid;
                 s_r[j] = (uint16_t)(cur_gs + (uint32_t)(h - cur_base));
+                // a cluster whose entries do not all share one home needs its (home, time) order re-sorted by time below;
+                // the others (nearly all) are in time order as they stand.  s_bm is free until the replay.
+                if (arank && h != cur_base) atomicOr(&s_bm[cur_gid >> 5], 1u << (cur_gid & 31u));
                 // the word's identity is the POSITION of its first occurrence in the block (the home order is stable in
                 // time).  While nothing of a cluster has been evicted that position is also what find() returns: the first
                 // copy sits at the lowest slot of the word and every slot between the home and it stays occupied.
@@ -378,12 +381,27 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
         // property radix_pass uses), so wave w takes the clusters whose cursor PAIR (two 16-bit cursors share a dword, the
         // unit of an LDS atomic) has number = w modulo the wave count, and every wave walks the whole time-ordered list.
         // Replaces two 6-bit radix passes (count, scan, scatter each): 20 k -> ~8 k cycles per part.
+        // Only clusters with MORE THAN ONE HOME need it (a cluster of one home is in time order already: the home sort is stable);
+        // their entries are compacted first, time order kept, so the eight waves walk a short list instead of the whole part.
         uint32_t *cur32 = &s_cnt[0][0];
         const uint32_t wv = (uint32_t)tid >> 6, ln = (uint32_t)tid & 63u;
-        for (uint32_t j0 = 0; j0 < m; j0 += 256u) {
-            uint32_t gg[4], old[4];
+        auto multi = [&](uint32_t g) -> bool { return (s_bm[g >> 5] >> (g & 31u)) & 1u; };
+        for (uint32_t k = k0; k < k1; ++k) { const uint32_t j = s_j0[k]; if (!multi(s_g[j])) s_j1[k] = (uint16_t)j; }
+        __syncthreads();                                     // (s_j0 is dead now: it takes the compacted list)
+        uint32_t nm;
+        {
+            uint32_t mine[CH], cnt = 0;
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) { const uint32_t j = j0 + 64u * u + ln; gg[u] = j < m ? (uint32_t)s_g[j] : 0xFFFFFFFFu; }
+            for (uint32_t c = 0; c < CH; ++c) { const uint32_t j = k0 + c; mine[c] = (j < m && multi(s_g[j])) ? 1u : 0u; cnt += mine[c]; }
+            uint32_t at = block_exclusive_scan<uint32_t>(cnt, OpAddU32(), 0u, reinterpret_cast<uint32_t *>(s_i32), &nm);
+#pragma unroll
+            for (uint32_t c = 0; c < CH; ++c) if (mine[c]) s_j0[at++] = (uint16_t)(k0 + c);
+        }
+        __syncthreads();
+        for (uint32_t x0 = 0; x0 < nm; x0 += 256u) {
+            uint32_t jj[4], gg[4], old[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) { const uint32_t x = x0 + 64u * u + ln; jj[u] = x < nm ? (uint32_t)s_j0[x] : 0u; gg[u] = x < nm ? (uint32_t)s_g[jj[u]] : 0xFFFFFFFFu; }
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u) {
                 old[u] = 0;
@@ -391,9 +409,10 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
             }
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u)
-                if (gg[u] != 0xFFFFFFFFu && ((gg[u] >> 1) % (uint32_t)LZ2_NWAVES) == wv) s_j1[(old[u] >> (16u * (gg[u] & 1u))) & 0xFFFFu] = (uint16_t)(j0 + 64u * u + ln);
+                if (gg[u] != 0xFFFFFFFFu && ((gg[u] >> 1) % (uint32_t)LZ2_NWAVES) == wv) s_j1[(old[u] >> (16u * (gg[u] & 1u))) & 0xFFFFu] = (uint16_t)jj[u];
         }
         __syncthreads();
+        for (uint32_t i = tid; i < LZ2_CAP / 32 + 2; i += LZ2_THREADS) s_bm[i] = 0;     // back to the replay's empty bitmap (barriers follow)
     } else {
         radix_pass<LZ2_NWAVES, 6, uint32_t>(m, s_cnt, [&](uint32_t i) { return i; },
             [&](uint32_t e) { return (uint32_t)s_g[e] & 63u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; }, arank);
