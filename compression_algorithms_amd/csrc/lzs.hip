@@ -22,8 +22,8 @@
 //                go out by position
 // Zero-filled ring: in step 0 one pseudo event clears bucket 0 after insertion W-1; an entry that a
 // clear removes early is carried into the next step as DEAD (it occupies nothing, its own clear still happens).
-// A step with a cluster above 4096 events (a run of one byte value) or more than 63 parts flags the block; the batch is
-// then redone by lzw.hip (whole-block clusters, any size).
+// A step with a cluster above 4096 events (a run of one byte value) or more than 63 parts flags the block; flagged blocks
+// are then redone by lzw.hip (whole-block clusters, any size): one by one when they are few, the whole batch otherwise.
 #include "lz_common.h"
 #include <stdlib.h>
 #include <stdio.h>
@@ -69,6 +69,8 @@ struct LzsScratch {
     uint32_t *big_key, *big_info;   // [nb * S] events of the exported clusters of the current step, (cluster, event) order
     uint64_t *big_desc[LZS_NCLS];   // per class: first event | count << 32 | block << 48
     uint32_t *flag_count; // flagged blocks of the whole batch
+    uint32_t *flag_list;  // their indices in the batch
+    uint32_t  lb0;        // batch index of this group's first block
     uint32_t  S;
     uint64_t *dbg;        // phase cycle counters of k_lzs_find (MI_LZ_DEBUG=1), else NULL
 };
@@ -230,7 +232,7 @@ void k_lzs_part(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     }
     __syncthreads();
     if (s_flag) {
-        if (tid == 0) { mt->fallback = 1; mt->nparts = 0; atomicAdd(sc.flag_count, 1u); }
+        if (tid == 0) { mt->fallback = 1; mt->nparts = 0; sc.flag_list[atomicAdd(sc.flag_count, 1u)] = sc.lb0 + lb; }
         return;
     }
     if (tid == 0) { mt->nparts = K; s_wbase = atomicAdd(&sc.counters[step], K); }
@@ -831,6 +833,8 @@ void lzs_view(const LzwScratch &ws, uint32_t nb, LzsScratch *sc)
     sc->work = reinterpret_cast<uint64_t *>(ws.eB);                      // nb x 64 items
     sc->counters = reinterpret_cast<uint32_t *>(sc->work + (size_t)nb * LZS_MAXPARTS);                 // four groups x LZS_CTR_WORDS ([64] of the first: flagged blocks)
     sc->flag_count = sc->counters + 64;
+    sc->flag_list = sc->counters + 4 * LZS_CTR_WORDS + 64;               // behind the debug counters: one word per block
+    sc->lb0 = 0;
     sc->dbg = getenv("MI_LZ_DEBUG") ? reinterpret_cast<uint64_t *>(sc->counters + 4 * LZS_CTR_WORDS) : nullptr;
     sc->big_key = ws.t_mix; sc->big_info = ws.slot_of;                   // nb x S words each: a step has at most nb x S events
     for (uint32_t q = 0; q < LZS_NCLS; ++q) sc->big_desc[q] = ws.clist[q];  // nb x S / 2 + 64 each (a cluster has >= 17 events)
@@ -851,7 +855,7 @@ bool lzs_applicable(const LzP &P)
 // their steps independently on the context's streams — one group's serial chains run beside another's sorts.
 // *flagged = blocks the sliced finder could not do (read back: one stream synchronisation per batch).
 mi_status lzs_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
-                   const LzwScratch &ws, hipStream_t s, uint32_t *flagged)
+                   const LzwScratch &ws, hipStream_t s, uint32_t *flagged, const uint32_t **flag_list)
 {
     static_assert(sizeof(LzsMeta) <= 65536u * 8u, "the meta records live in one row of eA");
     if (!lzs_applicable(P)) return MI_ERR_ARG;
@@ -880,7 +884,8 @@ mi_status lzs_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, u
         q.key += o; q.slot += o; q.cand += o; q.plist += o; q.big_key += o; q.big_info += o;
         q.meta += lo[g]; q.work += (size_t)lo[g] * LZS_MAXPARTS; q.counters += (size_t)g * LZS_CTR_WORDS;
         for (uint32_t c = 0; c < LZS_NCLS; ++c) q.big_desc[c] += o / 2;
-        q.flag_count = all.counters + 64;                 // one count of flagged blocks for the whole batch
+        q.flag_count = all.counters + 64;                 // one count and one list of flagged blocks for the whole batch
+        q.flag_list = all.flag_list; q.lb0 = lo[g];
         const uint32_t nbg = lo[g + 1] - lo[g];
         mi_prof_scope p(ctx, "k_lzs_keys", st[g], (uint64_t)nbg * P.block);
         hipLaunchKernelGGL(k_lzs_keys, dim3(chunks, nbg), dim3(256), 0, st[g], d_in, n, P, q, block0 + lo[g]);
@@ -917,6 +922,14 @@ mi_status lzs_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, u
     MI_HIP(ctx, hipMemcpyAsync(h, sc.flag_count, 4, hipMemcpyDeviceToHost, s));
     MI_HIP(ctx, hipStreamSynchronize(s));
     *flagged = *h;
+    if (*flagged && flag_list) {                         // which blocks: the caller redoes only those
+        const uint32_t k = *flagged < nb ? *flagged : nb;
+        if ((size_t)(k + 1) * 4 <= ctx->h_pinned_bytes) {
+            MI_HIP(ctx, hipMemcpyAsync(h + 1, sc.flag_list, (size_t)k * 4, hipMemcpyDeviceToHost, s));
+            MI_HIP(ctx, hipStreamSynchronize(s));
+            *flag_list = h + 1;
+        } else *flag_list = nullptr;
+    }
     if (sc.dbg) {                                        // development aid: phase shares of k_lzs_find on stderr
         uint64_t v[16];
         if (hipMemcpy(v, sc.dbg, sizeof v, hipMemcpyDeviceToHost) == hipSuccess && v[8]) {

@@ -24,6 +24,7 @@
 #include "lz_common.h"
 #include "lz_replay.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 #define LZW_MAX_BLOCK   (1u << 20)
 #define LZW_SEG         65536u                    // parse/emit segment
@@ -755,14 +756,41 @@ mi_status lzw_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, u
 // runs of one byte value) is redone here, whole-block clusters of any size.
 bool      lzs_applicable(const LzP &P);
 mi_status lzs_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
-                   const LzwScratch &ws, hipStream_t s, uint32_t *flagged);
+                   const LzwScratch &ws, hipStream_t s, uint32_t *flagged, const uint32_t **flag_list);
+
+// the workspace as block `lb` of the batch sees it: a one-block run of the whole-block finder then works in that block's own rows
+static LzwScratch lzw_view_at(const LzwScratch &ws, uint32_t lb)
+{
+    LzwScratch v = ws;
+    const size_t S = ws.S, o = (size_t)lb * S;
+    v.eA += o; v.eB += o; v.gid += o; v.rd += o; v.cstart += (size_t)lb * (S + 2); v.ncl += (size_t)lb * 4;
+    v.t_live += (size_t)lb * (S + 64); v.t_pos += o; v.t_mix += o; v.slot_of += o; v.cand += o; v.ent += o; v.relw += o; v.cand_e += o;
+    v.slot += (size_t)lb * ws.slot_words; v.block_bits += lb;
+    return v;                                            // (the class lists and their counters are shared: lzw_find resets them)
+}
+
 mi_status lzw_or_lzs_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb, const LzwScratch &sc, hipStream_t s)
 {
     if (lzs_applicable(P)) {
         uint32_t flagged = 0;
-        const mi_status st = lzs_find(ctx, P, d_in, n, block0, nb, sc, s, &flagged);
+        const uint32_t *list = nullptr;
+        const mi_status st = lzs_find(ctx, P, d_in, n, block0, nb, sc, s, &flagged, &list);
         if (st) return st;
         if (!flagged) return MI_OK;
+        if (list && flagged <= nb / 4u + 1u) {           // a few blocks with a giant cluster: only they are redone
+            uint32_t todo[64];
+            const uint32_t k = flagged < 64u ? flagged : 64u;
+            if (flagged <= 64u) {
+                for (uint32_t i = 0; i < k; ++i) todo[i] = list[i];          // (the pinned list is reused by later calls)
+                if (getenv("MI_LZ_DEBUG")) fprintf(stderr, "lzs: %u of %u blocks flagged, redone alone by the whole-block finder (first: %u)\n", flagged, nb, todo[0]);
+                for (uint32_t i = 0; i < k; ++i) {
+                    if (todo[i] >= nb) return MI_ERR_HIP;
+                    const mi_status s2 = lzw_find(ctx, P, d_in, n, block0 + todo[i], 1u, lzw_view_at(sc, todo[i]), s);
+                    if (s2) return s2;
+                }
+                return MI_OK;
+            }
+        }
     }
     return lzw_find(ctx, P, d_in, n, block0, nb, sc, s);
 }

@@ -210,3 +210,16 @@ def test_other_table_sizes(wbits, tbits):
         assert bad.size == 0, f"w{wbits} T{tbits} block at {at}: {bad.size} mismatches, first {bad[:5]}"
     st = lz.compress(data, p)
     assert np.array_equal(lz.decompress(st).cpu().numpy(), data)
+
+
+def test_one_flagged_block_is_redone_alone():
+    """six blocks of text, ONE of them with a 40 000-byte run of one value (a cluster above the sliced finder's capacity):
+    that block alone goes through the whole-block finder, in its own rows of the workspace; every block must match the oracle"""
+    data = synth.enwik_like(6 * 131072, seed=71).numpy().copy()
+    data[3 * 131072 + 5000: 3 * 131072 + 45000] = 0
+    data[5 * 131072 + 100: 5 * 131072 + 130] = 7                      # (a short run: no flag)
+    _check_find(data, 16, 131072)
+    _check_stream(data, 16, 131072)
+    data2 = synth.enwik_like(5 * 262144, seed=72).numpy().copy()      # the FIRST block flagged, 256 KiB blocks
+    data2[1000:60000] = 0x41
+    _check_find(data2, 16, 262144)
