@@ -23,7 +23,7 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
 {
     // region0: input bytes -> exit tables [64][1024] -> {token base, match base, staging window}
     __shared__ __attribute__((aligned(16))) uint8_t s_r0[LZ_MAX_BLOCK + LZ_TAIL + 16];
-    __shared__ uint8_t  s_L[LZ_MAX_BLOCK];
+    __shared__ __attribute__((aligned(16))) uint8_t s_L[LZ_MAX_BLOCK];
     __shared__ uint64_t s_tok[1024], s_mat[1024];
     __shared__ uint8_t  s_entry[1024];
     __shared__ uint8_t  s_sexit[32][32];
@@ -157,12 +157,21 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     // ---- B: exit offset of every position of a 64-position chunk into the next chunk
     uint8_t *ex = s_r0;                       // ex[o * 1024 + chunk]
     {
+        // the chunk's 64 lengths come in as four 16-byte LDS reads up front: the backward walk then has ONE dependent LDS
+        // read per step (the exit of the position it jumps to) instead of two
         const uint32_t c = tid;
+        uint32_t lw[16];
+        {
+            const uint4 *lp = reinterpret_cast<const uint4 *>(s_L + c * 64u);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const uint4 v = lp[q]; lw[4 * q] = v.x; lw[4 * q + 1] = v.y; lw[4 * q + 2] = v.z; lw[4 * q + 3] = v.w; }
+        }
+#pragma unroll
         for (int o = 63; o >= 0; --o) {
             const uint32_t p = c * 64u + (uint32_t)o;
             uint32_t e = 0;
             if (p < n) {
-                const uint32_t l = s_L[p];
+                const uint32_t l = (lw[o >> 2] >> (8 * (o & 3))) & 0xFFu;
                 const uint32_t nx = (uint32_t)o + (l ? l : 1u);
                 e = nx >= 64u ? nx - 64u : ex[nx * 1024u + c];
             }
