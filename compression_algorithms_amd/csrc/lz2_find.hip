@@ -775,7 +775,7 @@ void lz2_carve(mi_carver &cv, uint32_t nb, Lz2Scratch *sc)
     sc->big_count = sc->fallback_count + 16;
     sc->work_count = sc->fallback_count + 32;            // zeroed with the other counters by stage 1
     sc->work = cv.take<uint64_t>((size_t)nb * LZ2_MAXPARTS);
-    sc->dbg = getenv("MI_LZ_DEBUG") ? cv.take<uint64_t>(32) : nullptr;
+    sc->dbg = getenv("MI_LZ_DEBUG") ? cv.take<uint64_t>(64) : nullptr;
     sc->wave_min = LZ2_WAVE;
     sc->stop_phase = getenv("MI_LZ_STOP_PHASE") ? (uint32_t)atoi(getenv("MI_LZ_STOP_PHASE")) : 0u;
 }
@@ -793,7 +793,7 @@ extern "C" int mi_lz_debug_counters(mi_ctx *ctx, uint64_t *out32)
 {
     if (!ctx || !ctx->lz_dbg) return 0;
     (void)hipDeviceSynchronize();
-    return hipMemcpy(out32, ctx->lz_dbg, 32 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 1 : 0;
+    return hipMemcpy(out32, ctx->lz_dbg, 64 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 1 : 0;      // 64 counters: [0..31] find / parse, [32..47] partition
 }
 
 void lz2_launch_partition(const uint8_t *d_in, uint64_t n, const LzP &P, const Lz2Scratch &sc, uint64_t block0, uint32_t nb, hipStream_t s);
@@ -803,7 +803,7 @@ mi_status lz2_stage_partition(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, ui
                               const Lz2Scratch &sc, hipStream_t s)
 {
     MI_HIP(ctx, hipMemsetAsync(sc.fallback_count, 0, 256, s));      // fallback_count and big_count[]
-    if (sc.dbg && ctx->lz_dbg != sc.dbg) { ctx->lz_dbg = sc.dbg; MI_HIP(ctx, hipMemsetAsync(sc.dbg, 0, 256, s)); }
+    if (sc.dbg && ctx->lz_dbg != sc.dbg) { ctx->lz_dbg = sc.dbg; MI_HIP(ctx, hipMemsetAsync(sc.dbg, 0, 512, s)); }
     mi_prof_scope p(ctx, "k_lz2_partition", s, (uint64_t)nb * P.block);
     lz2_launch_partition(d_in, n, P, sc, block0, nb, s);
     MI_HIP(ctx, hipGetLastError());

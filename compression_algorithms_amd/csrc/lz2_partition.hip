@@ -34,6 +34,8 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
 
     const int tid = threadIdx.x;
     const uint32_t lb = blockIdx.x;
+    long long tk = clock64();
+#define PT_TICK(k) do { if (sc.dbg && tid == 0) { long long t2 = clock64(); atomicAdd((unsigned long long *)&sc.dbg[32 + (k)], (unsigned long long)(t2 - tk)); tk = t2; } } while (0)
     const uint64_t off = (block0 + lb) * (uint64_t)P.block;
     const uint32_t n = (uint32_t)((n_total - off) < P.block ? (n_total - off) : P.block);
     const uint8_t *src = in + off;
@@ -53,8 +55,19 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     if (tid == 0) { s_s0 = ~0u; s_flag = 0; }
     __syncthreads();
     auto home_of = [&](uint32_t p) -> uint32_t { return lz_mix32(lds_word(s_in, p)) & Tmask; };
-    for (uint32_t p = tid; p < n; p += 1024) atomicAdd(&s_grp[home_of(p) >> gshift], 1u);
+    PT_TICK(0);
+    // the group of every position stays in registers (two 14-bit numbers per register, 64 positions per thread): the hash is
+    // computed once — the pass that tabulates the part of every position further down used to compute it again
+    uint32_t gcache[32];
+#pragma unroll
+    for (uint32_t i = 0; i < 64u; ++i) {
+        const uint32_t p = (uint32_t)tid + 1024u * i;
+        uint32_t g = 0;
+        if (p < n) { g = home_of(p) >> gshift; atomicAdd(&s_grp[g], 1u); }
+        if (i & 1u) gcache[i >> 1] |= g << 16; else gcache[i >> 1] = g;
+    }
     __syncthreads();
+    PT_TICK(1);
 
     // ---- overflow certificate: 16 consecutive groups per thread
     const uint32_t g0 = tid * (LZ2_NG / 1024);
@@ -95,6 +108,7 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     }
     __syncthreads();
 
+    PT_TICK(2);
     // ---- cut the ring / choose the parts
     Lz2BlockMeta *mt = sc.meta + lb;
     const uint32_t s0 = s_s0;
@@ -162,6 +176,7 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     }
     __syncthreads();
     const uint32_t K = s_K;                             // <= LZ2_MAXPARTS
+    PT_TICK(3);
     // part sizes; refuse the block if any part exceeds the LDS capacity of stage 2
     if (tid < K) {
         const uint32_t a = s_thr[tid], b = s_thr[tid + 1];
@@ -208,19 +223,38 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     uint16_t *plist = sc.plist + (size_t)lb * LZ_MAX_BLOCK;
     uint8_t  *part_in = reinterpret_cast<uint8_t *>(s_grp);             // [65536] part of every position; the group array is dead now
     __shared__ uint8_t s_gpart[LZ2_NG];                                 // part of every rotated group (part boundaries are group boundaries)
-    for (uint32_t gr = tid; gr < LZ2_NG; gr += 1024) {
-        const uint32_t h = gr << gshift;
+    {
+        // sixteen consecutive groups per thread: one binary search for the first, then a walk along the thresholds
+        constexpr uint32_t GPT = LZ2_NG / 1024;
+        const uint32_t gr0 = (uint32_t)tid * GPT;
         uint32_t lo = 0, hi = K - 1;                    // last k with thr[k] <= h
-        while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (s_thr[mid] <= h) lo = mid; else hi = mid - 1; }
-        s_gpart[gr] = (uint8_t)lo;
+        { const uint32_t h = gr0 << gshift; while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (s_thr[mid] <= h) lo = mid; else hi = mid - 1; } }
+        uint32_t nxt = lo + 1 < K ? s_thr[lo + 1] : 0xFFFFFFFFu;
+        for (uint32_t k = 0; k < GPT; ++k) {
+            const uint32_t h = (gr0 + k) << gshift;
+            while (h >= nxt) { ++lo; nxt = lo + 1 < K ? s_thr[lo + 1] : 0xFFFFFFFFu; }
+            s_gpart[gr0 + k] = (uint8_t)lo;
+        }
     }
     __syncthreads();
-    for (uint32_t p = tid; p < n; p += 1024) part_in[p] = s_gpart[((home_of(p) - base) & Tmask) >> gshift];
+    PT_TICK(4);
+    {
+        const uint32_t gstart_ = base >> gshift;        // the ring is cut on a group boundary
+#pragma unroll
+        for (uint32_t i = 0; i < 64u; ++i) {
+            const uint32_t p = (uint32_t)tid + 1024u * i;
+            const uint32_t g = (gcache[i >> 1] >> (16u * (i & 1u))) & 0xFFFFu;
+            if (p < n) part_in[p] = s_gpart[(g - gstart_) & (LZ2_NG - 1u)];
+        }
+    }
     __syncthreads();
+    PT_TICK(5);
     radix_pass_1024<LZ2_PARTBITS, uint32_t>(n, s_cnt,
         [&](uint32_t i) { return i | ((uint32_t)part_in[i] << 16); },
         [&](uint32_t e) { return e >> 16; },
         [&](uint32_t j, uint32_t e) { plist[j] = (uint16_t)e; }, (P.flags & LZP_ARANK) != 0);
+    PT_TICK(6);
+    if (sc.dbg && tid == 0) atomicAdd((unsigned long long *)&sc.dbg[47], 1ull);
 }
 
 void lz2_launch_partition(const uint8_t *d_in, uint64_t n, const LzP &P, const Lz2Scratch &sc, uint64_t block0, uint32_t nb, hipStream_t s)

@@ -19,7 +19,7 @@ x = synth.enwik_like(n, seed=12345, device="cuda")
 p = lz.params("deflate")
 (lz.compress_h if os.environ.get("MI_PHASE_MODE_H") else lz.compress)(x, p, ctx)
 torch.cuda.synchronize()
-out = (C.c_uint64 * 32)()
+out = (C.c_uint64 * 64)()
 ctx.L.mi_lz_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
 ok = ctx.L.mi_lz_debug_counters(ctx.h, out)
 v = np.array(list(out), dtype=np.float64)
@@ -40,3 +40,10 @@ pt = pe.sum()
 print("k_lz_parse_emit blocks:", int(v[31]), " cycles/block:", int(pt / max(v[31], 1)))
 for k, nm in enumerate(["load", "lengths", "exit tables", "compose", "chunks", "scan+put", "emit"]):
     print(f"  {nm:14s} {100 * pe[k] / pt:5.1f} %   {pe[k] / max(v[31], 1):9.0f} cycles/block")
+
+pp = v[32:39]
+nb_ = max(v[47], 1)
+if v[47]:
+    print("k_lz2_partition blocks:", int(v[47]), " cycles/block:", int(pp.sum() / nb_))
+    for k, nm in enumerate(["load", "hash+count", "certificate+prefix", "cuts", "part table", "part of every position", "radix pass"]):
+        print(f"  {nm:24s} {100 * pp[k] / pp.sum():5.1f} %   {pp[k] / nb_:9.0f} cycles/block")
