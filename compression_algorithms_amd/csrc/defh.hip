@@ -17,6 +17,7 @@
 //   k_defh_decode   one wave per block: record -> tokens -> bytes (LZ copy in LDS), no token stream in HBM
 #include "lz_common.h"
 #include "lz_decode.h"
+#include <stdlib.h>
 
 #define DEFH_NSYM     286
 #define DEFH_HDR      292u          // bytes before the packed words
@@ -304,7 +305,7 @@ void k_defh_decode(const uint8_t *__restrict__ stream, uint64_t stream_bytes, co
             const uint32_t d = (1u << nx) + (nx ? x >> (32u - nx) : 0u);
             const uint32_t len = (x << nx) >> 27;
             br.skip(nx + 5u); pos += nx + 5u;
-            if (d > o || d > RING) { bad = true; break; }
+            if (d > o) { bad = true; break; }
             const uint32_t take = (o + len <= n) ? len : n - o;
             ring.copy(o, d, take);
             o += take;
@@ -348,11 +349,13 @@ extern "C" mi_status mi_deflate_h_decode_dev(mi_ctx *ctx, const mi_lz_params *p,
     if (!err) return MI_ERR_HIP;
     {
         mi_prof_scope pr(ctx, "k_defh_decode", s, n);
-        // the ring is the window (a distance never exceeds it) or the block, whichever is smaller
+        // a 16 KiB ring whatever the window (lz_decode.h): far matches read the output buffer
         const uint32_t W = 1u << P.wbits, need = W < P.block ? W : P.block;
-        if (need <= 16384u)      hipLaunchKernelGGL(k_defh_decode<16384u>, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, stream_bytes, d_block_bits, P, d_out, n, err);
-        else if (need <= 32768u) hipLaunchKernelGGL(k_defh_decode<32768u>, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, stream_bytes, d_block_bits, P, d_out, n, err);
-        else                     hipLaunchKernelGGL(k_defh_decode<65536u>, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, stream_bytes, d_block_bits, P, d_out, n, err);
+        const char *e = getenv("MI_LZ_DECODE_RING");
+        const uint32_t want = e ? (uint32_t)atoi(e) : (nblocks < 1024u ? need : 16384u);      // (few blocks: lz_decode.hip)
+        if (need <= 16384u || want <= 16384u) hipLaunchKernelGGL(k_defh_decode<16384u>, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, stream_bytes, d_block_bits, P, d_out, n, err);
+        else if (need <= 32768u || want <= 32768u) hipLaunchKernelGGL(k_defh_decode<32768u>, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, stream_bytes, d_block_bits, P, d_out, n, err);
+        else hipLaunchKernelGGL(k_defh_decode<65536u>, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, stream_bytes, d_block_bits, P, d_out, n, err);
     }
     uint32_t h_err = 0;
     MI_HIP(ctx, hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, s));

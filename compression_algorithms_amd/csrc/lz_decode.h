@@ -70,9 +70,11 @@ struct BitsMsb {
     __device__ __forceinline__ void skip(uint32_t k) { buf <<= k; have -= k; }
 };
 
-// The output ring.  Position x lives in cell x & (RING-1) and is overwritten by position x + RING; a match reaches back
-// at most RING bytes (checked), and a copy step reads all of its sources before it writes (one instruction pair for up
-// to 64 bytes), so RING == window size is enough.  Quarters are copied out as soon as the write cursor has left them.
+// The output ring.  Position x lives in cell x & (RING-1) and is overwritten by position x + RING.  Quarters are copied out
+// as soon as the write cursor has left them, so whatever has left the ring is in the output buffer already — and a match may
+// reach back FARTHER than the ring: such source bytes are read from the output buffer itself (past the CU's L1, which may
+// hold a line from before its bytes were written).  The ring therefore need not be the window: 16 KiB per wave puts two to
+// four times as many waves on a CU as a 32 / 64 KiB ring did, for a slower read on the minority of far matches.
 template <uint32_t RING>
 struct OutRing {
     static constexpr uint32_t RM = RING - 1u, CH = RING / 4u;
@@ -84,14 +86,23 @@ struct OutRing {
         ring = lds; dst = out; flushed = 0; lane = lane_; aligned = (((uintptr_t)out) & 15u) == 0;
     }
     __device__ __forceinline__ void put_literal(uint32_t o, uint32_t byte) { if (lane == 0) ring[o & RM] = (uint8_t)byte; }
-    // copy `take` bytes from distance d (1 <= d <= o, d <= RING): byte j comes from o - d + (j mod d)
+    // byte at position x < o: from the ring while it is there (and not about to be overwritten by the copy in progress, whose
+    // last byte is position `oend - 1`), else from the output buffer
+    __device__ __forceinline__ uint8_t fetch(uint32_t x, uint32_t oend) const
+    {
+        if (x + RING >= oend) return ring[x & RM];
+        return __hip_atomic_load(dst + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // copy `take` bytes from distance d (1 <= d <= o): byte j comes from o - d + (j mod d)
     __device__ __forceinline__ void copy(uint32_t o, uint32_t d, uint32_t take)
     {
+        const uint32_t oend = o + take;
         if (d >= take || d >= 64u) {
             // no source byte of a 64-byte step is written by the same step (or, for d >= 64, by an earlier lane of it)
-            for (uint32_t j = lane; j < take; j += 64u) ring[(o + j) & RM] = ring[(o - d + j) & RM];
+            if (d + take <= RING) { for (uint32_t j = lane; j < take; j += 64u) ring[(o + j) & RM] = ring[(o - d + j) & RM]; }       // all of it in the ring
+            else for (uint32_t j = lane; j < take; j += 64u) ring[(o + j) & RM] = fetch(o - d + j, oend);
         } else {
-            for (uint32_t j = lane; j < take; j += 64u) ring[(o + j) & RM] = ring[(o - d + (j % d)) & RM];
+            for (uint32_t j = lane; j < take; j += 64u) ring[(o + j) & RM] = ring[(o - d + (j % d)) & RM];      // d < 64: near
         }
     }
     __device__ __forceinline__ void copy_out(uint32_t from, uint32_t to)
@@ -105,7 +116,10 @@ struct OutRing {
     }
     __device__ __forceinline__ void advance(uint32_t o)
     {
-        if (__builtin_expect(o - flushed >= CH, 0)) { copy_out(flushed, flushed + CH); flushed += CH; }     // a token adds < CH bytes
+        if (__builtin_expect(o - flushed >= CH, 0)) {                                                           // a token adds < CH bytes
+            copy_out(flushed, flushed + CH); flushed += CH;
+            __threadfence();                                  // far matches read these bytes back: they must have left the CU
+        }
     }
     __device__ __forceinline__ void finish(uint32_t n) { copy_out(flushed, n); }
 };
