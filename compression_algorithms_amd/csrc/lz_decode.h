@@ -73,8 +73,8 @@ struct BitsMsb {
 // The output ring.  Position x lives in cell x & (RING-1) and is overwritten by position x + RING.  Quarters are copied out
 // as soon as the write cursor has left them, so whatever has left the ring is in the output buffer already — and a match may
 // reach back FARTHER than the ring: such source bytes are read from the output buffer itself (past the CU's L1, which may
-// hold a line from before its bytes were written).  The ring therefore need not be the window: 16 KiB per wave puts two to
-// four times as many waves on a CU as a 32 / 64 KiB ring did, for a slower read on the minority of far matches.
+// hold a line from before its bytes were written).  The ring therefore need not be the window: 4-8 KiB per wave put several
+// times as many waves on a CU as a 32 / 64 KiB ring did, for a slower read on the far matches (lz_decode.hip has the A/B).
 template <uint32_t RING>
 struct OutRing {
     static constexpr uint32_t RM = RING - 1u, CH = RING / 4u;

@@ -136,8 +136,8 @@ static void launch_ring(const uint8_t *d_stream, uint64_t stream_bytes, const ui
     else           hipLaunchKernelGGL(k_lz_decode_bits<RING>, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, stream_bytes, d_block_bits, P, d_out, n, err);
 }
 
-// A 16 KiB ring whatever the window (lz_decode.h: matches that reach back farther read the output buffer); MI_LZ_DECODE_RING=
-// 32768 / 65536 restores the ring-is-the-window shape for A/B runs.
+// An 8 KiB ring whatever the window (lz_decode.h: matches that reach back farther read the output buffer); MI_LZ_DECODE_RING=
+// 4096 .. 65536 forces a size (65536: the ring-is-the-window shape) for A/B runs.
 void lz_launch_decode(const uint8_t *d_stream, uint64_t stream_bytes, const uint64_t *d_block_bits, const LzP &P, uint8_t *d_out,
                       uint64_t n, uint64_t nblocks, uint32_t *err, hipStream_t s)
 {
@@ -145,8 +145,10 @@ void lz_launch_decode(const uint8_t *d_stream, uint64_t stream_bytes, const uint
     const char *e = getenv("MI_LZ_DECODE_RING");
     // few blocks (fewer than the waves a ring of the window's size lets the chip hold): more waves are no use, the far
     // reads only cost (381 blocks of 256 KiB: 5.3 GB/s with the window in the ring, 4.4 with 16 KiB)
-    const uint32_t want = e ? (uint32_t)atoi(e) : (nblocks < 1024u ? need : 16384u);
-    if (need <= 16384u || want <= 16384u) launch_ring<16384u>(d_stream, stream_bytes, d_block_bits, P, d_out, n, nblocks, err, s);
+    const uint32_t want = e ? (uint32_t)atoi(e) : (nblocks < 1024u ? need : 8192u);          // 8 KiB: 36 GB/s for byte tokens (16 KiB: 31, 4 KiB: 27)
+    if (want <= 4096u) launch_ring<4096u>(d_stream, stream_bytes, d_block_bits, P, d_out, n, nblocks, err, s);
+    else if (want <= 8192u) launch_ring<8192u>(d_stream, stream_bytes, d_block_bits, P, d_out, n, nblocks, err, s);
+    else if (need <= 16384u || want <= 16384u) launch_ring<16384u>(d_stream, stream_bytes, d_block_bits, P, d_out, n, nblocks, err, s);
     else if (need <= 32768u || want <= 32768u) launch_ring<32768u>(d_stream, stream_bytes, d_block_bits, P, d_out, n, nblocks, err, s);
     else launch_ring<65536u>(d_stream, stream_bytes, d_block_bits, P, d_out, n, nblocks, err, s);
 }

@@ -101,7 +101,7 @@ def test_unaligned_output_and_stream_pointers(flavour, wbits, mode_h, out_off, i
     assert not got[:out_off].any() and not got[out_off + len(data):].any()      # nothing written outside [out, out + n)
 
 
-@pytest.mark.parametrize("ring", ["16384", "32768", "65536"])
+@pytest.mark.parametrize("ring", ["4096", "8192", "16384", "65536"])
 @pytest.mark.parametrize("flavour,wbits,mode_h", [("deflate", None, False), ("deflate", None, True), ("lz77", 16, False)])
 def test_far_matches_read_the_output_buffer(ring, flavour, wbits, mode_h, monkeypatch):
     """a ring smaller than the window: matches whose source has left the ring read the bytes the wave flushed earlier (past
@@ -110,7 +110,7 @@ def test_far_matches_read_the_output_buffer(ring, flavour, wbits, mode_h, monkey
     monkeypatch.setenv("MI_LZ_DECODE_RING", ring)
     rng = np.random.default_rng(21)
     base = rng.integers(0, 256, 16384 - 40, dtype=np.uint8)
-    blk = np.concatenate([base, base[:9000], rng.integers(0, 256, 3000, dtype=np.uint8), base[100:16000], base[5000:12000]])
+    blk = np.concatenate([base, base[:9000], rng.integers(0, 256, 3000, dtype=np.uint8), base[100:16000], base[5000:12000], base[4090:4100], base[8185:8200]])
     blk = np.concatenate([blk, synth.enwik_like(65536 - len(blk), seed=3).numpy()])[:65536]
     data = np.concatenate([blk, synth.enwik_like(3 * 65536 + 123, seed=9).numpy()])
     p = lz.params(flavour, wbits, 65536)
