@@ -21,7 +21,12 @@
 
 #define DEFH_NSYM     286
 #define DEFH_HDR      292u          // bytes before the packed words
-#define DEFH_THREADS  512
+// 256 threads per block: the kernel spends its time behind ONE lane (the heap), so what counts is how many blocks a CU holds —
+// wave slots, not LDS, are the limit (32 per CU: 8 blocks of 4 waves instead of 4 of 8).  Same box: 512 / 256 / 128 threads
+// 17.30 / 17.72 / 17.68 GB/s for the whole mode-H step.
+#ifndef DEFH_THREADS
+#define DEFH_THREADS  256
+#endif
 #define DEFH_PER      4             // tokens per thread per round
 #define DEFH_MAXBITS  44u           // code <= 24 (65536 tokens: Fibonacci bound) + 15 offset bits + 5 length bits
 #define DEFH_LUT_BITS 11
@@ -146,11 +151,12 @@ void k_defh_encode(const uint32_t *__restrict__ trec_all, uint32_t *__restrict__
         }
     }
     __syncthreads();
-    if (tid < DEFH_NSYM && s_hist[tid]) {
+    for (int sy = tid; sy < DEFH_NSYM; sy += DEFH_THREADS) {
+        if (!s_hist[sy]) continue;
         uint32_t len = 0;
         if (h.nnodes == 1) len = 1;
-        else for (int node = h.leaf_of[tid]; node != h.root; node = h.parent[node]) ++len;
-        s_len[tid] = (uint8_t)len;
+        else for (int node = h.leaf_of[sy]; node != h.root; node = h.parent[node]) ++len;
+        s_len[sy] = (uint8_t)len;
     }
     __syncthreads();
     defh_canonical(s_len, s_code, s_count, s_next);
