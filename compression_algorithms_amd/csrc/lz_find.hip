@@ -615,7 +615,10 @@ mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t
 
 uint32_t lz_batch_blocks(uint64_t nblocks)
 {
-    uint64_t cap = 1024;        // measured: 256 -> 9.2, 512 -> 9.9, 1024 -> 10.3 GB/s (the replay kernels' tails amortise)
+    // measured in round 1: 256 -> 9.2, 512 -> 9.9, 1024 -> 10.3 GB/s (the replay kernels' tails amortise).  End of round 2, 10^9 B
+    // (15 259 blocks), same box: 1024 / 1536 / 2048 / 3072 / 4096 blocks per batch 17.71 / 17.83 / 17.96 / 18.14 / 18.01 GB/s —
+    // larger batches as long as three stages still have three batches to overlap (288 GB of HBM: ~5 GB per set at 3072)
+    uint64_t cap = nblocks >= 3u * 3072u ? 3072u : nblocks >= 3u * 2048u ? 2048u : 1024u;
     if (const char *e = getenv("MI_LZ_BATCH")) { long v = atol(e); if (v >= 1 && v <= 4096) cap = (uint64_t)v; }
     return (uint32_t)(nblocks < cap ? (nblocks ? nblocks : 1) : cap);
 }
