@@ -20,7 +20,9 @@
 #endif
 #define LZ2_MAXPARTS  (1u << LZ2_PARTBITS)
 static_assert(LZ2_CAP % LZ2_THREADS == 0, "entries per thread must be whole");
-#define LZ2_BIG       8u                    // clusters of at least this many entries leave k_lz2_find
+#ifndef LZ2_BIG
+#define LZ2_BIG       8u                    // clusters of at least this many entries leave k_lz2_find (8 or 16: the register replay holds < 16)
+#endif
 #define LZ2_WAVE      128u                  // ... and from this size on a whole wave replays one cluster
 #define LZ2_MAXBIG    (LZ2_CAP / LZ2_BIG)   // exported clusters per part, at most
 // Exported clusters start on 8-entry boundaries of the block's big arrays (the lane replay loads and stores 16 bytes =

@@ -79,6 +79,8 @@ __device__ void replay_small(const uint16_t *pos, uint16_t *rs, const uint16_t *
 // The same replay for a cluster of < 8 entries that does not cover bucket 0 / T, with its whole table in registers:
 // 7 occupancy bits, the occupant of every slot and the slot of every entry as 4-bit fields.  LDS is only read for the
 // entry records (and for an occupant's word id when a probe has to compare) and written for the result.
+// F = uint32_t: up to 8 four-bit fields (clusters below 8 entries); F = uint64_t: up to 16 (below 16).
+template <typename F>
 __device__ __forceinline__ void replay_small_reg(const uint16_t *pos, const uint16_t *rs, const uint16_t *pid,
                                                  uint32_t s, uint32_t e, uint32_t W, uint16_t *cand_i)
 {
@@ -88,13 +90,14 @@ __device__ __forceinline__ void replay_small_reg(const uint16_t *pos, const uint
         return;
     }
     const uint32_t n = e - s;
-    uint32_t mask = 0, ent = 0, slots = 0;
+    uint32_t mask = 0;
+    F ent = 0, slots = 0;
     uint32_t ev = 0, ev_pos = pos[s];
     for (uint32_t li = 0; li < n; ++li) {
         const uint32_t i = s + li;
         const uint32_t p = pos[i], rr = ((uint32_t)rs[i] & RS_MASK) - s, id = pid[i];
         while (ev < li && ev_pos + W < p) {                              // FIFO retirement, lz77.c:70-76
-            mask &= ~(1u << ((slots >> (4u * ev)) & 15u));
+            mask &= ~(1u << ((uint32_t)(slots >> (4u * ev)) & 15u));
             ++ev; ev_pos = pos[s + ev];
         }
         uint32_t res = LZ_NONE16;
@@ -102,15 +105,15 @@ __device__ __forceinline__ void replay_small_reg(const uint16_t *pos, const uint
             if (id != p) res = id;
         } else if (id != p) {                                           // (a word's first occurrence in the block finds nothing, ever)
             for (uint32_t b = rr; (mask >> b) & 1u; ++b) {              // bits >= n are never set: the probe ends inside the cluster
-                const uint32_t o = s + ((ent >> (4u * b)) & 15u);
+                const uint32_t o = s + ((uint32_t)(ent >> (4u * b)) & 15u);
                 if (pid[o] == id) { res = pos[o]; break; }
             }
         }
         cand_i[i] = (uint16_t)res;
         const uint32_t b = rr + (uint32_t)__builtin_ctz(~(mask >> rr));  // first fit (inside the cluster by the parking bound)
         mask |= 1u << b;
-        ent = (ent & ~(15u << (4u * b))) | (li << (4u * b));
-        slots |= b << (4u * li);
+        ent = (ent & ~((F)15u << (4u * b))) | ((F)li << (4u * b));
+        slots |= (F)b << (4u * li);
     }
 }
 
@@ -536,7 +539,8 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
             while (e < m && !(e_rs[e] & RS_HEAD)) ++e;
             const bool zc = (s == s_zhead);
             if (zc) replay_small(e_pos, e_rs, e_pid, occ, s_bm, s, e, W, s_zslot, P.deflate ? s_zslot : ~0u, cand_i);
-            else replay_small_reg(e_pos, e_rs, e_pid, s, e, W, cand_i);
+            else if (LZ2_BIG > 8u && e - s >= 8u) replay_small_reg<uint64_t>(e_pos, e_rs, e_pid, s, e, W, cand_i);
+            else replay_small_reg<uint32_t>(e_pos, e_rs, e_pid, s, e, W, cand_i);
         }
         if (want_cls) s_clsbase[tid] = pending_base;
         if (want_ent) s_entbase = pending_base;
@@ -757,7 +761,9 @@ static uint32_t lz2_class_cap(uint32_t c)
 
 size_t lz2_scratch_bytes(uint32_t nb)
 {
-    return (size_t)nb * (LZ_MAX_BLOCK * 2 * 2 + LZ2_BIG_STRIDE * 2 * 4 + sizeof(Lz2BlockMeta) + 4 + 8 * LZ2_MAXPARTS + 3 * LZ2_DESC_SMALL * sizeof(Lz2BigDesc)) + 16 * 256 + 4096;
+    size_t descs = 0;                                    // what lz2_carve takes for the class descriptor arrays, exactly
+    for (uint32_t c = 0; c < LZ2_NCLASS; ++c) descs += lz2_class_cap(c);
+    return (size_t)nb * (LZ_MAX_BLOCK * 2 * 2 + LZ2_BIG_STRIDE * 2 * 4 + sizeof(Lz2BlockMeta) + 4 + 8 * LZ2_MAXPARTS + descs * sizeof(Lz2BigDesc)) + 16 * 256 + 4096 + 64 * 256;
 }
 
 void lz2_carve(mi_carver &cv, uint32_t nb, Lz2Scratch *sc)
