@@ -124,8 +124,9 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     __shared__ uint16_t s_pos[LZ2_CAP];                 // position by time index j
     __shared__ uint32_t s_word[LZ2_CAP];                // mix32(word) by j; later e_pos / e_rs (replay order)
     __shared__ uint16_t s_j0[LZ2_CAP], s_j1[LZ2_CAP];   // sort ping-pong; later e_pid / (free)
-    __shared__ uint16_t s_g[LZ2_CAP];                   // cluster number by j; later occ
-    __shared__ uint16_t s_r[LZ2_CAP];                   // dense home slot by j; later cand by replay index
+    __shared__ __attribute__((aligned(16))) uint16_t s_gr[2 * LZ2_CAP];   // s_g | s_r; during the home sort: the second pass's counters
+    uint16_t *const s_g = s_gr;                          // cluster number by j; later occ
+    uint16_t *const s_r = s_gr + LZ2_CAP;                // dense home slot by j; later cand by replay index
     __shared__ uint16_t s_pid[LZ2_CAP + 2];             // word id by j (position of the first occurrence); then s_gstart; last cand by j
     __shared__ uint32_t s_cnt[LZ2_NWAVES + 1][256];   // radix counters, [digit][wave + pad] (lz_common.h)
     __shared__ uint32_t s_bm[LZ2_CAP / 32 + 2];
@@ -171,6 +172,18 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     const uint32_t T = 1u << P.tbits, Tmask = T - 1u, W = 1u << P.wbits;
     const uint16_t *plist = sc.plist + (size_t)lb * LZ_MAX_BLOCK + pstart;
     (void)n_total;
+    // keys of the home sort are relative to the part's first home; a part of a 2^20-bucket table spans < 2^16 homes, so two
+    // 8-bit passes are enough (three otherwise).  For two passes the digits are COUNTED where they are in hand anyway: the first
+    // pass's while the words are hashed, the second pass's while the first one scatters — no counting loops of their own.
+    const uint32_t plo_ = mt->part_lo[part];
+    const uint32_t phi_ = (part + 1 < mt->nparts) ? mt->part_lo[part + 1] : T;
+    const bool three = (phi_ - plo_) > 65536u;
+    uint32_t *const cntA = &s_cnt[0][0];
+    uint32_t (*const s_cntB)[256] = reinterpret_cast<uint32_t (*)[256]>(s_gr);       // 9 KiB of the 16 (s_g / s_r are idle until the sweep)
+    uint32_t *const cntB = &s_cntB[0][0];
+    constexpr uint32_t RST = LZ2_NWAVES + 1;                                        // counter stride of radix_pass
+    const uint32_t seg = radix_seg<LZ2_NWAVES>(m), seg_inv = (uint32_t)((0x100000000ull + seg - 1u) / seg);   // i / seg = umulhi(i, seg_inv) for i < 2^16
+    if (!three) for (uint32_t i = tid; i < 256u * RST; i += LZ2_THREADS) { cntA[i] = 0; cntB[i] = 0; }
 
     // ---- gather: positions (coalesced) and their words (4 unaligned bytes each from the block; bytes
     //      past the block end read as zero, the parity definition of the reference's over-read)
@@ -199,6 +212,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
                 }
             }
         }
+        __syncthreads();                                    // the counters are zero (the loads above are in flight across it)
 #pragma unroll
         for (uint32_t c = 0; c < GCH; ++c) {
             const uint32_t j = tid + c * LZ2_THREADS, p = gp[c];
@@ -211,7 +225,9 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
                 s_pos[j] = (uint16_t)p;
                 // every step of the reference hash is invertible (odd multipliers, rotations, xor-shifts), so the mixed
                 // value identifies the word: keep it instead of the word — the home is a mask away, equality is equality
-                s_word[j] = lz_mix32(w);
+                const uint32_t mx = lz_mix32(w);
+                s_word[j] = mx;
+                if (!three) atomicAdd(&cntA[(((((mx & Tmask) - base) & Tmask) - plo_) & 255u) * RST + __umulhi(j, seg_inv)], 1u);
             }
         }
     }
@@ -221,11 +237,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     auto homep = [&](uint32_t j) -> uint32_t { return ((s_word[j] & Tmask) - base) & Tmask; };
     LZ2_TICK(0);
 
-    // ---- sort time indices by home', stable.  Keys are relative to the part's first home; a part of a
-    //      2^20-bucket table spans < 2^16 homes, so two 8-bit passes are enough (three otherwise).
-    const uint32_t plo_ = mt->part_lo[part];
-    const uint32_t phi_ = (part + 1 < mt->nparts) ? mt->part_lo[part + 1] : T;
-    const bool three = (phi_ - plo_) > 65536u;
+    // ---- sort time indices by home', stable
     const bool arank = (P.flags & LZP_ARANK) != 0;
     auto keyp = [&](uint32_t j) -> uint32_t { return homep(j) - plo_; };
     uint16_t *srt = s_j0;                                   // where the home order ends up
@@ -238,9 +250,10 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
             [&](uint32_t e) { return (keyp(e) >> 16) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; }, arank);
     } else {
         radix_pass<LZ2_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return i; },
-            [&](uint32_t e) { return keyp(e) & 255u; }, [&](uint32_t d, uint32_t e) { s_j1[d] = (uint16_t)e; }, arank, sc.dbg);
-        radix_pass<LZ2_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return (uint32_t)s_j1[i]; },
-            [&](uint32_t e) { return (keyp(e) >> 8) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; }, arank, sc.dbg);
+            [&](uint32_t e) { return keyp(e) & 255u; }, [&](uint32_t d, uint32_t e) { s_j1[d] = (uint16_t)e; }, arank, sc.dbg, true,
+            [&](uint32_t d, uint32_t e) { atomicAdd(&cntB[((keyp(e) >> 8) & 255u) * RST + __umulhi(d, seg_inv)], 1u); });
+        radix_pass<LZ2_NWAVES, 8, uint32_t>(m, s_cntB, [&](uint32_t i) { return (uint32_t)s_j1[i]; },
+            [&](uint32_t e) { return (keyp(e) >> 8) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; }, arank, sc.dbg, true);
     }
     (void)srt;
 

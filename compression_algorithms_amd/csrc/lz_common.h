@@ -175,8 +175,14 @@ struct OpAm { __device__ uint64_t operator()(uint64_t earlier, uint64_t later) c
 //            words (declare [NWAVES + 1][ROW], ROW >= 1 << NBITS).  Digit-major with an odd stride: the thread that
 //            owns a digit reads its NWAVES counters at once (no read-modify-write chain through LDS) and the lanes of a
 //            wave, which hit different digits, still spread over the banks.
-template <int NWAVES, int NBITS, typename E, typename CntRow, typename Load, typename Digit, typename Store>
-__device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load, Digit digit, Store store, bool arank = false, uint64_t *dbg = nullptr)
+//   counted  the caller has zeroed the counters and counted already: cnt[digit * (NWAVES + 1) + i / radix_seg<NWAVES>(n)] for every
+//            input index i (it had the digits in hand: one pass over the input less)
+//   hook(j, e)  called for every element with the output index it was stored at (e.g. to count the NEXT pass's digits)
+struct RadixNoHook { __device__ __forceinline__ void operator()(uint32_t, uint32_t) const {} };
+template <int NWAVES> __device__ __forceinline__ uint32_t radix_seg(uint32_t n) { return ((n + (uint32_t)(NWAVES * 64) - 1u) / (uint32_t)(NWAVES * 64)) * 64u; }
+template <int NWAVES, int NBITS, typename E, typename CntRow, typename Load, typename Digit, typename Store, typename Hook = RadixNoHook>
+__device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load, Digit digit, Store store, bool arank = false, uint64_t *dbg = nullptr,
+                                           bool counted = false, Hook hook = Hook())
 {
     long long tk_ = dbg ? clock64() : 0;
 #define RP_TICK(k) do { if (dbg && threadIdx.x == 0) { long long t2 = clock64(); atomicAdd((unsigned long long *)&dbg[k], (unsigned long long)(t2 - tk_)); tk_ = t2; } } while (0)
@@ -188,16 +194,18 @@ __device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t seg = ((n + (uint32_t)NT - 1u) / (uint32_t)NT) * 64u;
     const uint32_t a = wave * seg, b = (a + seg < n) ? a + seg : n;
-    for (int i = tid; i < ND * ST; i += NT) cnt[i] = 0;
-    __syncthreads();
-    // four elements per lane and step: their (dependent) key lookups are in flight together — at 4 waves per SIMD a pass is
-    // a chain of LDS round trips, not a stream of instructions
-    for (uint32_t i = a + lane; i < b; i += 256) {
-        uint32_t dg[4];
+    if (!counted) {
+        for (int i = tid; i < ND * ST; i += NT) cnt[i] = 0;
+        __syncthreads();
+        // four elements per lane and step: their (dependent) key lookups are in flight together — at 4 waves per SIMD a pass is
+        // a chain of LDS round trips, not a stream of instructions
+        for (uint32_t i = a + lane; i < b; i += 256) {
+            uint32_t dg[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) dg[u] = (i + 64u * u < b) ? digit(load(i + 64u * u)) : 0u;
+            for (int u = 0; u < 4; ++u) dg[u] = (i + 64u * u < b) ? digit(load(i + 64u * u)) : 0u;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) if (i + 64u * u < b) atomicAdd(&cnt[dg[u] * ST + wave], 1u);
+            for (int u = 0; u < 4; ++u) if (i + 64u * u < b) atomicAdd(&cnt[dg[u] * ST + wave], 1u);
+        }
     }
     __syncthreads();
     RP_TICK(8);
@@ -235,7 +243,7 @@ __device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load,
 #pragma unroll
             for (int u = 0; u < 4; ++u) sl[u] = (i + 64u * u < b) ? atomicAdd(&cnt[dg[u] * ST + wave], 1u) : 0u;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) if (i + 64u * u < b) store(sl[u], ee[u]);
+            for (int u = 0; u < 4; ++u) if (i + 64u * u < b) { store(sl[u], ee[u]); hook(sl[u], (uint32_t)ee[u]); }
         }
         __syncthreads();
         RP_TICK(10);
@@ -265,7 +273,7 @@ __device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load,
         uint32_t old = 0;
         if (valid && lane == leader) old = atomicAdd(&cnt[d * ST + wave], num);
         old = __shfl(old, leader < 0 ? 0 : leader);
-        if (valid) store(old + rank, e);
+        if (valid) { store(old + rank, e); hook(old + rank, (uint32_t)e); }
     }
     __syncthreads();
     RP_TICK(10);
