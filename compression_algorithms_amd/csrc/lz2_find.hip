@@ -183,7 +183,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     uint32_t *const cntB = &s_cntB[0][0];
     constexpr uint32_t RST = LZ2_NWAVES + 1;                                        // counter stride of radix_pass
     const uint32_t seg = radix_seg<LZ2_NWAVES>(m), seg_inv = (uint32_t)((0x100000000ull + seg - 1u) / seg);   // i / seg = umulhi(i, seg_inv) for i < 2^16
-    if (!three) for (uint32_t i = tid; i < 256u * RST; i += LZ2_THREADS) { cntA[i] = 0; cntB[i] = 0; }
+    for (uint32_t i = tid; i < 256u * RST; i += LZ2_THREADS) { cntA[i] = 0; cntB[i] = 0; }
 
     // ---- gather: positions (coalesced) and their words (4 unaligned bytes each from the block; bytes
     //      past the block end read as zero, the parity definition of the reference's over-read)
@@ -227,7 +227,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
                 // value identifies the word: keep it instead of the word — the home is a mask away, equality is equality
                 const uint32_t mx = lz_mix32(w);
                 s_word[j] = mx;
-                if (!three) atomicAdd(&cntA[(((((mx & Tmask) - base) & Tmask) - plo_) & 255u) * RST + __umulhi(j, seg_inv)], 1u);
+                atomicAdd(&cntA[(((((mx & Tmask) - base) & Tmask) - plo_) & 255u) * RST + __umulhi(j, seg_inv)], 1u);
             }
         }
     }
@@ -243,11 +243,14 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     uint16_t *srt = s_j0;                                   // where the home order ends up
     if (three) {
         radix_pass<LZ2_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return i; },
-            [&](uint32_t e) { return keyp(e) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; }, arank);
-        radix_pass<LZ2_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return (uint32_t)s_j0[i]; },
-            [&](uint32_t e) { return (keyp(e) >> 8) & 255u; }, [&](uint32_t d, uint32_t e) { s_j1[d] = (uint16_t)e; }, arank);
+            [&](uint32_t e) { return keyp(e) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; }, arank, nullptr, true,
+            [&](uint32_t d, uint32_t e) { atomicAdd(&cntB[((keyp(e) >> 8) & 255u) * RST + __umulhi(d, seg_inv)], 1u); });
+        for (uint32_t i = tid; i < 256u * RST; i += LZ2_THREADS) cntA[i] = 0;         // (the next pass opens with a barrier)
+        radix_pass<LZ2_NWAVES, 8, uint32_t>(m, s_cntB, [&](uint32_t i) { return (uint32_t)s_j0[i]; },
+            [&](uint32_t e) { return (keyp(e) >> 8) & 255u; }, [&](uint32_t d, uint32_t e) { s_j1[d] = (uint16_t)e; }, arank, nullptr, true,
+            [&](uint32_t d, uint32_t e) { atomicAdd(&cntA[((keyp(e) >> 16) & 255u) * RST + __umulhi(d, seg_inv)], 1u); });
         radix_pass<LZ2_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return (uint32_t)s_j1[i]; },
-            [&](uint32_t e) { return (keyp(e) >> 16) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; }, arank);
+            [&](uint32_t e) { return (keyp(e) >> 16) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; }, arank, nullptr, true);
     } else {
         radix_pass<LZ2_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return i; },
             [&](uint32_t e) { return keyp(e) & 255u; }, [&](uint32_t d, uint32_t e) { s_j1[d] = (uint16_t)e; }, arank, sc.dbg, true,
