@@ -312,8 +312,9 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     __shared__ uint32_t s_key[LZS_CAP];                 // mix32(word) by event index j; later cand_i (u16, replay order)
     __shared__ uint32_t s_c[LZS_CAP];                   // coordinate - part_lo | CF_OLD | CF_DEAD by j; later e_key (replay order)
     __shared__ uint16_t s_j0[LZS_CAP], s_j1[LZS_CAP];   // sort ping-pong; later e_rf / the replay order -> j
-    __shared__ uint16_t s_g[LZS_CAP];                   // cluster number by j; later occ
-    __shared__ uint16_t s_r[LZS_CAP];                   // slot index by j; later e_slot (replay order)
+    __shared__ __attribute__((aligned(16))) uint16_t s_gr[2 * LZS_CAP];   // s_g | s_r; during the sort: the counters of every other pass
+    uint16_t *const s_g = s_gr;                          // cluster number by j; later occ
+    uint16_t *const s_r = s_gr + LZS_CAP;                // slot index by j; later e_slot (replay order)
     __shared__ uint32_t s_cnt[LZS_NWAVES + 1][256];     // radix counters; later cluster cursors (u16, rows 0..7) and the wave list (row 8)
     __shared__ int32_t  s_i32[18];
     __shared__ uint64_t s_u64[18];
@@ -345,6 +346,14 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     const bool arank = (P.flags & LZP_ARANK) != 0;
     constexpr uint32_t CH = LZS_CAP / LZS_THREADS;
 
+    // the sort's digits are counted where they are in hand (k_lz2_find): the first pass's here, while the coordinates are put
+    // together, each later pass's while the one before it scatters; the second counter array sits in the idle s_g / s_r
+    uint32_t *const cntA = &s_cnt[0][0];
+    uint32_t (*const s_cntB)[256] = reinterpret_cast<uint32_t (*)[256]>(s_gr);
+    uint32_t *const cntB = &s_cntB[0][0];
+    constexpr uint32_t RST = LZS_NWAVES + 1;
+    const uint32_t seg = radix_seg<LZS_NWAVES>(m), seg_inv = (uint32_t)((0x100000000ull + seg - 1u) / seg);
+    for (uint32_t i = tid; i < 256u * RST; i += LZS_THREADS) { cntA[i] = 0; cntB[i] = 0; }
     // ---- gather: event ids (coalesced), then keys and slots of all of a thread's events together
     {
         uint32_t ge[CH], gk[CH], gs[CH];
@@ -359,12 +368,15 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
                 else gk[c] = key_new[t];
             }
         }
+        __syncthreads();                                    // the counters are zero (the loads above are in flight across it)
 #pragma unroll
         for (uint32_t c = 0; c < CH; ++c) {
             const uint32_t j = tid + c * LZS_THREADS;
             if (j < m) {
                 s_key[j] = gk[c];
-                s_c[j] = (ge[c] & 1u) ? (((gs[c] & ~LZS_DEAD) - plo) | CF_OLD | ((gs[c] & LZS_DEAD) ? CF_DEAD : 0u)) : ((gk[c] & Tmask) - plo);
+                const uint32_t cv = (ge[c] & 1u) ? (((gs[c] & ~LZS_DEAD) - plo) | CF_OLD | ((gs[c] & LZS_DEAD) ? CF_DEAD : 0u)) : ((gk[c] & Tmask) - plo);
+                s_c[j] = cv;
+                atomicAdd(&cntA[(cv & 255u) * RST + __umulhi(j, seg_inv)], 1u);
             }
         }
     }
@@ -376,16 +388,20 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     // ---- stable sort of the event indices by coordinate: 8-bit passes over 16 or 24 bits -> s_j0
     if (phi - plo > 65536u) {
         radix_pass<LZS_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return i; },
-            [&](uint32_t e) { return keyp(e) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; }, arank);
-        radix_pass<LZS_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return (uint32_t)s_j0[i]; },
-            [&](uint32_t e) { return (keyp(e) >> 8) & 255u; }, [&](uint32_t d, uint32_t e) { s_j1[d] = (uint16_t)e; }, arank);
+            [&](uint32_t e) { return keyp(e) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; }, arank, nullptr, true,
+            [&](uint32_t d, uint32_t e) { atomicAdd(&cntB[((keyp(e) >> 8) & 255u) * RST + __umulhi(d, seg_inv)], 1u); });
+        for (uint32_t i = tid; i < 256u * RST; i += LZS_THREADS) cntA[i] = 0;         // (the next pass opens with a barrier)
+        radix_pass<LZS_NWAVES, 8, uint32_t>(m, s_cntB, [&](uint32_t i) { return (uint32_t)s_j0[i]; },
+            [&](uint32_t e) { return (keyp(e) >> 8) & 255u; }, [&](uint32_t d, uint32_t e) { s_j1[d] = (uint16_t)e; }, arank, nullptr, true,
+            [&](uint32_t d, uint32_t e) { atomicAdd(&cntA[((keyp(e) >> 16) & 255u) * RST + __umulhi(d, seg_inv)], 1u); });
         radix_pass<LZS_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return (uint32_t)s_j1[i]; },
-            [&](uint32_t e) { return (keyp(e) >> 16) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; }, arank);
+            [&](uint32_t e) { return (keyp(e) >> 16) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; }, arank, nullptr, true);
     } else {
         radix_pass<LZS_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return i; },
-            [&](uint32_t e) { return keyp(e) & 255u; }, [&](uint32_t d, uint32_t e) { s_j1[d] = (uint16_t)e; }, arank);
-        radix_pass<LZS_NWAVES, 8, uint32_t>(m, s_cnt, [&](uint32_t i) { return (uint32_t)s_j1[i]; },
-            [&](uint32_t e) { return (keyp(e) >> 8) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; }, arank);
+            [&](uint32_t e) { return keyp(e) & 255u; }, [&](uint32_t d, uint32_t e) { s_j1[d] = (uint16_t)e; }, arank, nullptr, true,
+            [&](uint32_t d, uint32_t e) { atomicAdd(&cntB[((keyp(e) >> 8) & 255u) * RST + __umulhi(d, seg_inv)], 1u); });
+        radix_pass<LZS_NWAVES, 8, uint32_t>(m, s_cntB, [&](uint32_t i) { return (uint32_t)s_j1[i]; },
+            [&](uint32_t e) { return (keyp(e) >> 8) & 255u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; }, arank, nullptr, true);
     }
 
     LZS_TICK(1);
