@@ -71,6 +71,11 @@ uint32_t *mi_err_slot(mi_ctx *ctx, hipStream_t s);
 extern "C" mi_status mi_validate_block_table(const uint64_t *h_block_bits, uint64_t nblocks, uint64_t stream_bytes, uint32_t align_bits);
 // the context's own stream for the host-buffer entry points, created on first use
 hipStream_t mi_host_stream(mi_ctx *ctx);
+// the block decoders without their closing status read (lz_emit.hip, defh.hip): host_api.hip launches one per chunk
+mi_status mi_lz_decode_launch(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_stream, uint64_t stream_bytes,
+                              const uint64_t *d_block_bits, uint8_t *d_out, uint64_t n, uint32_t *err, hipStream_t s);
+mi_status mi_deflate_h_decode_launch(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_stream, uint64_t stream_bytes,
+                                     const uint64_t *d_block_bits, uint8_t *d_out, uint64_t n, uint32_t *err, hipStream_t s);
 
 // profiling: bracket a launch with events on the launch stream
 struct mi_prof_scope {

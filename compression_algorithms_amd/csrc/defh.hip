@@ -340,19 +340,17 @@ extern "C" uint64_t mi_deflate_h_bound_bytes(uint64_t n, const mi_lz_params *p)
     return (nblocks ? (nblocks - 1) * rec(block) + rec(last) : 0) + 64;
 }
 
-extern "C" mi_status mi_deflate_h_decode_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_stream, uint64_t stream_bytes,
-                                             const uint64_t *d_block_bits, uint8_t *d_out, uint64_t n, void *stream)
+// launch alone: errors accumulate in *err (an mi_err_slot the caller reads once everything it launched has run)
+mi_status mi_deflate_h_decode_launch(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_stream, uint64_t stream_bytes,
+                                     const uint64_t *d_block_bits, uint8_t *d_out, uint64_t n, uint32_t *err, hipStream_t s)
 {
-    if (!ctx || !d_stream || !d_block_bits || (n && !d_out)) return MI_ERR_ARG;
+    if (!ctx || !d_stream || !d_block_bits || (n && !d_out) || !err) return MI_ERR_ARG;
     mi_status st = lz_check_params(p);
     if (st) return st;
     if (!p->deflate || p->lbits > 5 || p->wbits > 16 || ((uintptr_t)d_stream & 3u)) return MI_ERR_ARG;
     if (n == 0) return MI_OK;
-    hipStream_t s = (hipStream_t)stream;
     const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block, ctx->lds_rank_ok ? LZP_ARANK : 0u};
     const uint64_t nblocks = (n + P.block - 1) / P.block;
-    uint32_t *err = mi_err_slot(ctx, s);
-    if (!err) return MI_ERR_HIP;
     {
         mi_prof_scope pr(ctx, "k_defh_decode", s, n);
         // a 4 KiB ring whatever the window (lz_decode.h): far matches read the output buffer
@@ -365,6 +363,22 @@ extern "C" mi_status mi_deflate_h_decode_dev(mi_ctx *ctx, const mi_lz_params *p,
         else if (need <= 32768u || want <= 32768u) hipLaunchKernelGGL(k_defh_decode<32768u>, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, stream_bytes, d_block_bits, P, d_out, n, err);
         else hipLaunchKernelGGL(k_defh_decode<65536u>, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, stream_bytes, d_block_bits, P, d_out, n, err);
     }
+    return hipGetLastError() == hipSuccess ? MI_OK : MI_ERR_HIP;
+}
+
+extern "C" mi_status mi_deflate_h_decode_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_stream, uint64_t stream_bytes,
+                                             const uint64_t *d_block_bits, uint8_t *d_out, uint64_t n, void *stream)
+{
+    if (!ctx || !d_stream || !d_block_bits || (n && !d_out)) return MI_ERR_ARG;
+    mi_status st = lz_check_params(p);
+    if (st) return st;
+    if (!p->deflate || p->lbits > 5 || p->wbits > 16 || ((uintptr_t)d_stream & 3u)) return MI_ERR_ARG;
+    if (n == 0) return MI_OK;
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t *err = mi_err_slot(ctx, s);
+    if (!err) return MI_ERR_HIP;
+    st = mi_deflate_h_decode_launch(ctx, p, d_stream, stream_bytes, d_block_bits, d_out, n, err, s);
+    if (st) return st;
     uint32_t h_err = 0;
     MI_HIP(ctx, hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, s));
     MI_HIP(ctx, hipStreamSynchronize(s));

@@ -99,6 +99,101 @@ mi_status mi_encode_host_pipelined(mi_ctx *ctx, const mi_lz_params *p, int mode_
     return st;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The way back, every block format: the stream goes up and the bytes come down in chunks of whole blocks while the GPU decodes
+// the chunks between them.  The device buffers are whole (stream, table, output) — a chunk's kernel gets the table from its own
+// first block on and the output from its own first byte on; the table's bit offsets stay absolute — so there is nothing to
+// recycle.  A decoder wave is one block and the chip wants ~8 000 of them in flight, so chunks are launched AHEAD chunks before
+// their bytes are fetched, on AHEAD streams (kernels of neighbouring chunks overlap: one stream alone ran them one after the
+// other and mode H gained nothing).  Host order per chunk c: upload(c + AHEAD), launch(c + AHEAD), download(c) — pageable
+// copies block the calling thread, and the GPU has AHEAD chunks to decode while they do.
+// MI_HOST_DECODE_CHUNK_BLOCKS sets the chunk, MI_HOST_DECODE_AHEAD the look-ahead (1..4); tests use small chunks.  10^9 bytes of
+// output, ms one shot -> chunks of 4096 ahead 2: lz77 tokens 65 -> 52, deflate tokens 64 -> 41 (2 GB over the link: it is the
+// copies now), mode H 85 -> 78 (2048 x 3: 57 / 44 / 80; 1024 x 4: 71 / 56 / 100; scripts/ab_hostdec.sh).
+// ---------------------------------------------------------------------------------------------------------------------
+static uint64_t host_decode_chunk_blocks()
+{
+    const char *e = getenv("MI_HOST_DECODE_CHUNK_BLOCKS");
+    long v = e ? atol(e) : 4096;
+    if (v < 1) v = 1;
+    return (uint64_t)v;
+}
+static uint32_t host_decode_ahead()
+{
+    const char *e = getenv("MI_HOST_DECODE_AHEAD");
+    long v = e ? atol(e) : 2;
+    return (uint32_t)(v < 1 ? 1 : v > 4 ? 4 : v);
+}
+
+static mi_status mi_decode_host_pipelined(mi_ctx *ctx, const mi_lz_params *p, int mode_h, const uint8_t *h_stream, uint64_t stream_bytes,
+                                          const uint64_t *h_block_bits, uint8_t *h_out, uint64_t n, bool *done)
+{
+    *done = false;
+    constexpr uint32_t NE = 8;                                                                    // events in rotation (> AHEAD)
+    const uint64_t cb = host_decode_chunk_blocks(), C = cb * (uint64_t)p->block;
+    const uint32_t AHEAD = host_decode_ahead();
+    const uint64_t nblocks = (n + p->block - 1) / p->block;
+    if (nblocks <= cb) return MI_OK;                                                              // the caller's one-shot path
+    const uint64_t nchunks = (nblocks + cb - 1) / cb;
+    hipStream_t s = mi_host_stream(ctx), cin = nullptr, cout = nullptr, sx[4] = {s, nullptr, nullptr, nullptr};
+    hipEvent_t ev_in[NE] = {}, ev_dec[NE] = {}, ev_setup = nullptr;
+    DevBuf st_, bits, out;
+    if (!st_.alloc(stream_bytes + 64) || !bits.alloc((nblocks + 1) * 8) || !out.alloc(n + 16)) return MI_ERR_NOMEM;
+    bool ok = hipStreamCreateWithFlags(&cin, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&cout, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&ev_setup, hipEventDisableTiming) == hipSuccess;
+    for (uint32_t k = 1; k < AHEAD && ok; ++k) ok = hipStreamCreateWithFlags(&sx[k], hipStreamNonBlocking) == hipSuccess;
+    for (uint32_t b = 0; b < NE && ok; ++b)
+        ok = hipEventCreateWithFlags(&ev_in[b], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ev_dec[b], hipEventDisableTiming) == hipSuccess;
+    mi_status st = ok ? MI_OK : MI_ERR_HIP;
+    uint32_t *err = nullptr;
+    if (st == MI_OK) {
+        ok = hipMemsetAsync(st_.as<uint8_t>() + stream_bytes, 0, 64, s) == hipSuccess &&
+             hipMemcpyAsync(bits.p, h_block_bits, (nblocks + 1) * 8, hipMemcpyHostToDevice, s) == hipSuccess;
+        err = ok ? mi_err_slot(ctx, s) : nullptr;
+        if (!err || hipEventRecord(ev_setup, s) != hipSuccess) st = MI_ERR_HIP;
+        for (uint32_t k = 1; k < AHEAD && st == MI_OK; ++k)                                       // table and status word first
+            if (hipStreamWaitEvent(sx[k], ev_setup, 0) != hipSuccess) st = MI_ERR_HIP;
+    }
+    // stream bytes [lo, hi) of chunk c: from where the chunk before stopped to the dword that holds the chunk's last bit
+    // (the readers fetch aligned dwords, lz_decode.h)
+    auto stream_end = [&](uint64_t c) -> uint64_t {
+        if (c + 1 >= nchunks) return stream_bytes;
+        const uint64_t e = (((h_block_bits[(c + 1) * cb] + 7) >> 3) + 3) & ~3ull;
+        return e < stream_bytes ? e : stream_bytes;
+    };
+    auto chunk_len = [&](uint64_t c) -> uint64_t { return (c + 1 < nchunks) ? C : n - c * C; };
+    auto upload_launch = [&](uint64_t c) -> mi_status {
+        const uint64_t lo = c ? stream_end(c - 1) : 0, hi = stream_end(c);
+        hipStream_t sc = sx[c % AHEAD];
+        if (hi > lo && hipMemcpyAsync(st_.as<uint8_t>() + lo, h_stream + lo, hi - lo, hipMemcpyHostToDevice, cin) != hipSuccess) return MI_ERR_HIP;
+        if (hipEventRecord(ev_in[c % NE], cin) != hipSuccess || hipStreamWaitEvent(sc, ev_in[c % NE], 0) != hipSuccess) return MI_ERR_HIP;
+        const mi_status e = mode_h ? mi_deflate_h_decode_launch(ctx, p, st_.as<uint8_t>(), stream_bytes, bits.as<uint64_t>() + c * cb, out.as<uint8_t>() + c * C, chunk_len(c), err, sc)
+                                   : mi_lz_decode_launch(ctx, p, st_.as<uint8_t>(), stream_bytes, bits.as<uint64_t>() + c * cb, out.as<uint8_t>() + c * C, chunk_len(c), err, sc);
+        if (e) return e;
+        return hipEventRecord(ev_dec[c % NE], sc) == hipSuccess ? MI_OK : MI_ERR_HIP;
+    };
+    for (uint64_t c = 0; c < AHEAD && c < nchunks && st == MI_OK; ++c) st = upload_launch(c);
+    for (uint64_t c = 0; c < nchunks && st == MI_OK; ++c) {
+        if (c + AHEAD < nchunks) { st = upload_launch(c + AHEAD); if (st) break; }
+        if (hipStreamWaitEvent(cout, ev_dec[c % NE], 0) != hipSuccess ||
+            hipMemcpyAsync(h_out + c * C, out.as<uint8_t>() + c * C, chunk_len(c), hipMemcpyDeviceToHost, cout) != hipSuccess) { st = MI_ERR_HIP; break; }
+    }
+    // nothing may outlive the buffers: drain every stream whatever happened
+    if (cin) (void)hipStreamSynchronize(cin);
+    for (uint32_t k = 0; k < 4; ++k) if (k == 0 || sx[k]) (void)hipStreamSynchronize(sx[k]);
+    if (cout) (void)hipStreamSynchronize(cout);
+    uint32_t h_err = 0;
+    if (st == MI_OK && hipMemcpy(&h_err, err, 4, hipMemcpyDeviceToHost) != hipSuccess) st = MI_ERR_HIP;
+    for (uint32_t b = 0; b < NE; ++b) { if (ev_in[b]) (void)hipEventDestroy(ev_in[b]); if (ev_dec[b]) (void)hipEventDestroy(ev_dec[b]); }
+    if (ev_setup) (void)hipEventDestroy(ev_setup);
+    if (cin) (void)hipStreamDestroy(cin);
+    if (cout) (void)hipStreamDestroy(cout);
+    for (uint32_t k = 1; k < 4; ++k) if (sx[k]) (void)hipStreamDestroy(sx[k]);
+    if (st == MI_OK && h_err) st = MI_ERR_CORRUPT;       // (the caller's buffer may hold the chunks that came down before the bad one)
+    if (st == MI_OK) *done = true;
+    return st;
+}
+
 extern "C" mi_status mi_huffman_encode2(mi_ctx *ctx, const uint8_t *h_in, uint64_t n, uint32_t *h_words, uint64_t cap_words,
                                         mi_huffman_info *h_info, mi_huffman_tree *h_tree, uint64_t *h_tile_off)
 {
@@ -210,6 +305,11 @@ extern "C" mi_status mi_lz_decode(mi_ctx *ctx, const mi_lz_params *p, const uint
     // the table indexes the stream: check it before anything is copied or launched
     mi_status st = mi_validate_block_table(h_block_bits, nblocks, stream_bytes, p->deflate ? 8u : 1u);
     if (st) return st;
+    {
+        bool done = false;
+        st = mi_decode_host_pipelined(ctx, p, 0, h_stream, stream_bytes, h_block_bits, h_out, n, &done);
+        if (st || done) return st;
+    }
     DevBuf st_, bits, out;
     if (!st_.alloc(stream_bytes + 64) || !bits.alloc((nblocks + 1) * 8) || !out.alloc(n + 16)) return MI_ERR_NOMEM;
     MI_HIP(ctx, hipMemsetAsync(st_.as<uint8_t>() + stream_bytes, 0, 64, s));
@@ -254,6 +354,11 @@ extern "C" mi_status mi_deflate_h_decode(mi_ctx *ctx, const mi_lz_params *p, con
     const uint64_t nblocks = (n + p->block - 1) / p->block;
     mi_status st = mi_validate_block_table(h_block_bits, nblocks, stream_bytes, 32u);
     if (st) return st;
+    {
+        bool done = false;
+        st = mi_decode_host_pipelined(ctx, p, 1, h_stream, stream_bytes, h_block_bits, h_out, n, &done);
+        if (st || done) return st;
+    }
     DevBuf st_, bits, out;
     if (!st_.alloc(stream_bytes + 64) || !bits.alloc((nblocks + 1) * 8) || !out.alloc(n + 16)) return MI_ERR_NOMEM;
     MI_HIP(ctx, hipMemsetAsync(st_.as<uint8_t>() + stream_bytes, 0, 64, s));

@@ -8,8 +8,8 @@
 // One wave per block.  Round 1's decoder fetched every token with its own global load (two dependent ~1 µs round trips per
 // token, 443 ms per 10^9 bytes); here a wave keeps 64 stream dwords in one register per lane, reads them with v_readlane,
 // and — for the byte format — classifies 64 two-byte units at once: a ballot marks the units that open a match, a run of
-// literal units between two of them is ONE parallel LDS store.  The output lives in an LDS ring of the window's size
-// (lz_decode.h), so up to five waves share a CU instead of two.
+// literal units between two of them is ONE parallel LDS store.  The output passes through a small LDS ring (lz_decode.h: 8 KiB
+// by default, far matches read the output buffer), so the wave slots, not the LDS, bound how many blocks share a CU.
 #include "lz_decode.h"
 #include <stdlib.h>
 

@@ -670,6 +670,21 @@ extern "C" mi_status mi_lz_encode(mi_ctx *ctx, const mi_lz_params *p, const uint
     return st;
 }
 
+// launch alone: errors accumulate in *err (an mi_err_slot the caller reads once everything it launched has run)
+mi_status mi_lz_decode_launch(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_stream, uint64_t stream_bytes,
+                              const uint64_t *d_block_bits, uint8_t *d_out, uint64_t n, uint32_t *err, hipStream_t s)
+{
+    if (!ctx || !d_stream || !d_block_bits || (n && !d_out) || !err) return MI_ERR_ARG;
+    mi_status st = lz_check_params(p);
+    if (st) return st;
+    if (n == 0) return MI_OK;
+    const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block, ctx->lds_rank_ok ? LZP_ARANK : 0u};
+    const uint64_t nblocks = (n + P.block - 1) / P.block;
+    mi_prof_scope pr(ctx, "k_lz_decode", s, n);
+    lz_launch_decode(d_stream, stream_bytes, d_block_bits, P, d_out, n, nblocks, err, s);       // any block size
+    return hipGetLastError() == hipSuccess ? MI_OK : MI_ERR_HIP;
+}
+
 extern "C" mi_status mi_lz_decode_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_stream, uint64_t stream_bytes,
                                       const uint64_t *d_block_bits, uint8_t *d_out, uint64_t n, void *stream)
 {
@@ -678,14 +693,10 @@ extern "C" mi_status mi_lz_decode_dev(mi_ctx *ctx, const mi_lz_params *p, const 
     if (st) return st;
     if (n == 0) return MI_OK;
     hipStream_t s = (hipStream_t)stream;
-    const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block, ctx->lds_rank_ok ? LZP_ARANK : 0u};
-    const uint64_t nblocks = (n + P.block - 1) / P.block;
     uint32_t *err = mi_err_slot(ctx, s);
     if (!err) return MI_ERR_HIP;
-    {
-        mi_prof_scope pr(ctx, "k_lz_decode", s, n);
-        lz_launch_decode(d_stream, stream_bytes, d_block_bits, P, d_out, n, nblocks, err, s);       // any block size
-    }
+    st = mi_lz_decode_launch(ctx, p, d_stream, stream_bytes, d_block_bits, d_out, n, err, s);
+    if (st) return st;
     uint32_t h_err = 0;
     MI_HIP(ctx, hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, s));
     MI_HIP(ctx, hipStreamSynchronize(s));

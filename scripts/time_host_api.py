@@ -29,3 +29,22 @@ for name, p, fn, bound in [("deflate tokens (mi_lz_encode)", lz.params("deflate"
         _lib.check(st, name)
         best = min(best, dt)
     print(f"{name}: {n / best / 1e9:.2f} GB/s ({best * 1e3:.1f} ms for {n} bytes -> {int(bits[-1]) // 8} bytes)")
+
+# the way back: host stream in, host bytes out (what the drop-in decompress() calls)
+for name, p, enc_fn, dec_fn in [("lz77 tokens (mi_lz_decode)", lz.params("lz77"), lz.compress, ctx.L.mi_lz_decode),
+                                ("deflate tokens (mi_lz_decode)", lz.params("deflate"), lz.compress, ctx.L.mi_lz_decode),
+                                ("mode H (mi_deflate_h_decode)", lz.params("deflate"), lz.compress_h, ctx.L.mi_deflate_h_decode)]:
+    enc = enc_fn(x, p)
+    bits = np.ascontiguousarray(enc.block_bits.cpu().numpy().astype(np.uint64))
+    stream = np.frombuffer(enc.tobytes(), dtype=np.uint8).copy()
+    del enc
+    out = np.empty(n, np.uint8)
+    best = 1e9
+    for rep in range(3):
+        t0 = time.perf_counter()
+        st = dec_fn(ctx.h, C.byref(p), C.c_void_p(stream.ctypes.data), C.c_uint64(len(stream)), C.c_void_p(bits.ctypes.data), C.c_void_p(out.ctypes.data), C.c_uint64(n))
+        dt = time.perf_counter() - t0
+        _lib.check(st, name)
+        best = min(best, dt)
+    assert np.array_equal(out, x)
+    print(f"{name}: {n / best / 1e9:.2f} GB/s of output ({best * 1e3:.1f} ms, {len(stream)} stream bytes -> {n})")

@@ -381,3 +381,34 @@ def test_host_buffer_encoders_in_chunks(mode_h, chunk_blocks, n, monkeypatch):
     small = np.zeros(len(ref_bytes) // 2, np.uint8)
     rc = fn(ctx.h, C.byref(p), C.c_void_p(data.ctypes.data), C.c_uint64(n), C.c_void_p(small.ctypes.data), C.c_uint64(len(small)), C.c_void_p(bits.ctypes.data))
     assert rc == 4                                                      # MI_ERR_CAPACITY
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["lz77", "deflate", "mode_h"])
+@pytest.mark.parametrize("chunk_blocks,n", [(3, 1_000_001), (1, 200_000), (4, 4 * 65536 * 3), (7, 65536 * 7 + 1)])
+def test_host_buffer_decoders_in_chunks(fmt, chunk_blocks, n, monkeypatch):
+    """mi_lz_decode / mi_deflate_h_decode on host buffers of more blocks than a chunk: the stream goes up and the bytes come
+    down chunk by chunk around the decoder (host_api.hip).  The lz77 flavour's chunks end in the middle of a byte."""
+    import ctypes as C
+    from compression_algorithms_amd import lz, synth
+    from compression_algorithms_amd.context import default_context
+    ctx = default_context()
+    data = synth.enwik_like(n, seed=92).numpy()
+    p = lz.params("lz77" if fmt == "lz77" else "deflate")
+    enc = lz.compress_h(data, p) if fmt == "mode_h" else lz.compress(data, p)
+    bits = np.ascontiguousarray(enc.block_bits.cpu().numpy().astype(np.uint64))
+    stream = np.frombuffer(enc.tobytes(), dtype=np.uint8).copy()
+    monkeypatch.setenv("MI_HOST_DECODE_CHUNK_BLOCKS", str(chunk_blocks))
+    fn = ctx.L.mi_deflate_h_decode if fmt == "mode_h" else ctx.L.mi_lz_decode
+    out = np.zeros(n, np.uint8)
+    rc = fn(ctx.h, C.byref(p), C.c_void_p(stream.ctypes.data), C.c_uint64(len(stream)), C.c_void_p(bits.ctypes.data), C.c_void_p(out.ctypes.data), C.c_uint64(n))
+    assert rc == 0
+    assert np.array_equal(out, data)
+    # a damaged block in a middle chunk: the call reports it (a literal flag turned into a match that reaches before the block)
+    if fmt == "deflate":
+        bad = stream.copy()
+        mid = (len(bits) - 1) // 2
+        o = int(bits[mid]) // 8
+        bad[o:o + 4] = [1, 0xFF, 0xFF, 8]                                  # match of distance 65535 as the block's first token
+        rc = fn(ctx.h, C.byref(p), C.c_void_p(bad.ctypes.data), C.c_uint64(len(bad)), C.c_void_p(bits.ctypes.data), C.c_void_p(out.ctypes.data), C.c_uint64(n))
+        assert rc == 8                                                      # MI_ERR_CORRUPT
