@@ -20,7 +20,8 @@ line also carries
                   deflate/deflate.c:47-63) on a sample,
     roundtrip     decode(encode(x)) == x, checked once outside the timed region,
     decode_gbps   this rank's decoder on its last stream (one call incl. its synchronisation, outside the timed region),
-    end_to_end    the same bytes through the host-buffer entry point of the drop-in (PCIe inclusive; never `value`).
+    end_to_end    the same bytes through the host-buffer entry point of the drop-in (PCIe inclusive; never `value`);
+                  `decode_gbps` inside it = the way back through the host-buffer decoder, bytes of output per second.
 
 N > 1, --scaling weak (default): every rank encodes its own --bytes shard of independent blocks.
 N > 1, --scaling strong: ONE --bytes buffer (enwik9's size by default); rank r encodes the contiguous block range
@@ -449,7 +450,21 @@ def main():
                     extras["end_to_end"] = {"value": round(n / min(t_e2e[1:]) / 1e9, 3), "unit": "GB/s", "bytes": n,
                                             "what": "pageable host buffer -> mi_deflate_h_encode / mi_lz_encode (the drop-in's entry point: chunked H2D, encode, "
                                                     "chunked D2H of stream and block table) -> host buffer; best of 2 after 1 warm-up"}
-                    del xh, outh
+                    # and the way back through the drop-in's decompress() entry point: host stream -> host bytes
+                    dfn = ctx.L.mi_deflate_h_decode if mode_h else ctx.L.mi_lz_decode
+                    back = np.empty(n, np.uint8)
+                    t_d = []
+                    for it in range(3):
+                        t0 = time.perf_counter()
+                        rc = dfn(ctx.h, C.byref(p_), C.c_void_p(outh.ctypes.data), C.c_uint64(int(bits[-1]) // 8), C.c_void_p(bits.ctypes.data),
+                                 C.c_void_p(back.ctypes.data), C.c_uint64(n))
+                        t_d.append(time.perf_counter() - t0)
+                        if rc != 0:
+                            raise RuntimeError(f"host decode entry point returned {rc}")
+                    if not np.array_equal(back, xh):
+                        raise RuntimeError("host decode entry point returned different bytes")
+                    extras["end_to_end"]["decode_gbps"] = round(n / min(t_d[1:]) / 1e9, 3)
+                    del xh, outh, back
                 else:
                     ne = min(n, 256_000_000)
                     xh = x[:ne].cpu().pin_memory()

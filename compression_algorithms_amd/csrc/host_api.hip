@@ -75,14 +75,17 @@ mi_status mi_encode_host_pipelined(mi_ctx *ctx, const mi_lz_params *p, int mode_
     if (st == MI_OK) st = issue_encode(0);
     for (uint64_t c = 0; c < nchunks && st == MI_OK; ++c) {
         const int b = (int)(c & 1);
-        if (c + 1 < nchunks && !issue_h2d(c + 1)) { st = MI_ERR_HIP; break; }                      // (may block the host: the GPU is encoding chunk c)
+        if (c + 1 < nchunks) {
+            if (!issue_h2d(c + 1)) { st = MI_ERR_HIP; break; }                                     // (may block the host: the GPU is encoding chunk c)
+            st = issue_encode(c + 1);                                                              // queued behind chunk c: no idle GPU while the host reads c's sizes
+            if (st) break;
+        }
         if (hipEventSynchronize(ev_enc[b]) != hipSuccess) { st = MI_ERR_HIP; break; }
         const uint64_t nb = (chunk_len(c) + p->block - 1) / p->block, blk0 = c * cb;
         const uint64_t *cbits = pinned + (size_t)b * (cb + 1);
         for (uint64_t k = 0; k <= nb; ++k) h_block_bits[blk0 + k] = base_bits + cbits[k];
         const uint64_t cbytes = cbits[nb] / 8;                                                     // whole bytes: byte tokens / word-aligned records
         if (base_bits / 8 + cbytes > cap_bytes) { st = MI_ERR_CAPACITY; break; }
-        if (c + 1 < nchunks) { st = issue_encode(c + 1); if (st) break; }
         if (cbytes && hipMemcpyAsync(h_out + base_bits / 8, out[b].p, cbytes, hipMemcpyDeviceToHost, cout) != hipSuccess) { st = MI_ERR_HIP; break; }
         if (hipEventRecord(ev_out[b], cout) != hipSuccess) { st = MI_ERR_HIP; break; }
         base_bits += cbits[nb];
