@@ -537,8 +537,13 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
         // replay is through, so the wave that issues them does not stall in front of its share of the replay.
         uint32_t pending_base = 0;
         const bool want_cls = tid < (int)LZ2_NCLASS && s_cls[tid], want_ent = tid == 32 && s_ent;
-        if (want_cls) pending_base = atomicAdd(&sc.big_count[tid], s_cls[tid]);
-        if (want_ent) { pending_base = atomicAdd(&mt->nbig_entries, s_ent); atomicAdd(&mt->nbig, nbig); }
+        // (ONE returning atomic instruction with a per-lane address: on a uniform address the compiler's wave-aggregated
+        // form reads the result back with v_readfirstlane at once — wave 0 then stood ~13 k cycles in front of its replay)
+        if (want_cls || want_ent) {
+            uint32_t *ap = want_ent ? &mt->nbig_entries : &sc.big_count[tid & (int)(LZ2_NCLASS - 1u)];
+            pending_base = atomicAdd(ap, want_ent ? s_ent : s_cls[tid & (int)(LZ2_NCLASS - 1u)]);
+        }
+        if (want_ent) atomicAdd(&mt->nbig, nbig);
         for (uint32_t q = tid >> 6; q < s_nquiet; q += LZ2_NWAVES)
             for (uint32_t k = (uint32_t)s_quiet[2 * q] + (tid & 63u); k < s_quiet[2 * q + 1]; k += 64) {
                 const uint32_t id = e_pid[k];
