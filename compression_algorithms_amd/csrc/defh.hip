@@ -356,7 +356,7 @@ mi_status mi_deflate_h_decode_launch(mi_ctx *ctx, const mi_lz_params *p, const u
         // a 4 KiB ring whatever the window (lz_decode.h): far matches read the output buffer
         const uint32_t W = 1u << P.wbits, need = W < P.block ? W : P.block;
         const char *e = getenv("MI_LZ_DECODE_RING");
-        const uint32_t want = e ? (uint32_t)atoi(e) : (nblocks < 1024u ? need : 4096u);       // (few blocks: lz_decode.hip; 4 KiB: 17 GB/s, 8 KiB: 15, 16 KiB: 12.4)
+        const uint32_t want = e ? (uint32_t)atoi(e) : (nblocks < 1024u ? need : 4096u);       // (few blocks: lz_decode.hip; 4 KiB: 17 GB/s, 8 KiB: 15, 16 KiB: 12.4, 2 KiB: 16.2)
         if (want <= 4096u) hipLaunchKernelGGL(k_defh_decode<4096u>, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, stream_bytes, d_block_bits, P, d_out, n, err);
         else if (want <= 8192u) hipLaunchKernelGGL(k_defh_decode<8192u>, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, stream_bytes, d_block_bits, P, d_out, n, err);
         else if (need <= 16384u || want <= 16384u) hipLaunchKernelGGL(k_defh_decode<16384u>, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, stream_bytes, d_block_bits, P, d_out, n, err);

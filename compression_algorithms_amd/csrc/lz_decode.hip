@@ -145,7 +145,7 @@ void lz_launch_decode(const uint8_t *d_stream, uint64_t stream_bytes, const uint
     const char *e = getenv("MI_LZ_DECODE_RING");
     // few blocks (fewer than the waves a ring of the window's size lets the chip hold): more waves are no use, the far
     // reads only cost (381 blocks of 256 KiB: 5.3 GB/s with the window in the ring, 4.4 with 16 KiB)
-    const uint32_t want = e ? (uint32_t)atoi(e) : (nblocks < 1024u ? need : 8192u);          // 8 KiB: 36 GB/s for byte tokens (16 KiB: 31, 4 KiB: 27)
+    const uint32_t want = e ? (uint32_t)atoi(e) : (nblocks < 1024u ? need : 8192u);          // 8 KiB: 36 GB/s for byte tokens (16 KiB: 31, 4 KiB: 27, 2 KiB: 16)
     if (want <= 4096u) launch_ring<4096u>(d_stream, stream_bytes, d_block_bits, P, d_out, n, nblocks, err, s);
     else if (want <= 8192u) launch_ring<8192u>(d_stream, stream_bytes, d_block_bits, P, d_out, n, nblocks, err, s);
     else if (need <= 16384u || want <= 16384u) launch_ring<16384u>(d_stream, stream_bytes, d_block_bits, P, d_out, n, nblocks, err, s);
