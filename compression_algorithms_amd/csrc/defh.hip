@@ -29,7 +29,9 @@
 #endif
 #define DEFH_PER      4             // tokens per thread per round
 #define DEFH_MAXBITS  44u           // code <= 24 (65536 tokens: Fibonacci bound) + 15 offset bits + 5 length bits
-#define DEFH_LUT_BITS 11
+#ifndef DEFH_LUT_BITS
+#define DEFH_LUT_BITS 9
+#endif
 
 // The reference's array heap (algorithms/huffman/huffman.c:100-163: strict '<' on the frequency in both sifts, leaves
 // enqueued in symbol order, first pop = left).  A heap cell holds frequency << 10 | node id (frequencies are <= 65 536
@@ -235,8 +237,11 @@ void k_defh_decode(const uint8_t *__restrict__ stream, uint64_t stream_bytes, co
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_ring[RING];
     __shared__ uint16_t s_lut[1 << DEFH_LUT_BITS];                     // symbol | length << 9; 0xFFFF = longer than the table
-    __shared__ uint8_t  s_len[DEFH_NSYM + 2];
-    __shared__ uint32_t s_code[DEFH_NSYM + 2], s_count[34], s_next[34];
+    // lengths and codes are only needed while the tables are built: they lie in the (still unused) ring
+    static_assert(RING >= 4u * (DEFH_NSYM + 2) + ((DEFH_NSYM + 2 + 3) & ~3u), "the ring holds the build-time tables");
+    uint32_t *s_code = reinterpret_cast<uint32_t *>(s_ring);
+    uint8_t  *s_len = s_ring + 4u * (DEFH_NSYM + 2);
+    __shared__ uint32_t s_count[34], s_next[34];
     __shared__ uint16_t s_sorted[DEFH_NSYM];                           // symbols by (length, symbol)
     __shared__ uint32_t s_first[34];                                   // index into s_sorted of the first symbol of a length
     const uint32_t lane = threadIdx.x;
