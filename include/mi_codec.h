@@ -202,6 +202,9 @@ mi_status mi_lz_encode(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *h_in, 
 mi_status mi_lz_decode_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_stream, uint64_t stream_bytes,
                            const uint64_t *d_block_bits, uint8_t *d_out, uint64_t n, void *stream);
 
+/* host buffers: the table is validated (mi_validate_block_table) before anything is copied; above one chunk (4 096
+ * blocks) the stream goes up and the bytes come down chunk by chunk around the decoder.  On MI_ERR_CORRUPT h_out may hold
+ * the chunks decoded before the bad block. */
 mi_status mi_lz_decode(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *h_stream, uint64_t stream_bytes,
                        const uint64_t *h_block_bits, uint8_t *h_out, uint64_t n);
 
