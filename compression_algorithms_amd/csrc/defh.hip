@@ -29,6 +29,8 @@
 #endif
 #define DEFH_PER      4             // tokens per thread per round
 #define DEFH_MAXBITS  44u           // code <= 24 (65536 tokens: Fibonacci bound) + 15 offset bits + 5 length bits
+// direct LUT of the decoder: 9 bits = 1 KiB of LDS (more waves per CU beat fewer slow-path symbols: 11 / 10 / 9 / 8 / 7 bits
+// decode 17.8 / 19.2 / 19.5 / 18.6 / 18.6 GB/s); decode-side only, the format does not depend on it
 #ifndef DEFH_LUT_BITS
 #define DEFH_LUT_BITS 9
 #endif
@@ -361,7 +363,7 @@ mi_status mi_deflate_h_decode_launch(mi_ctx *ctx, const mi_lz_params *p, const u
         // a 4 KiB ring whatever the window (lz_decode.h): far matches read the output buffer
         const uint32_t W = 1u << P.wbits, need = W < P.block ? W : P.block;
         const char *e = getenv("MI_LZ_DECODE_RING");
-        const uint32_t want = e ? (uint32_t)atoi(e) : (nblocks < 1024u ? need : 4096u);       // (few blocks: lz_decode.hip; 4 KiB: 17 GB/s, 8 KiB: 15, 16 KiB: 12.4, 2 KiB: 16.2)
+        const uint32_t want = e ? (uint32_t)atoi(e) : (nblocks < 1024u ? need : 4096u);       // (few blocks: lz_decode.hip; with the 11-bit LUT 4 KiB: 17 GB/s, 8 KiB: 15, 16 KiB: 12.4, 2 KiB: 16.2; 9-bit LUT: 19.5 at 4 KiB, 19.7 at 8)
         if (want <= 4096u) hipLaunchKernelGGL(k_defh_decode<4096u>, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, stream_bytes, d_block_bits, P, d_out, n, err);
         else if (want <= 8192u) hipLaunchKernelGGL(k_defh_decode<8192u>, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, stream_bytes, d_block_bits, P, d_out, n, err);
         else if (need <= 16384u || want <= 16384u) hipLaunchKernelGGL(k_defh_decode<16384u>, dim3((unsigned)nblocks), dim3(64), 0, s, d_stream, stream_bytes, d_block_bits, P, d_out, n, err);
