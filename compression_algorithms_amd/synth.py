@@ -5,15 +5,24 @@ The reference's data step (get_data.sh:1-9) downloads enwik9 and derives enwik8/
 same gross structure: a Zipf-distributed vocabulary of pseudo-words
 wrapped in the MediaWiki XML page/revision skeleton with [[links]], '''bold''', &quot;
 entities, == headings == and punctuation.  Like the reference's derived files, a shorter
-buffer is a prefix of a longer one (same seed, same device type).
+buffer is a prefix of a longer one (same seed).
 
 Everything is tensor ops, so a 10^9-byte buffer is produced directly in HBM in well under a
-second; on CPU the same code serves the small test inputs.  CPU and GPU generators give
-different (equally shaped) bytes for one seed — comparisons always use one buffer.
+second; on CPU the same code serves the small test inputs.
+
+Reproducible to the byte: the vocabulary is built once on the CPU; every per-slot draw is a
+counter-based integer hash of (seed, stream, global slot number) compared against INTEGER
+thresholds (the Zipf CDF is summed in float64 on the CPU, scaled to 53-bit integers and looked up
+with searchsorted) — no device floating point, no device random generator, no reduction whose
+order could differ.  One seed therefore gives the same bytes on every run, on the CPU and on the
+GPU alike, whatever `slots_per_chunk` is (tests/test_synth.py, tests/test_determinism_gpu.py).
 """
 import math
 
+import numpy as np
 import torch
+
+_U53 = 1 << 53
 
 _LETTERS = "etaoinshrdlcumwfgypbvkjxqz"
 _V = 20000
@@ -60,10 +69,13 @@ class _Tables:
         self.tok_len = torch.tensor([len(t) for t in toks], dtype=torch.int64)
         self.tok_start = torch.cumsum(self.tok_len, 0) - self.tok_len
         self.flat = torch.frombuffer(bytearray(b"".join(toks)), dtype=torch.uint8).clone()
-        self.zipf = 1.0 / torch.arange(1, _V + 1, dtype=torch.float32)
+        # Zipf (1/rank) CDF, summed in float64 on the CPU, as 53-bit integer thresholds
+        cdf = np.cumsum(1.0 / np.arange(1, _V + 1, dtype=np.float64))
+        self.zipf_thr = torch.from_numpy(np.floor(cdf / cdf[-1] * float(_U53)).astype(np.int64))
         # cumulative thresholds of the decoration variants (SURVEY.md Appendix C proportions)
-        self.var_edges = torch.tensor([0.04, 0.05, 0.06, 0.12, 0.17, 0.175, 0.18])
+        self.var_edges = torch.tensor([int(e * _U53) for e in (0.04, 0.05, 0.06, 0.12, 0.17, 0.175, 0.18)], dtype=torch.int64)
         self.var_ids = torch.tensor([1, 2, 3, 4, 5, 6, 7, 0])
+        self.hdr_thr = _U53 // 1500
 
 
 _TAB = {}
@@ -73,20 +85,46 @@ def _tables(seed, device):
     key = (seed, str(device))
     if key not in _TAB:
         t = _Tables(seed)
-        for name in ("tok_len", "tok_start", "flat", "zipf", "var_edges", "var_ids"):
+        for name in ("tok_len", "tok_start", "flat", "zipf_thr", "var_edges", "var_ids"):
             setattr(t, name, getattr(t, name).to(device))
         _TAB[key] = t
     return _TAB[key]
 
 
-def _chunk(t, n_slots, gen, device):
-    """one chunk of `n_slots` word slots -> uint8 tensor"""
-    word = torch.multinomial(t.zipf, n_slots, replacement=True, generator=gen)
-    r = torch.rand(n_slots, generator=gen, device=device)
-    variant = t.var_ids[torch.bucketize(r, t.var_edges, right=True)]
+def _s64(v):
+    """python int -> the same 64 bits as a signed value (torch has no uint64 arithmetic)"""
+    v &= (1 << 64) - 1
+    return v - (1 << 64) if v >> 63 else v
+
+
+def _lsr(x, k):
+    """logical right shift of an int64 tensor"""
+    return (x >> k) & ((1 << (64 - k)) - 1)
+
+
+def _u53(seed, stream, idx):
+    """counter-based draw: 53 uniform bits per element of the int64 tensor `idx` (splitmix64's finaliser over
+    seed / stream / counter; int64 products wrap identically on the CPU and on the device)"""
+    x = idx * _s64(0x9E3779B97F4A7C15) + _s64((seed * 0xD1342543DE82EF95 + (stream + 1) * 0xA0761D6478BD642F))
+    x = (x ^ _lsr(x, 30)) * _s64(0xBF58476D1CE4E5B9)
+    x = (x ^ _lsr(x, 27)) * _s64(0x94D049BB133111EB)
+    x = x ^ _lsr(x, 31)
+    return _lsr(x, 11)
+
+
+def _zipf(t, u):
+    return torch.clamp(torch.searchsorted(t.zipf_thr, u, right=True), max=_V - 1)
+
+
+def _chunk(t, seed, first_slot, n_slots, device):
+    """word slots [first_slot, first_slot + n_slots) of the corpus of `seed` -> uint8 tensor"""
+    slot = torch.arange(first_slot, first_slot + n_slots, dtype=torch.int64, device=device)
+    word = _zipf(t, _u53(seed, 0, slot))
+    variant = t.var_ids[torch.bucketize(_u53(seed, 1, slot), t.var_edges, right=True)]
     tok = variant * _V + word
-    hdr = torch.rand(n_slots, generator=gen, device=device) < (1.0 / 1500.0)
-    hdr[0] = True
+    hdr = _u53(seed, 2, slot) < t.hdr_thr
+    if first_slot == 0:
+        hdr[0] = True
     H = 13
     count = torch.where(hdr, torch.full_like(word, H), torch.ones_like(word))
     off = torch.cumsum(count, 0) - count
@@ -94,12 +132,12 @@ def _chunk(t, n_slots, gen, device):
     out = torch.empty(total, dtype=torch.int64, device=device)
     out[off[~hdr]] = tok[~hdr]
     ho = off[hdr]
-    nh = ho.numel()
-    rnd = lambda hi: torch.randint(0, hi, (nh,), generator=gen, device=device)
+    hs = slot[hdr]
+    rnd = lambda stream, hi: _u53(seed, stream, hs) % hi
     fb = t.fixed_base
-    seq = [fb + 0, 8 * _V + torch.multinomial(t.zipf, nh, replacement=True, generator=gen),
-           fb + 1, t.num_base + rnd(4096), fb + 2, t.num_base + rnd(4096), fb + 3, t.ts_base + rnd(4096),
-           fb + 4, 8 * _V + rnd(_V), fb + 5, t.num_base + rnd(4096), fb + 6]
+    seq = [fb + 0, 8 * _V + _zipf(t, _u53(seed, 3, hs)),
+           fb + 1, t.num_base + rnd(4, 4096), fb + 2, t.num_base + rnd(5, 4096), fb + 3, t.ts_base + rnd(6, 4096),
+           fb + 4, 8 * _V + rnd(7, _V), fb + 5, t.num_base + rnd(8, 4096), fb + 6]
     for k, v in enumerate(seq):
         out[ho + k] = v
     lens = t.tok_len[out]
@@ -111,17 +149,25 @@ def _chunk(t, n_slots, gen, device):
 
 
 def enwik_like(nbytes, seed=12345, device="cpu", slots_per_chunk=1 << 21):
-    """uint8 tensor of exactly `nbytes` enwik-shaped bytes on `device`."""
+    """uint8 tensor of exactly `nbytes` enwik-shaped bytes on `device`: the same bytes for one seed on every run and
+    every device (module docstring)."""
     device = torch.device(device)
     t = _tables(seed, device)
-    gen = torch.Generator(device=device).manual_seed(seed + 1)
-    parts, have = [], 0
+    parts, have, slot = [], 0, 0
     while have < nbytes:
-        c = _chunk(t, slots_per_chunk, gen, device)
+        c = _chunk(t, seed, slot, slots_per_chunk, device)
+        slot += slots_per_chunk
         parts.append(c)
         have += c.numel()
     out = torch.cat(parts)[:nbytes].contiguous()
     return out
+
+
+def digest(x):
+    """sha256 (first 16 hex digits) of a buffer's bytes — the `input_sha256` field of bench.py's line"""
+    import hashlib
+    a = x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+    return hashlib.sha256(memoryview(np.ascontiguousarray(a))).hexdigest()[:16]
 
 
 def adversarial(kind, n, seed=1):
