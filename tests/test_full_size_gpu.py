@@ -1,0 +1,140 @@
+"""Parity at BASELINE size, checked rather than sampled.
+
+  * the bench input is reproducible: one seed gives one buffer, on the CPU and on the GPU (digest pinned);
+  * two encodes of one buffer give one stream;
+  * config 4, mode T: EVERY one of the 15 259 blocks of 10^9 bytes against the oracle's token bytes
+    (algorithms/deflate/lz77.c:199-280, fresh table per block);
+  * config 4, mode H: EVERY record against oracle/orc_defh.c fed with the oracle's tokens (bit stream parity
+    unpinned: the reference stops at a TODO there, DESIGN.md section 1 — tokens, tally and length procedure are pinned);
+  * config 2 in its real shape: lz77 W = 64 KiB on 256 KiB and 1 MiB blocks, 10^8 bytes, EVERY block against the
+    oracle's bit stream (algorithms/lz77/lz77.c:264-345).
+
+The oracle runs on the host's cores in parallel threads (ctypes releases the GIL; the C restatement is re-entrant).
+"""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+import torch
+
+from compression_algorithms_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+BLOCK = 65536
+N9 = 1_000_000_000
+SEED = 12345
+# sha256[:16] of enwik_like(10^9, seed 12345) — computed on the CPU in the build container, checked on the GPU here and
+# printed by bench.py as config.input_sha256
+DIGEST_1E9 = "fc5b7c102ca0b71b"
+THREADS = max(1, min(16, (os.cpu_count() or 2)))
+
+
+def _pool():
+    return ThreadPoolExecutor(THREADS)
+
+
+@pytest.fixture(scope="module")
+def corpus():
+    x = synth.enwik_like(N9, seed=SEED, device="cuda")
+    return x, x.cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def oracle_tokens(corpus):
+    """the oracle's byte tokens of every block of the corpus, and their sizes (threads over spans of 256 blocks)"""
+    from oracle import orc
+    _, host = corpus
+    span = 256 * BLOCK
+    with _pool() as ex:
+        parts = list(ex.map(lambda at: orc.deflate_stream(host[at:at + span], BLOCK, True), range(0, len(host), span)))
+    sizes = np.concatenate([s for _, s in parts]).astype(np.int64)
+    return parts, sizes
+
+
+def test_generator_is_reproducible_on_the_device(corpus):
+    x, host = corpus
+    assert synth.digest(host) == DIGEST_1E9
+    y = synth.enwik_like(N9, seed=SEED, device="cuda")
+    assert torch.equal(x, y)
+    del y
+    # the CPU generator gives the same bytes
+    assert np.array_equal(synth.enwik_like(5_000_000, seed=SEED).numpy(), host[:5_000_000])
+
+
+def test_mode_t_every_block_of_1e9(corpus, oracle_tokens):
+    from compression_algorithms_amd import lz
+    x, host = corpus
+    parts, sizes = oracle_tokens
+    st = lz.compress(x, lz.params("deflate"))
+    bb = st.block_bits.cpu().numpy()
+    assert len(bb) == 15259 + 1 and bool((bb % 16 == 0).all())
+    assert np.array_equal(np.diff(bb) // 8, sizes)
+    got = st.data[: st.nbytes].cpu().numpy()
+    at = 0
+    for k, (tok, _) in enumerate(parts):
+        assert np.array_equal(got[at:at + len(tok)], tok), f"blocks {256 * k}..{256 * k + 255}"
+        at += len(tok)
+    assert at == st.nbytes
+    # a second encode of the same buffer is the same stream
+    st2 = lz.compress(x, lz.params("deflate"))
+    assert torch.equal(st2.block_bits, st.block_bits) and torch.equal(st2.data[: st.nbytes], st.data[: st.nbytes])
+    del st2
+    assert torch.equal(lz.decompress(st), x)
+
+
+def test_mode_h_every_record_of_1e9(corpus, oracle_tokens):
+    from compression_algorithms_amd import lz
+    from oracle import orc
+    x, host = corpus
+    parts, sizes = oracle_tokens
+    st = lz.compress_h(x)
+    bb = st.block_bits.cpu().numpy()
+    assert len(bb) == 15259 + 1 and bool((bb % 32 == 0).all())
+    got = st.data[: st.nbytes].cpu().numpy()
+
+    def span(k):
+        tok, sz = parts[k]
+        bad, at = [], 0
+        for j, s in enumerate(sz):
+            b = 256 * k + j
+            want = orc.defh_encode_block(tok[at:at + int(s)])
+            at += int(s)
+            if not np.array_equal(got[bb[b] // 8: bb[b + 1] // 8], want):
+                bad.append(b)
+        return bad
+
+    with _pool() as ex:
+        bad = [b for r in ex.map(span, range(len(parts))) for b in r]
+    assert not bad, f"{len(bad)} records differ, first {bad[:8]}"
+    st2 = lz.compress_h(x)
+    assert torch.equal(st2.block_bits, st.block_bits) and torch.equal(st2.data[: st.nbytes], st.data[: st.nbytes])
+    del st2
+    assert torch.equal(lz.decompress_h(st), x)
+
+
+@pytest.mark.parametrize("block", [262144, 1 << 20])
+def test_lz77_sliding_window_every_block_of_1e8(corpus, block):
+    """config 2 as SURVEY 8d words it (W = 64 KiB, blocks above the window: the table evicts): 382 / 96 blocks"""
+    from compression_algorithms_amd import lz
+    from oracle import orc
+    x, host = corpus
+    n = 100_000_000
+    p = lz.params("lz77", 16, block)
+    st = lz.compress(x[:n], p)
+    bb = st.block_bits.cpu().numpy()
+    nblocks = (n + block - 1) // block
+    assert len(bb) == nblocks + 1
+    with _pool() as ex:
+        want = list(ex.map(lambda b: orc.lz77_encode(host[b * block:min((b + 1) * block, n)], 16, 4), range(nblocks)))
+    assert np.array_equal(np.diff(bb), np.array([nb for _, nb in want], dtype=np.int64))
+    bits = np.unpackbits(st.data[: st.nbytes].cpu().numpy(), bitorder="little")
+    bad = []
+    for b, (s, nb) in enumerate(want):
+        if not np.array_equal(bits[bb[b]:bb[b + 1]], np.unpackbits(s, bitorder="little")[:nb]):
+            bad.append(b)
+    assert not bad, f"{len(bad)} of {nblocks} blocks differ, first {bad[:8]}"
+    st2 = lz.compress(x[:n], p)
+    assert torch.equal(st2.block_bits, st.block_bits) and torch.equal(st2.data[: st.nbytes], st.data[: st.nbytes])
+    assert torch.equal(lz.decompress(st), x[:n])
