@@ -61,7 +61,7 @@ def parse_args():
     ap.add_argument("--gather", dest="gather", action="store_true", default=None,
                     help="N>1: gather the compressed streams to rank 0 inside the timed region (default for --scaling strong)")
     ap.add_argument("--no-gather", dest="gather", action="store_false")
-    ap.add_argument("--cpu-sample-mb", type=float, default=None)
+    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="target duration of each leg of the headline's CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip mode_T / shard_125MB / end_to_end (A/B runs)")
     ap.add_argument("--seed", type=int, default=12345)
@@ -142,17 +142,17 @@ def timed_steps(codec, x, steps, warmup, sync, after_step=None):
     return time.perf_counter() - t0, holder["h"]
 
 
-def cpu_baseline(workload, sample, sample_desc):
-    """the reference (oracle/_ref, compiled from /root/reference in the build container) or, where the reference has
-    no such code, the oracle's CPU restatement — timed single-threaded on the host.  Checker code, never the product."""
+def cpu_encode(workload, sample):
+    """one pass of the CPU path over `sample` (numpy uint8): the REFERENCE (oracle/_ref, compiled from /root/reference in
+    the build container) where it has code for the workload, the oracle's restatement otherwise.  Checker code, never the
+    product.  -> (kind, seconds, extra)"""
     import numpy as np
     from oracle import orc, ref
     n = len(sample)
-    kind = "port"
-    extra = {}
-    t0 = time.perf_counter()
+    kind, extra = "port", {}
+    have_ref = ref.available()
     if workload == "deflate":
-        if ref.available():
+        if have_ref:
             kind = "reference"
             rd = ref.RefDeflate()
             t0 = time.perf_counter()
@@ -163,7 +163,7 @@ def cpu_baseline(workload, sample, sample_desc):
     elif workload == "deflate-h":
         # the reference stops at a TODO where the entropy stage would be (deflate/lz77.c:279): its tokeniser (the real
         # reference when oracle/_ref is there) + the oracle's restatement of the mode-H coder
-        rd = ref.RefDeflate() if ref.available() else None
+        rd = ref.RefDeflate() if have_ref else None
         d = None if rd else orc.Deflate(BLOCK)
         kind = "reference" if rd else "port"
         t_tok = 0.0
@@ -178,17 +178,32 @@ def cpu_baseline(workload, sample, sample_desc):
                 tok = d.block_encode(sample[at:at + BLOCK])
             t_tok += time.perf_counter() - ta
             orc.defh_encode_block(tok)
-        extra = {"tokeniser_only_gbs": round(n / t_tok / 1e9, 5),
+        extra = {"tokeniser_only_gbs": round(n / max(t_tok, 1e-9) / 1e9, 5),
                  "note": "tokeniser = " + ("the compiled reference" if rd else "oracle port") +
                          "; entropy stage = oracle port (the reference has none)"}
     elif workload.startswith("lz77w"):
         wb = 14 if workload == "lz77w14" else 16
         blk = {"lz77w16-256k": 262144, "lz77w16-1m": 1 << 20}.get(workload, BLOCK)
-        t0 = time.perf_counter()
-        for at in range(0, n, blk):
-            orc.lz77_encode(sample[at:at + blk].tobytes(), wb, 4)
+        # the reference's insert probes without wrapping (lz77.c:61): on an input where a word with a home just below the
+        # table's end repeats, the compiled reference writes past its bucket array (heap corruption).
+        # The oracle tells beforehand (untimed); such a sample is timed with the oracle port instead, and says so.
+        safe = have_ref and not orc.past_table_end(sample, wb, wb + 6, False)
+        if have_ref and not safe:
+            extra = {"note": "the compiled reference would write past its table on this sample (lz77.c:61 UB): oracle port timed instead"}
+        if safe:
+            # lz77_compress (lz77/lz77.c:264-345) as the reference runs it: ONE call over the sample, one stream — its
+            # 2^(W+6)-bucket table is allocated and cleared once per call (lz77.c:43-53), so per-block calls would mostly
+            # time that fill; the block-parallel streams this build emits are those of per-block calls (parity tests)
+            kind = "reference"
+            extra = {"note": "reference lz77_compress over the sample as one stream (one table fill per call)"}
+            t0 = time.perf_counter()
+            ref.lz77_compress(sample, wb)
+        else:
+            t0 = time.perf_counter()
+            for at in range(0, n, blk):
+                orc.lz77_encode(sample[at:at + blk], wb, 4)
     elif workload == "huffman":
-        if ref.available():
+        if have_ref:
             kind = "reference"
             import ctypes as C
             L = ref._huff()
@@ -200,14 +215,126 @@ def cpu_baseline(workload, sample, sample_desc):
             t0 = time.perf_counter()
             orc.huff_encode(sample)
     elif workload == "fse":
+        extra = {"note": "the reference's FSE does not compile (fse/src/main.zig:47): oracle port of this build's format"}
         t0 = time.perf_counter()
         for at in range(0, n, BLOCK):
             orc.fse_encode_block(sample[at:at + BLOCK], 8, 64, 1)
-    dt = time.perf_counter() - t0
-    out = {"value": round(n / dt / 1e9, 5), "unit": "GB/s", "cores": 1, "kind": kind,
-           "sample": f"{sample_desc}; {n} bytes in {dt:.2f} s on 1 of {os.cpu_count()} host cores"}
+    else:
+        raise ValueError(workload)
+    return kind, time.perf_counter() - t0, extra
+
+
+def _cpu_worker(job):
+    """all-cores leg: one independent-block worker per core; runs in a process forked BEFORE the parent
+    touched the GPU.  The sample comes through a file in /dev/shm."""
+    import numpy as np
+    workload, path, lo, hi, reps = job
+    a = np.array(np.memmap(path, dtype=np.uint8, mode="r")[lo:hi])
+    dt = 0.0
+    for _ in range(reps):
+        dt += cpu_encode(workload, a)[1]
+    return (hi - lo) * reps, dt
+
+
+def host_cores():
+    """cores this process may really use: the affinity mask, cut by a cgroup CPU quota if there is one"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            t = open(f).read().split()
+            if f.endswith("cpu.max"):
+                if t[0] != "max":
+                    n = min(n, max(1, int(int(t[0]) / int(t[1]))))
+            elif int(t[0]) > 0:
+                n = min(n, max(1, int(int(t[0]) / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()))))
+            break
+        except Exception:
+            continue
+    env = os.environ.get("MI_BENCH_CPU_WORKERS")
+    return max(1, min(n, int(env))) if env else n
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+class CpuPool:
+    """worker processes for the all-cores CPU baseline, forked at the top of main() before any torch.cuda call (a forked
+    child of a process that has initialised HIP is not usable, and a late fork is what the box's exec guard forbids)"""
+
+    def __init__(self):
+        import multiprocessing as mp
+        self.cores = host_cores()
+        self.pool = mp.get_context("fork").Pool(self.cores) if self.cores > 1 else None
+        self.model = cpu_model()
+
+    def run(self, workload, sample, per_core_bytes, grain, want_bytes):
+        """every core encodes its own `per_core_bytes` slice of `sample` (whole blocks), as often as it takes to have done
+        about `want_bytes`; a first tiny round loads the libraries in every worker; -> dict or None"""
+        import numpy as np
+        if self.pool is None:
+            return None
+        per = max(grain, per_core_bytes // grain * grain)
+        k = min(self.cores, len(sample) // per)
+        if k < 2:
+            return None
+        path = f"/dev/shm/mi_bench_{os.getpid()}.bin"
+        try:
+            np.asarray(sample[: k * per]).tofile(path)
+            reps = max(1, -(-want_bytes // per))
+            self.pool.map(_cpu_worker, [(workload, path, 0, min(grain, per), 1)] * k, chunksize=1)      # warm-up
+            jobs = [(workload, path, i * per, (i + 1) * per, reps) for i in range(k)]
+            t0 = time.perf_counter()
+            res = self.pool.map(_cpu_worker, jobs, chunksize=1)
+            wall = time.perf_counter() - t0
+        finally:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+        nb = sum(r[0] for r in res)
+        return {"value": round(nb / wall / 1e9, 4), "unit": "GB/s", "cores": k, "host_cores": os.cpu_count(), "cpu_model": self.model,
+                "sample": f"{k} workers x {reps} pass(es) over {per} bytes each (independent blocks, one worker per core), wall {wall:.2f} s, "
+                          f"slowest worker {max(r[1] for r in res):.2f} s"}
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.terminate()
+            self.pool.join()
+            self.pool = None
+
+
+# single-core CPU rates (GB/s) used only to size the samples so that each leg takes ~2-3 s
+CPU_RATE = {"deflate": 0.045, "deflate-h": 0.029, "lz77w16": 0.012, "lz77w14": 0.014, "lz77w16-256k": 0.012, "lz77w16-1m": 0.012,
+            "huffman": 0.23, "fse": 0.04}
+
+
+def cpu_baseline(workload, x, pool, seconds=2.5):
+    """cpu_baseline object of the JSON line for one workload: single core + all cores, on a bounded prefix of `x`"""
+    n = x.numel()
+    grain = {"lz77w16-256k": 262144, "lz77w16-1m": 1 << 20}.get(workload, BLOCK)
+    want = int(CPU_RATE[workload] * 1e9 * seconds)
+    nsamp = max(grain, min(n, want) // grain * grain) if n >= grain else n
+    cores = pool.cores if pool is not None else 1
+    per_core = nsamp if workload != "huffman" else max(grain, nsamp // 4 // grain * grain)
+    nall = min(n, per_core * cores) // grain * grain
+    sample = x[: max(nsamp, nall)].cpu().numpy()
+    kind, dt, extra = cpu_encode(workload, sample[:nsamp])
+    out = {"value": round(nsamp / dt / 1e9, 5), "unit": "GB/s", "cores": 1, "kind": kind,
+           "sample": f"first {nsamp} bytes of the rank-0 buffer in {dt:.2f} s on 1 of {os.cpu_count()} host cores"}
     out.update(extra)
-    return out
+    if pool is not None:
+        try:
+            out["all_cores"] = pool.run(workload, sample, min(per_core, max(grain, nall // max(cores, 1))), grain, per_core)
+        except Exception as e:
+            out["all_cores"] = {"value": None, "error": repr(e)[:200]}
+    return out, sample[:nsamp]
 
 
 def reference_output_bytes(workload, sample):
@@ -232,12 +359,75 @@ def reference_output_bytes(workload, sample):
     return None, "the reference's FSE does not compile: no reference output exists"
 
 
+def roofline_of(workload, n, c, ktimes, steps, dt):
+    """roofline object for one measured workload: the dominant kernel (largest share of the timed region, HIP events on
+    its launch stream) is credited the job's ALGORITHMIC bytes — (passes*n + c), DESIGN.md section 3 — split over its
+    launches.  `traffic` is HBM bytes per launch from a committed rocprofv3 --pmc run of the same command
+    (profiles/pmc_traffic_<workload>.json: `traffic_source`), not a measurement of this run."""
+    if not ktimes:
+        return None
+    dom = max(ktimes, key=lambda k: k["ms"] * k["launches"])
+    lps = dom["launches"] / steps
+    passes = 2 if workload == "huffman" else 1
+    alg = (passes * n + c) / lps
+    achieved = alg / (dom["ms"] * 1e-3) / 1e9
+    traffic, src = None, None
+    tj = os.path.join(ROOT, "profiles", f"pmc_traffic_{workload}.json")
+    if os.path.exists(tj):
+        try:
+            traffic = json.load(open(tj)).get(dom["name"])
+            src = f"profiles/pmc_traffic_{workload}.json (committed rocprofv3 --pmc run, not this run)" if traffic is not None else None
+        except Exception:
+            traffic = None
+    own = {"k_huff_hist": n, "k_huff_encode": n + c}.get(dom["name"], (passes * n + c)) / lps
+    return {"bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "achieved_own_bytes": round(own / (dom["ms"] * 1e-3) / 1e9, 2),
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": src,
+            "algorithmic_bytes_per_launch": int(alg),
+            "whole_step_frac": round((passes * n + c) / (dt / steps) / 1e9 / HBM_PEAK_GBS, 5),
+            "avg_launch_ms": round(dom["ms"], 4), "launches_per_step": lps,
+            "kernel_share": round(dom["ms"] * dom["launches"] / (dt * 1e3), 3),
+            "all_kernels_ms_per_step": {k["name"]: round(k["ms"] * k["launches"] / steps, 3) for k in ktimes}}
+
+
+def measure(ctx, workload, x, steps, warmup, pool=None, cpu=True):
+    """one sub-record: K timed encode steps of `workload` over the resident buffer x (after `warmup` untimed ones), kernel
+    times from HIP events, one decode for the round trip, roofline, CPU baseline"""
+    co = Codec(workload, ctx)
+    n = x.numel()
+    timed_steps(co, x, 0, max(warmup, 1), torch.cuda.synchronize)
+    ctx.set_profiling(True)
+    ctx.kernel_times()
+    dt, h = timed_steps(co, x, steps, 0, torch.cuda.synchronize)
+    ctx.set_profiling(False)
+    kt = ctx.kernel_times()
+    c = co.nbytes(h)
+    ok = bool(torch.equal(co.decode(h), x))
+    del h
+    rec = {"value": round(n * steps / dt / 1e9, 3), "unit": "GB/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+           "input_bytes": n, "compressed_bytes": int(c), "ratio": round(n / max(c, 1), 4), "roundtrip": ok, "what": DESC[workload],
+           "roofline": roofline_of(workload, n, c, kt, steps, dt)}
+    if cpu:
+        try:
+            rec["cpu_baseline"], _ = cpu_baseline(workload, x, pool)
+        except Exception as e:
+            rec["cpu_baseline"] = {"value": None, "error": repr(e)[:200]}
+    return rec
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # the all-cores CPU baseline needs worker processes: fork them NOW, before anything touches the GPU
+    pool = None
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            pool = CpuPool()
+        except Exception:
+            pool = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
@@ -271,6 +461,8 @@ def main():
         x = synth.enwik_like(args.bytes, seed=args.seed + 1000 * rank, device=dev)
     n = x.numel()
     torch.cuda.synchronize()
+    # digest of the rank-0 buffer: the generator is byte-reproducible (synth.py), so this field is too
+    input_digest = synth.digest(x) if rank == 0 else None
 
     def barrier():
         torch.cuda.synchronize()
@@ -342,54 +534,15 @@ def main():
 
     if rank == 0:
         value = n_job * args.steps / dt / 1e9
-        # ---- roofline of the dominant kernel (largest share of the timed region), HIP events on its launch stream
-        roof = None
-        if ktimes:
-            dom = max(ktimes, key=lambda k: k["ms"] * k["launches"])
-            launches_per_step = dom["launches"] / args.steps
-            passes = 2 if args.workload == "huffman" else 1
-            alg_bytes_per_launch = (passes * n + c) / launches_per_step       # (passes*n + c) per job, split over the launches
-            achieved = alg_bytes_per_launch / (dom["ms"] * 1e-3) / 1e9
-            traffic = None
-            tj = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}.json")
-            if os.path.exists(tj):
-                try:
-                    traffic = json.load(open(tj)).get(dom["name"])
-                except Exception:
-                    traffic = None
-            own = {"k_huff_hist": n, "k_huff_encode": n + c}.get(dom["name"], (passes * n + c)) / launches_per_step
-            roof = {"bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "achieved_own_bytes": round(own / (dom["ms"] * 1e-3) / 1e9, 2),
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "whole_step_frac": round((passes * n + c) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
-                    "avg_launch_ms": round(dom["ms"], 4), "launches_per_step": launches_per_step,
-                    "kernel_share": round(dom["ms"] * dom["launches"] / (dt * 1e3), 3),
-                    "all_kernels_ms_per_step": {k["name"]: round(k["ms"] * k["launches"] / args.steps, 3) for k in ktimes}}
+        roof = roofline_of(args.workload, n, c, ktimes, args.steps, dt)
 
         extras = {}
         single = world == 1 and not args.no_extras
+        cpu_on = not args.no_cpu_baseline
         if single and args.workload == "deflate-h":
-            # the token-only mode, timed the same way (what BENCH_r01 carried as its headline)
-            ct = Codec("deflate", ctx)
-            h0 = ct.encode(x); h0 = None                               # warm-up
-            torch.cuda.synchronize()
-            ctx.set_profiling(True)
-            ctx.kernel_times()
-            dtt, ht = timed_steps(ct, x, args.steps, 0, torch.cuda.synchronize)
-            ctx.set_profiling(False)
-            kt = ctx.kernel_times()
-            ctn = ct.nbytes(ht)
-            extras["mode_T"] = {"value": round(n * args.steps / dtt / 1e9, 3), "unit": "GB/s", "ms_per_step": round(dtt / args.steps * 1e3, 3),
-                                "ratio": round(n / max(ctn, 1), 4), "what": DESC["deflate"]}
-            if kt:
-                # the same roofline arithmetic for this mode (BENCH_r01's headline: the token stream is as large as the input,
-                # so a launch is credited n + c = 2.0008 n where mode H is credited n + 0.52 n)
-                domt = max(kt, key=lambda k: k["ms"] * k["launches"])
-                lps = domt["launches"] / args.steps
-                extras["mode_T"]["roofline"] = {"kernel": domt["name"], "avg_launch_ms": round(domt["ms"], 4), "launches_per_step": lps,
-                                                "achieved": round((n + ctn) / lps / (domt["ms"] * 1e-3) / 1e9, 2), "unit": "GB/s",
-                                                "frac": round((n + ctn) / lps / (domt["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
-            del ht
+            # the token-only mode, timed the same way (what BENCH_r01 carried as its headline; a launch is credited
+            # n + c = 2.0008 n here where mode H is credited n + 0.52 n)
+            extras["mode_T"] = measure(ctx, "deflate", x, args.steps, 1, pool, cpu_on)
         if single and args.workload in ("deflate-h", "deflate") and n >= 125_000_000 + BLOCK:
             # config 5's per-GPU shape on this one GPU: 1/8 of enwik9 = 125 MB = 1 908 blocks
             xs = x[:125_000_000]
@@ -400,9 +553,10 @@ def main():
                                      "what": "one GPU's share of config 5 (enwik9 / 8), same workload, single-GPU proxy"}
             del hs
         if single and args.workload == "deflate-h" and n >= 1_000_000_000:
-            # the other BASELINE.json configs on the same box, same method (inputs resident, K steps after a warm-up), so that
-            # the driver's record backs every figure the documents quote: config 1's codec (whole-buffer Huffman, 10^8 B),
-            # config 2 (lz77, 10^8 B, W = 64 KiB and the shipped 16 KiB), config 3 (FSE table_log 8, 10^9 B)
+            # the other BASELINE.json configs on the same box, same method (inputs resident, K steps after a warm-up), each
+            # with its own roofline and CPU baseline, so that the driver's record backs every figure the documents quote:
+            # config 1's codec (whole-buffer Huffman, 10^8 B), config 2 (lz77, 10^8 B: W = 64 KiB on 64 KiB / 256 KiB /
+            # 1 MiB blocks and the shipped W = 16 KiB), config 3 (FSE table_log 8, 10^9 B)
             others = {}
             for key, wl, nb_ in (("config1_huffman_1e8", "huffman", 100_000_000), ("config2_lz77_w16_1e8", "lz77w16", 100_000_000),
                                  ("config2_lz77_w14_1e8", "lz77w14", 100_000_000),
@@ -410,17 +564,28 @@ def main():
                                  ("config2_lz77_w16_1MiB_blocks_1e8", "lz77w16-1m", 100_000_000),
                                  ("config3_fse_1e9", "fse", 1_000_000_000)):
                 try:
-                    co = Codec(wl, ctx)
-                    xo = x[:nb_]
-                    ko = max(args.steps, 5)
-                    dto, ho = timed_steps(co, xo, ko, 1, torch.cuda.synchronize)
-                    ok_ = bool(torch.equal(co.decode(ho), xo))
-                    others[key] = {"value": round(nb_ * ko / dto / 1e9, 3), "unit": "GB/s", "ms_per_step": round(dto / ko * 1e3, 3),
-                                   "ratio": round(nb_ / max(co.nbytes(ho), 1), 4), "roundtrip": ok_, "what": DESC[wl]}
-                    del ho
+                    others[key] = measure(ctx, wl, x[:nb_], max(args.steps, 5), 1, pool, cpu_on)
                 except Exception as e:
                     others[key] = {"value": None, "error": repr(e)[:200]}
             extras["other_configs"] = others
+            # inputs that are not text (SURVEY.md 8d "adversarial"; the fuzz families of tests/test_fuzz_gpu.py): 10^8 bytes
+            # each = a seeded 2^24-byte sample repeated (blocks are independent and the window is 32 KiB, so the repeat
+            # changes nothing per block), through the headline workload; value + round trip
+            adv = {}
+            import numpy as np
+            reps = 6
+            kinds = [(k, lambda k=k: synth.family(k, 4242, 1 << 24)) for k in synth.FAMILIES if k != "text"]
+            kinds += [("zeros", lambda: np.zeros(1 << 24, np.uint8)), ("single_symbol", lambda: np.full(1 << 24, 0x61, np.uint8)),
+                      ("random", lambda: np.random.default_rng(1).integers(0, 256, 1 << 24, dtype=np.uint8))]
+            for kind, gen in kinds:
+                try:
+                    xa = torch.from_numpy(gen()).to(dev).repeat(reps)[:100_000_000].contiguous()
+                    r = measure(ctx, args.workload, xa, 2, 1, None, False)
+                    adv[kind] = {k_: r[k_] for k_ in ("value", "unit", "ms_per_step", "ratio", "roundtrip", "input_bytes")}
+                    del xa
+                except Exception as e:
+                    adv[kind] = {"value": None, "error": repr(e)[:200]}
+            extras["adversarial"] = adv
         if single:
             # PCIe-inclusive (never `value`).  The deflate workloads go through the HOST-buffer entry points the drop-in
             # compress() calls (pageable memory in and out, transfers chunked beside the encoder: host_api.hip); the others
@@ -496,13 +661,9 @@ def main():
         cpu = None
         ratio_vs_ref = None
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is a rank-0, N = 1 measurement
-            rate = {"deflate": 0.045, "deflate-h": 0.029, "lz77w16": 0.012, "lz77w14": 0.014, "lz77w16-256k": 0.012, "lz77w16-1m": 0.012, "huffman": 0.23, "fse": 0.15}[args.workload]
-            mb = args.cpu_sample_mb if args.cpu_sample_mb else min(n / 1e6, max(4.0, 5.0 * rate * 1e3))
-            nsamp = int(mb * 1e6) // BLOCK * BLOCK or min(n, BLOCK)
-            sample = x[:nsamp].cpu().numpy()
-            cpu = cpu_baseline(args.workload, sample, f"first {nsamp} bytes of the rank-0 buffer")
+            cpu, sample = cpu_baseline(args.workload, x, pool, seconds=args.cpu_seconds)
             # ratio vs the reference's own output on (a prefix of) the same sample
-            nr = min(nsamp, 64 * 1024 * 1024)
+            nr = min(len(sample), 64 * 1024 * 1024)
             try:
                 ref_bytes, ref_what = reference_output_bytes(args.workload, sample[:nr])
                 own = codec.nbytes(codec.encode(x[:nr]))
@@ -514,12 +675,15 @@ def main():
                     ratio_vs_ref = {"value": None, "ref": ref_what}
             except Exception as e:
                 ratio_vs_ref = {"value": None, "error": repr(e)[:200]}
+        if pool is not None:
+            pool.close()
         line = {
             "metric": "encode GB/s on enwik9 at 1/2/4/8 MI355X; ratio vs ref; round-trip bit-exact",
             "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{DESC[args.workload]}; {n_job} enwik-shaped bytes in the job, {n} on rank 0",
+                       "input_sha256": input_digest, "input_seed": args.seed,
                        "mode": {"deflate-h": "H", "deflate": "T"}.get(args.workload),
                        "input_bytes_job": n_job, "input_bytes_rank0": n, "compressed_bytes_job": c_job, "compressed_bytes_rank0": int(c),
                        "ratio": round(n_job / max(c_job, 1), 4), "gather_to_rank0": bool(gather),

@@ -195,3 +195,53 @@ def adversarial(kind, n, seed=1):
         # geometric byte distribution: deep Huffman trees
         return bytes(min(int(-math.log(1.0 - rng.random()) * 3.0), 255) for _ in range(n))
     raise ValueError(kind)
+
+
+FAMILIES = ("text", "lowent", "phrases", "runs", "pages")
+
+
+def family(kind, seed, n):
+    """seeded input families that stress different parts of the cluster machinery (tests/test_fuzz_gpu.py, scripts/fuzz_campaign.py,
+    bench.py `adversarial`): numpy uint8 array of n bytes"""
+    rng = np.random.default_rng(seed)
+    if kind == "text":
+        return enwik_like(n, seed=seed).numpy()
+    if kind == "lowent":                      # tiny alphabet: a few hundred distinct words, clusters of hundreds of entries
+        k = int(rng.integers(2, 7))
+        return (rng.integers(0, k, n) + 97).astype(np.uint8)
+    if kind == "phrases":                     # random bytes with a handful of phrases pasted at random places
+        data = rng.integers(0, 256, n, dtype=np.uint8)
+        phrases = [rng.integers(0, 256, int(rng.integers(4, 40)), dtype=np.uint8) for _ in range(6)]
+        for _ in range(n // 60):
+            ph = phrases[int(rng.integers(0, len(phrases)))]
+            at = int(rng.integers(0, n - len(ph)))
+            data[at:at + len(ph)] = ph
+        return data
+    if kind == "runs":                        # text interrupted by runs of one byte, 10 .. 3000 long
+        data = enwik_like(n, seed=seed).numpy().copy()
+        at = 0
+        while at < n:
+            at += int(rng.integers(200, 6000))
+            ln = int(rng.integers(10, 3000))
+            data[at:at + ln] = int(rng.integers(0, 256))
+            at += ln
+        return data
+    if kind == "pages":                       # binary-like: zero pages, counters, a repeated record
+        data = np.zeros(n, dtype=np.uint8)
+        rec = rng.integers(0, 256, 24, dtype=np.uint8)
+        at = 0
+        while at + 64 < n:
+            what = int(rng.integers(0, 4))
+            ln = int(rng.integers(64, 5000))
+            ln = min(ln, n - at)
+            if what == 0:
+                pass                          # zeros
+            elif what == 1:
+                data[at:at + ln] = np.arange(ln, dtype=np.uint32).astype(np.uint8)
+            elif what == 2:
+                data[at:at + ln] = np.resize(rec, ln)
+            else:
+                data[at:at + ln] = rng.integers(0, 256, ln, dtype=np.uint8)
+            at += ln
+        return data
+    raise ValueError(kind)
