@@ -223,7 +223,13 @@ mi_status mi_ws_reserve(mi_ctx *c, size_t bytes)
     MI_HIP(c, hipDeviceSynchronize());
     if (c->ws) { MI_HIP(c, hipFree(c->ws)); c->ws = nullptr; c->ws_bytes = 0; }
     size_t want = mi_align_up(bytes + bytes / 8, 1 << 20);
-    MI_HIP(c, hipMalloc(&c->ws, want));
+    if (hipMalloc(&c->ws, want) != hipSuccess) {
+        // without the slack; a caller that can work in smaller batches halves its request on MI_ERR_NOMEM (lz_emit.hip)
+        (void)hipGetLastError();
+        want = mi_align_up(bytes, 1 << 20);
+        c->ws = nullptr;
+        if (hipMalloc(&c->ws, want) != hipSuccess) { (void)hipGetLastError(); c->ws = nullptr; return MI_ERR_NOMEM; }
+    }
     c->ws_bytes = want;
     return MI_OK;
 }

@@ -22,28 +22,64 @@ static mi_ctx *dropin_ctx(void)
 /* Side tables of the drop-ins, kept OUT of band.  The reference's BitStream / BitWriter have no room for the per-block
  * (per-tile) offsets a parallel decoder needs, and probing for a trailer behind a caller's buffer reads past a buffer
  * the reference produced.  So compress registers {buffer pointer, stream length in bits} -> table here and
- * decompress looks it up; a buffer this library did not produce simply has no entry. */
+ * decompress looks it up; a buffer this library did not produce simply has no entry.  The registry grows (no eviction: every
+ * live stream keeps its table), is guarded by a mutex, and an entry goes when its stream is released
+ * (mi_lz77_release / mi_huffman_release) or when the same address is registered again (the caller freed and malloc reused it).
+ * In-process only: a stream that must outlive the process is framed (mi_frame.h). */
+#include <pthread.h>
 typedef struct { const void *key; uint64_t bits, n, aux, count; uint64_t *table; } dropin_side;
-#define DROPIN_SIDE_SLOTS 64
-static dropin_side g_side[DROPIN_SIDE_SLOTS];
-static unsigned g_side_next;
+static dropin_side *g_side;
+static size_t g_side_len, g_side_cap;
+static pthread_mutex_t g_side_mu = PTHREAD_MUTEX_INITIALIZER;
 
 __attribute__((unused)) static void dropin_side_put(const void *key, uint64_t bits, uint64_t n, uint64_t aux, const uint64_t *table, uint64_t count)
 {
+    uint64_t *copy = (uint64_t *)malloc(8 * (count ? count : 1));
+    if (!copy) { fprintf(stderr, "mi_codec: out of memory\n"); exit(1); }
+    for (uint64_t i = 0; i < count; ++i) copy[i] = table[i];
+    pthread_mutex_lock(&g_side_mu);
     dropin_side *e = NULL;
-    for (unsigned i = 0; i < DROPIN_SIDE_SLOTS; ++i) if (g_side[i].key == key) { e = &g_side[i]; break; }
-    if (!e) e = &g_side[g_side_next++ % DROPIN_SIDE_SLOTS];
+    for (size_t i = 0; i < g_side_len; ++i) if (g_side[i].key == key) { e = &g_side[i]; break; }
+    if (!e) {
+        if (g_side_len == g_side_cap) {
+            const size_t cap = g_side_cap ? 2 * g_side_cap : 16;
+            dropin_side *g = (dropin_side *)realloc(g_side, cap * sizeof *g);
+            if (!g) { fprintf(stderr, "mi_codec: out of memory\n"); exit(1); }
+            g_side = g; g_side_cap = cap;
+        }
+        e = &g_side[g_side_len++];
+        e->table = NULL;
+    }
     free(e->table);
-    e->table = (uint64_t *)malloc(8 * (count ? count : 1));
-    if (!e->table) { fprintf(stderr, "mi_codec: out of memory\n"); exit(1); }
-    for (uint64_t i = 0; i < count; ++i) e->table[i] = table[i];
-    e->key = key; e->bits = bits; e->n = n; e->aux = aux; e->count = count;
+    e->table = copy; e->key = key; e->bits = bits; e->n = n; e->aux = aux; e->count = count;
+    pthread_mutex_unlock(&g_side_mu);
 }
 
-__attribute__((unused)) static const dropin_side *dropin_side_get(const void *key, uint64_t bits, uint64_t n)
+/* copies the entry out (the registry may grow under another thread); the table pointer stays valid until the stream is
+ * released or its address registered again */
+__attribute__((unused)) static int dropin_side_get(const void *key, uint64_t bits, uint64_t n, dropin_side *out)
 {
-    for (unsigned i = 0; i < DROPIN_SIDE_SLOTS; ++i)
-        if (g_side[i].key == key && g_side[i].table && g_side[i].bits == bits && g_side[i].n == n) return &g_side[i];
-    return NULL;
+    int found = 0;
+    pthread_mutex_lock(&g_side_mu);
+    for (size_t i = 0; i < g_side_len; ++i)
+        if (g_side[i].key == key && g_side[i].table && g_side[i].bits == bits && g_side[i].n == n) { *out = g_side[i]; found = 1; break; }
+    pthread_mutex_unlock(&g_side_mu);
+    return found;
+}
+
+__attribute__((unused)) static void dropin_side_drop(const void *key)
+{
+    pthread_mutex_lock(&g_side_mu);
+    for (size_t i = 0; i < g_side_len; ++i)
+        if (g_side[i].key == key) { free(g_side[i].table); g_side[i] = g_side[--g_side_len]; break; }
+    pthread_mutex_unlock(&g_side_mu);
+}
+
+__attribute__((unused)) static size_t dropin_side_count(void)
+{
+    pthread_mutex_lock(&g_side_mu);
+    const size_t k = g_side_len;
+    pthread_mutex_unlock(&g_side_mu);
+    return k;
 }
 #endif

@@ -44,6 +44,36 @@ void init_hash_table(HashTableArray *table)                         /* deflate/l
     table->is_full = false;
 }
 
+/* deflate/lz77.h:32-33 (deflate/lz77.c:77-174): the per-entry table operations on the host table above; host helpers, the
+ * encoder never calls them.  insert wraps modulo TABLE_SIZE as the reference's does (lz77.c:99-101); find does not wrap
+ * (lz77.c:163-169) and — where the reference reads patterns[TABLE_SIZE] — stops at the last bucket: "not found", the
+ * definition the oracle and the kernels share. */
+void insert_hash_table(HashTableArray *table, uint32_t pattern, uint64_t index)
+{
+    uint32_t b = hash(pattern);
+    for (uint32_t probes = 0; table->buckets.is_set[b]; ++probes) {
+        if (probes >= TABLE_SIZE) { fprintf(stderr, "insert_hash_table: table full\n"); exit(1); }   /* the reference spins forever */
+        b = (b + 1u) % TABLE_SIZE;
+    }
+    table->buckets.patterns[b] = pattern; table->buckets.indices[b] = index; table->buckets.is_set[b] = true;
+    if (table->is_full) {                                         /* FIFO retirement of the bucket recorded W insertions ago */
+        const uint32_t old = table->bucket_indices[table->current_idx];
+        table->buckets.patterns[old] = 0; table->buckets.indices[old] = 0; table->buckets.is_set[old] = false;
+    }
+    table->bucket_indices[table->current_idx] = b;
+    if (++table->current_idx >= WINDOW_SIZE - 1) table->is_full = true;
+    table->current_idx %= WINDOW_SIZE;
+}
+
+uint64_t find(HashTableArray *table, uint32_t pattern)
+{
+    for (uint32_t b = hash(pattern); b < TABLE_SIZE; ++b) {
+        if (!table->buckets.is_set[b]) return UINT64_MAX;         /* a hole ends the probe: no tombstones */
+        if (table->buckets.patterns[b] == pattern) return table->buckets.indices[b];
+    }
+    return UINT64_MAX;
+}
+
 void write_literal(char *buffer, char c, uint64_t *at) { buffer[(*at)++] = 0; buffer[(*at)++] = c; }          /* deflate/lz77.c:176-184 */
 void write_length_distance(char *buffer, uint8_t length, uint16_t distance, uint64_t *at)              /* deflate/lz77.c:186-197 */
 {

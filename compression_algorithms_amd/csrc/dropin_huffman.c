@@ -157,11 +157,28 @@ void huffman_decompress(BitWriter *writer, Node *root, char *output, uint64_t *o
     memcpy(tree.code, codes, sizeof codes); memcpy(tree.length, lens, sizeof lens);
     const uint64_t n = *output_size;                            /* the original length (huffman/main.c:69) */
     const uint64_t bits = writer->word_idx * 32 + writer->bit_idx;
-    const dropin_side *e = dropin_side_get(writer->buffer, bits, n);
-    const uint64_t *toff = (e && e->count == (n + MI_HUFFMAN_TILE - 1) / MI_HUFFMAN_TILE + 1) ? e->table : NULL;   /* foreign stream: single-lane decode */
+    dropin_side e;
+    const int have = dropin_side_get(writer->buffer, bits, n, &e);
+    const uint64_t *toff = (have && e.count == (n + MI_HUFFMAN_TILE - 1) / MI_HUFFMAN_TILE + 1) ? e.table : NULL;   /* foreign stream: single-lane decode */
     mi_status st = mi_huffman_decode(ctx, writer->buffer, bits, &tree, (uint32_t)next, toff, (uint8_t *)output, n);
     if (st != MI_OK) { fprintf(stderr, "huffman_decompress: %s\n", mi_status_str(st)); exit(1); }
     *output_size = n;
+}
+
+/* huffman.h:108-113 (huffman.c:366-401): the reference's second decoder, a lookup-table walk it left unfinished.  The GPU
+ * decoder IS a lookup-table decoder (k_huff_decode: 12-bit LUT + tree walk for longer codes), so both names run it. */
+void huffman_decompress_lookup_table(BitWriter *writer, Node *root, char *output, uint64_t *output_size)
+{
+    huffman_decompress(writer, root, output, output_size);
+}
+
+/* frees writer->buffer and the tile table huffman_compress registered for it (the struct itself is the caller's) */
+void mi_huffman_release(BitWriter *writer)
+{
+    if (!writer) return;
+    dropin_side_drop(writer->buffer);
+    free(writer->buffer);
+    writer->buffer = NULL;
 }
 
 /* ---- framed files (mi_frame.h): self-describing, decodable without the Node tree ------------------------------------ */

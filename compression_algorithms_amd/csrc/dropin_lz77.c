@@ -46,6 +46,44 @@ void init_hash_table(HashTableArray *table)                         /* lz77.c:43
     table->is_full = false;
 }
 
+/* lz77.h:34-35 (lz77.c:55-108): the reference's per-entry table operations, on the host table init_hash_table allocates.
+ * Host helpers like write_bit: the encoder never calls them (its table is never materialised) — they are here
+ * so that a caller written against lz77.h links completely, and they are what tests/test_dropin.py checks the oracle's
+ * literal table against.  One deliberate difference: the reference probes without wrapping and without a bound (lz77.c:61,
+ * :97-105), so a run of occupied buckets that reaches the end of the array makes it write past it; here the probe stops at
+ * the last bucket and the call fails loudly instead. */
+static void table_overrun(const char *who)
+{
+    fprintf(stderr, "%s: probe ran past bucket TABLE_SIZE-1 (the reference writes out of bounds here, lz77.c:61)\n", who);
+    exit(1);
+}
+
+void insert_hash_table(HashTableArray *table, uint32_t pattern, uint64_t index)
+{
+    const uint32_t ring = 1u << WINDOW_BITS;
+    uint64_t b = hash(pattern) % (uint32_t)TABLE_SIZE;
+    while (b < (uint64_t)TABLE_SIZE && table->buckets[b].is_set) ++b;          /* first free bucket at or after the home */
+    if (b >= (uint64_t)TABLE_SIZE) table_overrun("insert_hash_table");
+    table->buckets[b].pattern = pattern; table->buckets[b].index = index; table->buckets[b].is_set = true;
+    if (table->is_full) {                                                      /* FIFO retirement: whatever sits in the bucket */
+        ArrayNode *old = &table->buckets[table->bucket_indices[table->current_idx]];   /* recorded W insertions ago goes */
+        old->pattern = 0; old->index = 0; old->is_set = false;
+    }
+    table->bucket_indices[table->current_idx] = (uint32_t)b;
+    if (++table->current_idx >= ring - 1u) table->is_full = true;              /* trips after insertion #(W - 1): SURVEY A.1.2 */
+    table->current_idx %= ring;
+}
+
+uint64_t find(HashTableArray *table, uint32_t pattern)
+{
+    for (uint64_t b = hash(pattern) % (uint32_t)TABLE_SIZE; b < (uint64_t)TABLE_SIZE; ++b) {
+        if (!table->buckets[b].is_set) return UINT64_MAX;                      /* a hole ends the probe: no tombstones */
+        if (table->buckets[b].pattern == pattern) return table->buckets[b].index;
+    }
+    table_overrun("find");
+    return UINT64_MAX;
+}
+
 void init_bitstream(BitStream *stream, uint8_t *buffer) { stream->data = buffer; stream->bit_index = 0; }   /* lz77.c:139-142 */
 
 void write_bit(BitStream *stream, bool bit)                         /* lz77.c:144-156: sets OR clears (the buffer need not be zeroed) */
@@ -136,11 +174,15 @@ char *lz77_decompress(BitStream *cs, uint64_t size, uint64_t *decompressed_size)
     const uint64_t *bits = one;
     if (size > p.block) {
         /* more than one block: the offsets are the ones lz77_compress registered for this buffer */
-        const dropin_side *e = dropin_side_get(cs->data, total, size);
-        if (!e) { fprintf(stderr, "lz77_decompress: stream carries no block table (not produced by this library's lz77_compress)\n"); exit(1); }
-        p.wbits = (uint32_t)(e->aux >> 32); p.tbits = p.wbits + 6; p.block = (uint32_t)e->aux;
-        if (e->count != mi_lz_num_blocks(size, &p) + 1) { fprintf(stderr, "lz77_decompress: block table does not match the size\n"); exit(1); }
-        bits = e->table;
+        dropin_side e;
+        if (!dropin_side_get(cs->data, total, size, &e)) {
+            fprintf(stderr, "lz77_decompress: no block table is registered for this stream: it was not produced by this process's "
+                            "lz77_compress, or it was released (mi_lz77_release).  Streams that cross processes are framed: mi_frame.h\n");
+            exit(1);
+        }
+        p.wbits = (uint32_t)(e.aux >> 32); p.tbits = p.wbits + 6; p.block = (uint32_t)e.aux;
+        if (e.count != mi_lz_num_blocks(size, &p) + 1) { fprintf(stderr, "lz77_decompress: block table does not match the size\n"); exit(1); }
+        bits = e.table;
     }
     mi_status st = mi_lz_decode(ctx, &p, cs->data, total / 8 + 1, bits, (uint8_t *)out, size);
     if (st != MI_OK) { fprintf(stderr, "lz77_decompress: %s\n", mi_status_str(st)); exit(1); }
@@ -148,3 +190,15 @@ char *lz77_decompress(BitStream *cs, uint64_t size, uint64_t *decompressed_size)
     *decompressed_size = size;
     return out;
 }
+
+/* frees a stream lz77_compress returned (data, struct) and its out-of-band block table.  Reference-style callers that
+ * free ->data and the struct themselves (lz77/main.c:66-67) leave the table registered until the address is reused. */
+void mi_lz77_release(BitStream *stream)
+{
+    if (!stream) return;
+    dropin_side_drop(stream->data);
+    free(stream->data);
+    free(stream);
+}
+
+uint64_t mi_lz77_registered_streams(void) { return (uint64_t)dropin_side_count(); }

@@ -581,6 +581,10 @@ void k_huff_decode(const uint32_t *__restrict__ words, uint64_t total_bits, cons
         pack |= sym << (8 * (uint32_t)(o & 3u));                 // tiles start 4-byte aligned
         if ((o & 3u) == 3u) { *reinterpret_cast<uint32_t *>(out + o - 3) = pack; pack = 0; }
     }
+    // a tile must end exactly where the table says the next one starts (the last entry is the end of the stream): a
+    // table that does not belong to this stream or to this tile grid (a shard that did not start on a tile
+    // boundary) otherwise decodes to garbage with MI_OK
+    if (!bad && tile_off && bit != tile_off[t + 1]) bad = true;
     if (!bad) for (uint64_t q = o1 & ~3ull; q < o1; ++q) out[q] = (uint8_t)(pack >> (8 * (uint32_t)(q & 3u)));
     if (bad) atomicOr(err, 1u);
 }

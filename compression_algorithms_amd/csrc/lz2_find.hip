@@ -159,8 +159,15 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     const uint32_t lb = (uint32_t)item & 0xFFFFu, part = (uint32_t)(item >> 16) & 0xFFu;
     Lz2BlockMeta *mt = sc.meta + lb;
     long long tk = clock64();
+    // stop_phase exists only in a measurement build (make EXTRA=-DMI_MEASURE, scripts/phase_pmc.sh): the shipped library never
+    // leaves early, whatever the environment says (a stray MI_LZ_STOP_PHASE produced wrong streams with MI_OK)
+#ifdef MI_MEASURE
+#define LZ2_STOP(k) if ((k) < 7 && sc.stop_phase == (uint32_t)(k) + 1u) return
+#else
+#define LZ2_STOP(k) do { } while (0)
+#endif
 #define LZ2_TICK(k) do { if (sc.dbg && tid == 0) { long long t2 = clock64(); atomicAdd((unsigned long long *)&sc.dbg[k], (unsigned long long)(t2 - tk)); tk = t2; } \
-                         if ((k) < 7 && sc.stop_phase == (uint32_t)(k) + 1u) return; } while (0)     /* stop_phase: per-phase counter runs (scripts/phase_pmc.sh) */
+                         LZ2_STOP(k); } while (0)
     // (only parts of blocks that did not fall back are listed; the list position and length ride in the item, so the list
     //  loads below do not wait for the block's meta record)
     const uint32_t m = (uint32_t)(item >> 24) & 0xFFFFu;
@@ -804,7 +811,11 @@ void lz2_carve(mi_carver &cv, uint32_t nb, Lz2Scratch *sc)
     sc->work = cv.take<uint64_t>((size_t)nb * LZ2_MAXPARTS);
     sc->dbg = getenv("MI_LZ_DEBUG") ? cv.take<uint64_t>(64) : nullptr;
     sc->wave_min = LZ2_WAVE;
+#ifdef MI_MEASURE
     sc->stop_phase = getenv("MI_LZ_STOP_PHASE") ? (uint32_t)atoi(getenv("MI_LZ_STOP_PHASE")) : 0u;
+#else
+    sc->stop_phase = 0u;
+#endif
 }
 
 static uint32_t lz2_env_u32(const char *name, uint32_t dflt)

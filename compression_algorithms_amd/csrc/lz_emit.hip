@@ -500,7 +500,7 @@ void defh_launch_encode(const uint32_t *trec, uint32_t *slots, uint64_t *block_b
 // lzw.hip: the lz77 flavour on blocks above 64 KiB
 size_t    lzw_scratch_bytes(uint32_t nb, uint32_t block);
 void      lzw_carve(mi_ctx *ctx, uint32_t nb, uint32_t block, LzwScratch *sc);
-uint32_t  lzw_batch_blocks(uint64_t nblocks, uint32_t block);
+uint32_t  lzw_batch_blocks(mi_ctx *ctx, uint64_t nblocks, uint32_t block);
 mi_status lzw_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb, const LzwScratch &sc, hipStream_t s);
 mi_status lzw_or_lzs_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb, const LzwScratch &sc, hipStream_t s);
 void      lzw_launch_parse_emit(const uint8_t *d_in, uint64_t n, const LzP &P, const LzwScratch &sc, uint64_t block0, uint32_t nb, hipStream_t s);
@@ -527,8 +527,9 @@ static mi_status lz_encode_impl(mi_ctx *ctx, const mi_lz_params *p, const uint8_
     if (P.block > LZ_MAX_BLOCK) {
         // blocks above 64 KiB (lz77 flavour): the HBM-resident finder of lzw.hip, one stream, batches sized by workspace
         if (mode_h) return MI_ERR_ARG;
-        const uint32_t nbw = lzw_batch_blocks(nblocks, P.block);
-        st = mi_ws_reserve(ctx, lzw_scratch_bytes(nbw, P.block) + 4096);
+        uint32_t nbw = lzw_batch_blocks(ctx, nblocks, P.block);
+        // (a workspace the context already holds is reused whatever its size; a batch that does not fit is halved)
+        while ((st = mi_ws_reserve(ctx, lzw_scratch_bytes(nbw, P.block) + 4096)) == MI_ERR_NOMEM && nbw > 1) nbw = (nbw + 1) / 2;
         if (st) return st;
         LzwScratch ws;
         lzw_carve(ctx, nbw, P.block, &ws);

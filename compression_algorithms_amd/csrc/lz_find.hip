@@ -657,7 +657,7 @@ extern "C" mi_status mi_lz_find_all_dev(mi_ctx *ctx, const mi_lz_params *p, cons
 // lzw.hip
 size_t    lzw_scratch_bytes(uint32_t nb, uint32_t block);
 void      lzw_carve(mi_ctx *ctx, uint32_t nb, uint32_t block, LzwScratch *sc);
-uint32_t  lzw_batch_blocks(uint64_t nblocks, uint32_t block);
+uint32_t  lzw_batch_blocks(mi_ctx *ctx, uint64_t nblocks, uint32_t block);
 mi_status lzw_or_lzs_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb, const LzwScratch &sc, hipStream_t s);
 
 // the same hook for blocks above 64 KiB (lz77 flavour, lzw.hip): 32-bit positions, 0xFFFFFFFF = none
@@ -672,8 +672,8 @@ extern "C" mi_status mi_lz_find_all32_dev(mi_ctx *ctx, const mi_lz_params *p, co
     hipStream_t s = (hipStream_t)stream;
     const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block, ctx->lds_rank_ok ? LZP_ARANK : 0u};
     const uint64_t nblocks = (n + P.block - 1) / P.block;
-    const uint32_t nbw = lzw_batch_blocks(nblocks, P.block);
-    st = mi_ws_reserve(ctx, lzw_scratch_bytes(nbw, P.block) + 4096);
+    uint32_t nbw = lzw_batch_blocks(ctx, nblocks, P.block);
+    while ((st = mi_ws_reserve(ctx, lzw_scratch_bytes(nbw, P.block) + 4096)) == MI_ERR_NOMEM && nbw > 1) nbw = (nbw + 1) / 2;
     if (st) return st;
     LzwScratch ws;
     lzw_carve(ctx, nbw, P.block, &ws);

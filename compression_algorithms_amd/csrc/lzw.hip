@@ -691,10 +691,18 @@ void lzw_carve(mi_ctx *ctx, uint32_t nb, uint32_t block, LzwScratch *sc)
     sc->block_bits = cv.take<uint64_t>(nb + 1);
 }
 
-// blocks per batch: the workspace is ~50 bytes per input byte
-uint32_t lzw_batch_blocks(uint64_t nblocks, uint32_t block)
+// blocks per batch.  The workspace is ~80 bytes per input byte (lzw_scratch_bytes: S * 78 + the table bytes + the output
+// slot), so 256 MiB of input per batch — what keeps the latency chains of the time-sliced finder long enough to fill the
+// chip — is ~21 GiB of workspace: nothing beside 288 GB of HBM, too much for a card that is nearly full.  The batch is
+// therefore also held to half of the memory that is free right now, and the caller halves it again on MI_ERR_NOMEM.
+uint32_t lzw_batch_blocks(mi_ctx *ctx, uint64_t nblocks, uint32_t block)
 {
     uint64_t cap = (256ull << 20) / block;                                 // 256 MiB of input per batch
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const uint64_t fit = (uint64_t)(free_b / 2 + (ctx ? ctx->ws_bytes : 0)) / (lzw_scratch_bytes(1, block) - 65536);   // (the workspace it already holds is reused)
+        if (fit < cap) cap = fit;
+    } else (void)hipGetLastError();
     if (cap < 1) cap = 1;
     if (cap > 1024) cap = 1024;
     return (uint32_t)(nblocks < cap ? (nblocks ? nblocks : 1) : cap);

@@ -12,6 +12,8 @@ the CPU tests.
 import torch
 import torch.distributed as dist
 
+HUFF_TILE = 32768          # MI_HUFFMAN_TILE of include/mi_codec.h: the output tile of the parallel Huffman decoder
+
 
 def shard_blocks(nblocks, rank, world):
     """contiguous block range [lo, hi) of rank `rank`"""
@@ -26,56 +28,89 @@ def shard_bytes(n, block, rank, world):
     return lo * block, min(hi * block, n)
 
 
-def gather_streams(data, block_bits, dst=0, group=None):
-    """data: uint8 tensor (this rank's stream, byte aligned); block_bits: int64 [nb+1] exclusive
-    prefix in bits.  Returns on `dst`: (stream uint8 tensor, global int64 block table), else (None, None).
-    Streams are byte-concatenated: use with byte-aligned flavours (deflate tokens, mode-H / FSE records);
-    for the bit-packed lz77 flavour keep the per-rank streams separate or pad each to a byte.
+def _shift_left_bits(stream, nbits, sh):
+    """uint8 tensor holding `nbits` stream bits (LSB first, pad bits zero) -> the same bits starting `sh` (0..7) bits into
+    byte 0: ceil((sh + nbits) / 8) bytes, pad bits zero"""
+    nb_in = (nbits + 7) // 8
+    nb_out = (sh + nbits + 7) // 8
+    if sh == 0:
+        return stream[:nb_in]
+    s16 = stream[:nb_in].to(torch.int32)
+    out = torch.zeros(nb_out, dtype=torch.int32, device=stream.device)
+    out[:nb_in] = (s16 << sh) & 0xFF
+    k = min(nb_in, nb_out - 1)
+    out[1:1 + k] |= s16[:k] >> (8 - sh)
+    return out.to(torch.uint8)
 
-    Exchange: one all_gather of {bytes, blocks} per rank (16 B each), then ONE group of point-to-point
+
+def gather_streams(data, block_bits, dst=0, group=None):
+    """data: uint8 tensor holding this rank's stream from bit 0 (LSB-first bits, pad bits zero); block_bits: int64 [nb+1]
+    exclusive prefix in bits.  Returns on `dst`: (stream uint8 tensor, global int64 block table in bits), else (None, None).
+
+    The result is BIT-contiguous, exactly the stream one GPU writes for the whole buffer: rank r's bits start where rank
+    r-1's end.  For the byte-aligned flavours (deflate tokens, mode-H and FSE records) that is a byte concatenation and the
+    peers' streams are received straight into their place; for the bit-packed lz77 flavour (config 2) every rank first
+    shifts its stream by its global bit offset modulo 8 — on its own GPU — and `dst` OR-merges the byte two neighbours share
+    (the same seam rule as the whole-buffer Huffman below).
+
+    Exchange: one all_gather of {bits, blocks} per rank (16 B each), then ONE group of point-to-point
     transfers (ncclGroupStart .. ncclSend/ncclRecv x (world-1) .. ncclGroupEnd under RCCL): every peer owns a direct
-    xGMI link into `dst`, so the variable-length gather is not ring-bound.  Two host reads: this rank's stream length
-    and the gathered sizes (the receive buffers have to be sized on the host)."""
+    xGMI link into `dst`, so the variable-length gather is not ring-bound.  ONE host read: the gathered sizes (receive
+    buffers are sized on the host); this rank's own length travels in the same tensor."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = data.device
-    nbytes = (int(block_bits[-1]) + 7) // 8
-    meta = torch.tensor([nbytes, block_bits.numel() - 1], dtype=torch.int64, device=dev)
+    meta = torch.stack([block_bits[-1].to(torch.int64), torch.tensor(block_bits.numel() - 1, dtype=torch.int64, device=dev)])
     metas = [torch.zeros_like(meta) for _ in range(world)]
     dist.all_gather(metas, meta, group=group)
     metas = torch.stack(metas).cpu().tolist()
-    sizes = [int(m[0]) for m in metas]
+    bits = [int(m[0]) for m in metas]
     nbs = [int(m[1]) for m in metas]
-    if rank == dst:
-        streams = [None] * world
-        tables = [None] * world
+    start = [0] * (world + 1)
+    for r in range(world):
+        start[r + 1] = start[r] + bits[r]
+    total = start[world]
+    aligned = all(start[r] % 8 == 0 for r in range(world))
+
+    def part_bytes(r):                                   # bytes rank r sends: its bits placed (start % 8) bits into byte 0
+        return ((start[r] % 8) + bits[r] + 7) // 8 if bits[r] else 0
+
+    mine = _shift_left_bits(data, bits[rank], start[rank] % 8) if bits[rank] else data[:0]
+    if rank != dst:
         ops = []
+        if part_bytes(rank):
+            ops.append(dist.P2POp(dist.isend, mine.contiguous(), dst, group))
+        ops.append(dist.P2POp(dist.isend, block_bits.contiguous(), dst, group))
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
+        return None, None
+    out = torch.zeros((total + 7) // 8, dtype=torch.uint8, device=dev) if not aligned else \
+        torch.empty((total + 7) // 8, dtype=torch.uint8, device=dev)
+    parts, tables, ops = [None] * world, [None] * world, []
+    for r in range(world):
+        b0 = start[r] // 8
+        if r == rank:
+            tables[r] = block_bits
+            continue
+        # byte-aligned streams land in place; shifted ones share a seam byte with their neighbour and are OR-ed in below
+        parts[r] = out[b0:b0 + part_bytes(r)] if aligned else torch.empty(part_bytes(r), dtype=torch.uint8, device=dev)
+        tables[r] = torch.empty(nbs[r] + 1, dtype=torch.int64, device=dev)
+        if part_bytes(r):
+            ops.append(dist.P2POp(dist.irecv, parts[r], r, group))
+        ops.append(dist.P2POp(dist.irecv, tables[r], r, group))
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
+    b0 = start[rank] // 8
+    if aligned:
+        out[b0:b0 + part_bytes(rank)] = mine
+    else:
+        parts[rank] = mine
         for r in range(world):
-            if r == rank:
-                streams[r], tables[r] = data[:nbytes], block_bits
-            else:
-                streams[r] = torch.empty(sizes[r], dtype=torch.uint8, device=dev)
-                tables[r] = torch.empty(nbs[r] + 1, dtype=torch.int64, device=dev)
-                if sizes[r]:
-                    ops.append(dist.P2POp(dist.irecv, streams[r], r, group))
-                ops.append(dist.P2POp(dist.irecv, tables[r], r, group))
-        if ops:
-            for q in dist.batch_isend_irecv(ops):
-                q.wait()
-        out = torch.cat(streams)
-        base, parts = 0, []
-        for r in range(world):
-            parts.append(tables[r][:-1] + base)
-            base += sizes[r] * 8
-        parts.append(torch.tensor([base], dtype=torch.int64, device=dev))
-        return out, torch.cat(parts)
-    ops = []
-    if nbytes:
-        ops.append(dist.P2POp(dist.isend, data[:nbytes].contiguous(), dst, group))
-    ops.append(dist.P2POp(dist.isend, block_bits.contiguous(), dst, group))
-    for q in dist.batch_isend_irecv(ops):
-        q.wait()
-    return None, None
+            if part_bytes(r):
+                out[start[r] // 8:start[r] // 8 + part_bytes(r)] |= parts[r]
+    table = torch.cat([tables[r][:-1] + start[r] for r in range(world)] + [torch.tensor([total], dtype=torch.int64, device=dev)])
+    return out, table
 
 
 class ShardedHuffman:
@@ -95,8 +130,8 @@ class ShardedHuffman:
 
 def huffman_compress(shard, engine, dst=0, group=None):
     """Whole-buffer Huffman over a buffer whose contiguous byte ranges live on the ranks of `group` (rank order = byte
-    order; ranges should start on multiples of 32 768 bytes — shard_bytes() with 64 KiB blocks does — so that the tile
-    table of the parallel decoder stays valid).  The reference semantics are kept: ONE tree over the whole buffer
+    order; when every range but the last is a multiple of 32 768 bytes — shard_bytes() with 64 KiB blocks gives that — the
+    result carries the tile table of the parallel decoder, otherwise its `tile_off` is None).  The reference semantics are kept: ONE tree over the whole buffer
     (algorithms/huffman/huffman.c:179-215), tree-path codes, MSB-first u32 words (:18-48, :267-328).
 
     Exchange steps, everything else is per-rank work through `engine`
@@ -156,5 +191,9 @@ def huffman_compress(shard, engine, dst=0, group=None):
         if nwords(r):
             w0 = starts[r] // 32
             out[w0:w0 + nwords(r)] |= parts[r]                                     # seam words are shared: OR-merge
-    tile_table = torch.cat([t[:-1] for t in tiles] + [torch.tensor([total], dtype=torch.int64, device=dev)])
+    # the parallel decoder cuts the OUTPUT into fixed 32 768-byte tiles: the per-rank tables only line up with that grid if
+    # every shard but the last is a whole number of tiles.  Otherwise no table is handed on (the decoder then walks the
+    # stream with one lane, slowly but correctly; k_huff_decode refuses a table that does not fit its grid).
+    aligned = all(int(metas[r][1]) % HUFF_TILE == 0 for r in range(world - 1))
+    tile_table = torch.cat([t[:-1] for t in tiles] + [torch.tensor([total], dtype=torch.int64, device=dev)]) if aligned else None
     return ShardedHuffman(out[: (total + 31) // 32], total, tree, sum(int(m[1]) for m in metas), tile_table)

@@ -76,9 +76,13 @@ uint64_t min(uint64_t a, uint64_t b);
 uint64_t max(uint64_t a, uint64_t b);
 uint32_t hash(uint32_t pattern);                                  /* deflate/lz77.c:14-42 */
 void     init_hash_table(HashTableArray *table);                  /* deflate/lz77.c:44-67: allocates and zeroes, as the reference */
-/* NOT exported: insert_hash_table, find (deflate/lz77.h:32-33): per-entry operations on a host table the GPU path does
- * not have (mi_lz_find_all_dev gives find() for every position of a buffer); lz77_decompress (deflate/lz77.h:54-59): the
- * reference's body discards its output (deflate/lz77.c:282-311) — use decompress() or mi_lz_decode. */
+/* deflate/lz77.h:32-33, deflate/lz77.c:77-174: per-entry operations on the host table above — host helpers (the GPU path
+ * has no table; mi_lz_find_all_dev gives find() for every position of a buffer).  insert wraps modulo TABLE_SIZE, find
+ * stops at the last bucket (the reference reads one element past the array there). */
+void     insert_hash_table(HashTableArray *table, uint32_t pattern, uint64_t index);
+uint64_t find(HashTableArray *table, uint32_t pattern);
+/* NOT exported: lz77_decompress (deflate/lz77.h:54-59): the reference's body discards its output
+ * (deflate/lz77.c:282-311) — use decompress() or mi_lz_decode. */
 void write_literal(char *buffer, char c, uint64_t *buffer_index);                                   /* deflate/lz77.c:176-184 */
 void write_length_distance(char *buffer, uint8_t length, uint16_t distance, uint64_t *buffer_index);   /* deflate/lz77.c:186-197 */
 

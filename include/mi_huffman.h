@@ -64,6 +64,11 @@ Node  huffman_compress(char *buffer, uint64_t size, BitWriter *writer);
 /* *output_size carries the ORIGINAL length on entry (huffman/main.c:69) and the decoded count on return */
 void  huffman_decompress(BitWriter *writer, Node *root, char *output, uint64_t *output_size);
 void  gather_codes(Node *root, uint32_t code, uint32_t length, uint32_t *codes, uint8_t *code_lengths);
+/* huffman.h:108-113 (huffman.c:366-401): the lookup-table decoder the reference left unfinished; the GPU decoder is one,
+ * so this is huffman_decompress under its second name */
+void  huffman_decompress_lookup_table(BitWriter *writer, Node *root, char *output, uint64_t *output_size);
+/* extension: frees writer->buffer and the tile-offset table registered for it (in-process registry, as in mi_lz77.h) */
+void  mi_huffman_release(BitWriter *writer);
 
 /* Extensions (no counterpart in huffman.h): the same codec to and from a self-describing FILE (mi_frame.h: serialised
  * tree + {last_block, size} chunks, after zig_huffman/src/main.zig:155-176,513-530), so that decoding needs neither the

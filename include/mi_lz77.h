@@ -43,7 +43,7 @@ typedef struct {
 } BitStream;
 
 /* algorithms/lz77/lz77.h:19-30, same layout: reference-style callers (`HashTableArray t; init_hash_table(&t);`) compile
- * and run.  The GPU path never materialises this table: see insert_hash_table / find below. */
+ * and run.  The GPU path never materialises this table: insert_hash_table / find below work on it on the host. */
 typedef struct ArrayNode {
     uint32_t pattern;
     uint64_t index;
@@ -63,10 +63,13 @@ uint64_t max(uint64_t a, uint64_t b);
 uint32_t hash(uint32_t pattern);
 /* lz77.h:33, lz77.c:43-53: allocates and zeroes the table exactly like the reference */
 void init_hash_table(HashTableArray *table);
-/* NOT exported: insert_hash_table, find (lz77.h:34-35) — single-entry operations on a host-resident table.  The hot path
- * replaces the table by a per-block replay in LDS and has no per-entry host form; a caller that wants find() for every
- * position of a buffer uses mi_lz_find_all_dev (mi_codec.h).  Also NOT exported: lz77_compress_old (lz77.h:51-54), the
- * reference's unused brute-force parser (commented out at lz77/main.c:26): a different stream, O(n * W) by design. */
+/* lz77.h:34-35, lz77.c:55-108: per-entry operations on the host table above — host helpers (the encoder's table is never
+ * materialised; mi_lz_find_all_dev gives find() for every position of a buffer on the GPU).  Unlike the
+ * reference they stop at the last bucket and exit(1) where the reference's unbounded probe would write past the array. */
+void     insert_hash_table(HashTableArray *table, uint32_t pattern, uint64_t index);
+uint64_t find(HashTableArray *table, uint32_t pattern);
+/* NOT exported: lz77_compress_old (lz77.h:51-54), the reference's unused brute-force parser (commented out at
+ * lz77/main.c:26): a different stream, O(n * W) by design. */
 void  print_bit_string(const char *buffer, uint64_t size);
 char *read_input_buffer(const char *filename, uint64_t *size);
 bool  check_buffer_equivalence(const char *buffer1, const char *buffer2, uint64_t size);
@@ -82,6 +85,12 @@ BitStream *lz77_compress(const char *buffer, uint64_t size);
 /* `size` is the ORIGINAL length (the stream has no header); returns malloc(size) */
 char *lz77_decompress(BitStream *compressed_stream, uint64_t size, uint64_t *decompressed_size);
 
+/* Extensions.  A stream of more than one block keeps its per-block bit offsets in a registry of this library (keyed by the
+ * `data` pointer, in-process only, grows as needed, thread-safe).  mi_lz77_release frees the stream AND its entry; callers
+ * that free ->data and the struct by hand (lz77/main.c:66-67) leave the entry until the address is registered again.
+ * lz77_decompress on a multi-block stream without an entry prints why and exit(1)s (the reference's error convention). */
+void     mi_lz77_release(BitStream *stream);
+uint64_t mi_lz77_registered_streams(void);
 /* run-time override of the window (14 or 16): lets one binary serve both reference builds */
 void mi_lz77_set_window_bits(uint32_t wbits);
 
