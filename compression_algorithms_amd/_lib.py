@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("MI_CODEC_LIB") or os.path.join(LIB_DIR, "libmi_codec.
 MI_OK = 0
 STATUS = {0: "MI_OK", 1: "MI_ERR_ARG", 2: "MI_ERR_HIP", 3: "MI_ERR_NOMEM", 4: "MI_ERR_CAPACITY",
           5: "MI_ERR_EMPTY_INPUT", 6: "MI_ERR_SINGLE_SYMBOL", 7: "MI_ERR_CODE_TOO_LONG", 8: "MI_ERR_CORRUPT",
-          9: "MI_ERR_NO_DEVICE"}
+          9: "MI_ERR_NO_DEVICE", 10: "MI_ERR_UNSTABLE"}
 
 
 class MiError(RuntimeError):
@@ -50,7 +50,7 @@ class KernelTime(C.Structure):
 
 # every symbol include/mi_codec.h declares; tests check that the library exports them all
 EXPORTS = [
-    "mi_ctx_create", "mi_ctx_destroy", "mi_status_str", "mi_last_hip_error", "mi_version", "mi_sync", "mi_validate_block_table",
+    "mi_ctx_create", "mi_ctx_destroy", "mi_status_str", "mi_last_hip_error", "mi_version", "mi_sync", "mi_order_violations", "mi_validate_block_table",
     "mi_huffman_encode_dev", "mi_huffman_encode", "mi_huffman_encode2", "mi_huffman_decode_dev", "mi_huffman_decode",
     "mi_huffman_num_tiles", "mi_huffman_hist_dev", "mi_huffman_build_dev", "mi_huffman_encode_with_tree_dev",
     "mi_huffman_build", "mi_huffman_encode_with_codes",
@@ -87,6 +87,8 @@ def lib():
         L.mi_version.restype = C.c_char_p
         L.mi_last_hip_error.argtypes = [vp]
         L.mi_sync.argtypes = [vp, vp]
+        L.mi_order_violations.restype = C.c_uint32
+        L.mi_order_violations.argtypes = [vp]
         L.mi_validate_block_table.argtypes = [vp, u64, u64, C.c_uint32]
         L.mi_set_profiling.argtypes = [vp, C.c_int]
         L.mi_get_kernel_times.argtypes = [vp, C.POINTER(KernelTime), C.c_int]

@@ -32,6 +32,14 @@ class Context:
     def stream_ptr(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def sync(self):
+        """mi_sync on the current torch stream: raises MiError(MI_ERR_UNSTABLE) if an encoder reported a sort out of order"""
+        _lib.check(self.L.mi_sync(self.h, self.stream_ptr()), "mi_sync")
+
+    def order_violations(self):
+        """sorts found out of (key, time) order by the kernels of this context so far (include/mi_codec.h); 0 on gfx950"""
+        return int(self.L.mi_order_violations(self.h))
+
     def set_profiling(self, on=True):
         _lib.check(self.L.mi_set_profiling(self.h, 1 if on else 0), "mi_set_profiling")
 

@@ -34,6 +34,11 @@ struct mi_ctx {
     int         profiling = 0;
     int         num_cu = 256;
     int         lds_rank_ok = 0;       // LDS returning atomics serve the lanes of one instruction in lane order (self-check at creation)
+    int         test_break_rank = 0;   // MI_LZ_TEST_BREAK_RANK=1: the scatter mis-ranks on purpose (tests of the order check)
+    uint32_t   *h_order = nullptr;     // pinned, device-visible: set by a kernel that found a sort out of order (lz_common.h)
+    uint32_t   *d_order = nullptr;     // the same word as the device addresses it
+    uint32_t    order_violations = 0;  // violations noticed so far (mi_order_poll)
+    uint32_t    order_reported = 0;    // ... and already returned through mi_sync
     // workspace (device), grown on demand, never inside a captured region
     void       *ws = nullptr;
     size_t      ws_bytes = 0;
@@ -63,6 +68,9 @@ struct mi_ctx {
         }                                                                     \
     } while (0)
 
+// has a kernel reported a sort out of order since the last poll?  If so the context ranks with ballots from now on.
+// Returns 1 when a NEW violation was seen.  (The word lives in pinned host memory: no synchronisation.)
+int mi_order_poll(mi_ctx *ctx);
 // grow the context workspace to at least `bytes` (256-byte aligned carve-outs are the caller's job)
 mi_status mi_ws_reserve(mi_ctx *ctx, size_t bytes);
 // a zeroed-on-stream status word for one decode call (never the workspace: two streams may decode at once)

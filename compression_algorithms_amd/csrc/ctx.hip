@@ -56,6 +56,7 @@ const char *mi_status_str(mi_status s)
     case MI_ERR_CODE_TOO_LONG: return "Huffman code longer than 32 bits";
     case MI_ERR_CORRUPT: return "corrupt stream";
     case MI_ERR_NO_DEVICE: return "no HIP device: this library has no CPU fallback";
+    case MI_ERR_UNSTABLE: return "a sort came out unstable (LDS atomics not lane-ordered): encode again, the context now ranks with ballots";
     }
     return "unknown";
 }
@@ -100,7 +101,11 @@ mi_status mi_ctx_create(mi_ctx **out, int device)
         mi_ctx_destroy(c); return MI_ERR_NOMEM;
     }
     if (hipMalloc((void **)&c->d_err, MI_ERR_SLOTS * sizeof(uint32_t)) != hipSuccess) { mi_ctx_destroy(c); return MI_ERR_NOMEM; }
+    if (hipHostMalloc((void **)&c->h_order, 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&c->d_order, c->h_order, 0) != hipSuccess) { mi_ctx_destroy(c); return MI_ERR_NOMEM; }
+    *c->h_order = 0;
     c->lds_rank_ok = lds_rank_selfcheck(c);
+    c->test_break_rank = getenv("MI_LZ_TEST_BREAK_RANK") != nullptr;
     *out = c;
     return MI_OK;
 }
@@ -116,6 +121,7 @@ void mi_ctx_destroy(mi_ctx *c)
     if (c->ws) hipFree(c->ws);
     if (c->d_err) hipFree(c->d_err);
     if (c->h_pinned) hipHostFree(c->h_pinned);
+    if (c->h_order) hipHostFree(c->h_order);
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->side) hipStreamDestroy(c->side);
     if (c->fb) hipStreamDestroy(c->fb);
@@ -137,7 +143,16 @@ mi_status mi_sync(mi_ctx *c, void *stream)
 {
     if (!c) return MI_ERR_ARG;
     MI_HIP(c, hipStreamSynchronize((hipStream_t)stream));
+    mi_order_poll(c);
+    if (c->order_violations != c->order_reported) { c->order_reported = c->order_violations; return MI_ERR_UNSTABLE; }
     return MI_OK;
+}
+
+uint32_t mi_order_violations(mi_ctx *c)
+{
+    if (!c) return 0;
+    mi_order_poll(c);
+    return c->order_violations;
 }
 
 mi_status mi_set_profiling(mi_ctx *c, int on)
@@ -215,6 +230,16 @@ hipStream_t mi_host_stream(mi_ctx *c)
     return c->stream;
 }
 
+
+int mi_order_poll(mi_ctx *c)
+{
+    if (!c->h_order) return 0;
+    const uint32_t v = __atomic_exchange_n(c->h_order, 0u, __ATOMIC_RELAXED);
+    if (!v) return 0;
+    ++c->order_violations;
+    c->lds_rank_ok = 0;                 // ballots from now on (and the test hook, which needs LZP_ARANK, is off with it)
+    return 1;
+}
 
 mi_status mi_ws_reserve(mi_ctx *c, size_t bytes)
 {

@@ -356,7 +356,7 @@ mi_status mi_deflate_h_decode_launch(mi_ctx *ctx, const mi_lz_params *p, const u
     if (st) return st;
     if (!p->deflate || p->lbits > 5 || p->wbits > 16 || ((uintptr_t)d_stream & 3u)) return MI_ERR_ARG;
     if (n == 0) return MI_OK;
-    const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block, ctx->lds_rank_ok ? LZP_ARANK : 0u};
+    const LzP P = lz_params_of(ctx, p);
     const uint64_t nblocks = (n + P.block - 1) / P.block;
     {
         mi_prof_scope pr(ctx, "k_defh_decode", s, n);

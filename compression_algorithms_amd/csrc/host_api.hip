@@ -324,10 +324,39 @@ extern "C" mi_status mi_lz_decode(mi_ctx *ctx, const mi_lz_params *p, const uint
     return MI_OK;
 }
 
+static mi_status deflate_h_encode_once(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *h_in, uint64_t n,
+                                       uint8_t *h_out, uint64_t cap_bytes, uint64_t *h_block_bits);
+
+// A synchronous entry point has its result in hand when it returns, so an order violation reported while it ran (lz_common.h
+// lz_order_violation) is repaired here: the context has switched to ballot ranking, the call encodes once more.
+mi_status mi_encode_again_if_unstable(mi_ctx *ctx, uint32_t seen_before, mi_status st, mi_status (*again)(void *), void *arg)
+{
+    mi_order_poll(ctx);                                                     // (chunked paths poll between their chunks too)
+    if (st != MI_OK || ctx->order_violations == seen_before) return st;
+    const uint32_t seen = ctx->order_violations;
+    st = again(arg);
+    mi_order_poll(ctx);
+    if (st == MI_OK && ctx->order_violations != seen) st = MI_ERR_UNSTABLE; // ballots cannot mis-rank: this does not happen
+    ctx->order_reported = ctx->order_violations;                            // handled here: mi_sync need not repeat it
+    return st;
+}
+
+struct HostEncArgs { mi_ctx *ctx; const mi_lz_params *p; const uint8_t *h_in; uint64_t n; uint8_t *h_out; uint64_t cap; uint64_t *bits; };
+
 extern "C" mi_status mi_deflate_h_encode(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *h_in, uint64_t n,
                                          uint8_t *h_out, uint64_t cap_bytes, uint64_t *h_block_bits)
 {
     if (!ctx || !p || !h_out || !h_block_bits || (n && !h_in) || !p->block) return MI_ERR_ARG;
+    mi_order_poll(ctx);
+    const uint32_t seen = ctx->order_violations;
+    HostEncArgs a{ctx, p, h_in, n, h_out, cap_bytes, h_block_bits};
+    return mi_encode_again_if_unstable(ctx, seen, deflate_h_encode_once(ctx, p, h_in, n, h_out, cap_bytes, h_block_bits),
+        [](void *v) { HostEncArgs *q = (HostEncArgs *)v; return deflate_h_encode_once(q->ctx, q->p, q->h_in, q->n, q->h_out, q->cap, q->bits); }, &a);
+}
+
+static mi_status deflate_h_encode_once(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *h_in, uint64_t n,
+                                       uint8_t *h_out, uint64_t cap_bytes, uint64_t *h_block_bits)
+{
     {
         bool done = false;
         const mi_status ps = mi_encode_host_pipelined(ctx, p, 1, h_in, n, h_out, cap_bytes, h_block_bits, &done);

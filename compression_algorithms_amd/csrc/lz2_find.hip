@@ -242,10 +242,13 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     if (tid == 0) { s_zslot = ~0u; s_zgid = ~0u; s_nbigl = 0; }
     __syncthreads();
     auto homep = [&](uint32_t j) -> uint32_t { return ((s_word[j] & Tmask) - base) & Tmask; };
+    // order checks (lz_common.h lz_order_violation): a part's list must be in time order — the partition's stable pass —
+    bool viol = false;
+    for (uint32_t j = tid + 1; j < m; j += LZ2_THREADS) viol |= s_pos[j - 1] >= s_pos[j];
     LZ2_TICK(0);
 
     // ---- sort time indices by home', stable
-    const bool arank = (P.flags & LZP_ARANK) != 0;
+    const uint32_t arank = P.flags & (LZP_ARANK | LZP_BREAK);
     auto keyp = [&](uint32_t j) -> uint32_t { return homep(j) - plo_; };
     uint16_t *srt = s_j0;                                   // where the home order ends up
     if (three) {
@@ -287,8 +290,8 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
         }
         int32_t gmax_total;
         const int32_t premax = block_exclusive_scan<int32_t>(mx, OpMaxI32(), INT32_MIN, s_i32, &gmax_total);
-        int32_t prev_h0 = 0;
-        if (k0 > 0 && k0 < m) prev_h0 = (int32_t)homep(s_j0[k0 - 1]);
+        int32_t prev_h0 = 0; uint32_t prev_j = 0;
+        if (k0 > 0 && k0 < m) { prev_j = s_j0[k0 - 1]; prev_h0 = (int32_t)homep(prev_j); }
         uint32_t nheads = 0; int32_t lasthead = -1, lastrun = -1;
         {
             int32_t run = premax, prev_h = prev_h0;
@@ -337,6 +340,9 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
                 const bool head = (k == 0) || (g >= run);
                 run = g > run ? g : run;
                 const uint32_t w = rw[c];
+                // ... and the home sort must have left (home, time) ascending: the check of every pass at once
+                if (k > 0 && (h < prev_h || (h == prev_h && j < prev_j))) viol = true;
+                prev_j = j;
                 if (head) {
                     cur_gs = k; cur_base = h; cur_gid = gid_base + seen; ++seen;
                     // cursor of the cluster for the one-pass placement below: its first index in replay order (a cluster
@@ -355,7 +361,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
                 s_r[j] = (uint16_t)(cur_gs + (uint32_t)(h - cur_base));
                 // a cluster whose entries do not all share one home needs its (home, time) order re-sorted by time below;
                 // the others (nearly all) are in time order as they stand.  s_bm is free until the replay.
-                if (arank && h != cur_base) atomicOr(&s_bm[cur_gid >> 5], 1u << (cur_gid & 31u));
+                if ((arank & LZP_ARANK) && h != cur_base) atomicOr(&s_bm[cur_gid >> 5], 1u << (cur_gid & 31u));
                 // the word's identity is the POSITION of its first occurrence in the block (the home order is stable in
                 // time).  While nothing of a cluster has been evicted that position is also what find() returns: the first
                 // copy sits at the lowest slot of the word and every slot between the home and it stays occupied.
@@ -363,6 +369,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
             }
         }
     }
+    if (viol) { lz_order_violation(P); viol = false; }
     __syncthreads();
     if (!P.deflate && W >= nblk) {
         // lz77 flavour with a window that covers the block (the 64 KiB-window build): nothing is ever retired, find() never
@@ -400,7 +407,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     static_assert(LZ2_CAP <= 8192, "cluster numbers must fit 13 bits");
     constexpr int GB2 = LZ2_CAP > 4096 ? 7 : 6;          // bits of the second cluster-number pass
     static_assert(2 * LZ2_CAP <= sizeof(uint32_t) * (LZ2_NWAVES + 1) * 256, "the cluster cursors live in the radix counters");
-    if (arank) {
+    if (arank & LZP_ARANK) {
         // ONE pass, no counting: the sweep left every cluster's first replay index as a 16-bit cursor; an entry's place is its
         // cluster's cursor, post-incremented — in TIME order.  Time order needs every cursor to be advanced by one wave only
         // (a wave's LDS instructions execute in order, and the lanes of one returning add are served in lane order: the
@@ -457,11 +464,16 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
         if (i < m) {
             const uint32_t j = s_j1[i];
             const bool head = (i == 0) || (s_g[j] != s_g[s_j1[i - 1]]);
+            if (i > 0) {                                       // the (cluster, time) order, however it was made
+                const uint32_t jp = s_j1[i - 1], gp = s_g[jp], gj = s_g[j];
+                if (gp > gj || (gp == gj && jp > j)) viol = true;
+            }
             regs[c][0] = s_pos[j];
             regs[c][1] = (uint32_t)s_r[j] | (head ? RS_HEAD : 0u);
             regs[c][2] = (uint32_t)s_pid[j] | ((uint32_t)s_g[j] << 16);
         }
     }
+    if (viol) lz_order_violation(P);
     __syncthreads();
     uint16_t *occ = s_g;                    // cluster numbers are dead from here on, except the one remembered in s_zgid
     uint16_t *cand_i = s_r;

@@ -252,7 +252,7 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     radix_pass_1024<LZ2_PARTBITS, uint32_t>(n, s_cnt,
         [&](uint32_t i) { return i | ((uint32_t)part_in[i] << 16); },
         [&](uint32_t e) { return e >> 16; },
-        [&](uint32_t j, uint32_t e) { plist[j] = (uint16_t)e; }, (P.flags & LZP_ARANK) != 0);
+        [&](uint32_t j, uint32_t e) { plist[j] = (uint16_t)e; }, P.flags & (LZP_ARANK | LZP_BREAK));
     PT_TICK(6);
     if (sc.dbg && tid == 0) atomicAdd((unsigned long long *)&sc.dbg[47], 1ull);
 }

@@ -26,8 +26,31 @@
 struct LzP {
     uint32_t wbits, lbits, tbits, deflate, block;
     uint32_t flags;        // LZP_ARANK: the context's self-check found LDS returning atomics lane-ordered (ctx.hip)
+    uint32_t *order_flag;  // host-visible word of the context: a consumer that finds a sort out of order sets it (below)
 };
 #define LZP_ARANK 1u
+#define LZP_BREAK 2u       // TEST ONLY (MI_LZ_TEST_BREAK_RANK=1): the scatter swaps the ranks of neighbouring lanes with equal digits
+
+// The stable radix scatter under LZP_ARANK ranks by the order in which ONE returning LDS add serves the lanes that hit one
+// address — lane order on gfx950, measured (scripts/micro/lds_atomic_order.hip) and probed once per context (ctx.hip), but
+// not an ISA promise.  An unstable sort would still round-trip (find() would pick a later copy of a word: a valid,
+// different stream), so stability is CHECKED where every sort is consumed, for a few compares per entry: the final order
+// must be ascending in (key, time).  A violation sets this word in pinned host memory; the context then ranks with
+// ballots from its next call on, mi_sync() / mi_order_violations() report it (MI_ERR_UNSTABLE), and the host-buffer
+// entry points — which wait for their result anyway — encode again with ballots before they return.
+__device__ __forceinline__ void lz_order_violation(const LzP &P)
+{
+    if (P.order_flag) __hip_atomic_fetch_or(P.order_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// kernel parameters of one call: the caller's mi_lz_params + what the context knows (ranking mode, order-violation word)
+static inline LzP lz_params_of(mi_ctx *ctx, const mi_lz_params *p)
+{
+    mi_order_poll(ctx);                                             // a violation reported by an earlier call switches to ballots
+    uint32_t fl = ctx->lds_rank_ok ? LZP_ARANK : 0u;
+    if (fl && ctx->test_break_rank) fl |= LZP_BREAK;
+    return LzP{p->wbits, p->lbits, p->tbits, p->deflate, p->block, fl, ctx->d_order};
+}
 
 // per-block record written by k_lz_sort_home
 struct LzBlockMeta {
@@ -181,7 +204,7 @@ struct OpAm { __device__ uint64_t operator()(uint64_t earlier, uint64_t later) c
 struct RadixNoHook { __device__ __forceinline__ void operator()(uint32_t, uint32_t) const {} };
 template <int NWAVES> __device__ __forceinline__ uint32_t radix_seg(uint32_t n) { return ((n + (uint32_t)(NWAVES * 64) - 1u) / (uint32_t)(NWAVES * 64)) * 64u; }
 template <int NWAVES, int NBITS, typename E, typename CntRow, typename Load, typename Digit, typename Store, typename Hook = RadixNoHook>
-__device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load, Digit digit, Store store, bool arank = false, uint64_t *dbg = nullptr,
+__device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load, Digit digit, Store store, uint32_t arank = 0u /* LZP_ARANK | LZP_BREAK */, uint64_t *dbg = nullptr,
                                            bool counted = false, Hook hook = Hook())
 {
     long long tk_ = dbg ? clock64() : 0;
@@ -227,7 +250,7 @@ __device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load,
     }
     __syncthreads();
     RP_TICK(9);
-    if (arank) {
+    if (arank & LZP_ARANK) {
         // Rank by the LDS itself: a returning add on the (digit, wave) cursor hands every lane of the instruction its slot,
         // and lanes that hit one address are served in LANE order (measured on gfx950, scripts/micro/lds_atomic_order.hip;
         // the context re-checks it when it is created and clears LZP_ARANK otherwise) — so the pass stays stable with ~10
@@ -242,6 +265,16 @@ __device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load,
             for (int u = 0; u < 4; ++u) { ee[u] = E{}; dg[u] = 0; if (i + 64u * u < b) { ee[u] = load(i + 64u * u); dg[u] = digit(ee[u]); } }
 #pragma unroll
             for (int u = 0; u < 4; ++u) sl[u] = (i + 64u * u < b) ? atomicAdd(&cnt[dg[u] * ST + wave], 1u) : 0u;
+            if (arank & LZP_BREAK) {
+                // test hook: what an out-of-order atomic would do — neighbours with one digit trade places (still a permutation)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool v = i + 64u * u < b;
+                    const uint32_t dn = __shfl_xor(dg[u], 1), sn = __shfl_xor(sl[u], 1);
+                    const bool vn = __shfl_xor(v ? 1 : 0, 1) != 0;
+                    if (v && vn && dn == dg[u]) sl[u] = sn;
+                }
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) if (i + 64u * u < b) { store(sl[u], ee[u]); hook(sl[u], (uint32_t)ee[u]); }
         }
@@ -286,7 +319,7 @@ __device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load,
 // 2 x 8 bits (12.35 vs 13.1 GB/s); it was removed.
 
 template <int NBITS, typename E, typename CntRow, typename Load, typename Digit, typename Store>
-__device__ __forceinline__ void radix_pass_1024(uint32_t n, CntRow *s_cnt, Load load, Digit digit, Store store, bool arank = false)
+__device__ __forceinline__ void radix_pass_1024(uint32_t n, CntRow *s_cnt, Load load, Digit digit, Store store, uint32_t arank = 0u)
 {
     radix_pass<16, NBITS, E>(n, s_cnt, load, digit, store, arank);
 }

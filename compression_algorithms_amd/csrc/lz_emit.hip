@@ -522,7 +522,7 @@ static mi_status lz_encode_impl(mi_ctx *ctx, const mi_lz_params *p, const uint8_
     if (mode_h && (!p->deflate || p->lbits > 5 || p->wbits > 16)) return MI_ERR_ARG;
     if (cap_bytes < (mode_h ? mi_deflate_h_bound_bytes(n, p) : mi_lz_bound_bytes(n, p))) return MI_ERR_CAPACITY;
     hipStream_t s = (hipStream_t)stream;
-    const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block, ctx->lds_rank_ok ? LZP_ARANK : 0u};
+    const LzP P = lz_params_of(ctx, p);
     const uint64_t nblocks = (n + P.block - 1) / P.block;
     if (P.block > LZ_MAX_BLOCK) {
         // blocks above 64 KiB (lz77 flavour): the HBM-resident finder of lzw.hip, one stream, batches sized by workspace
@@ -642,10 +642,25 @@ extern "C" mi_status mi_deflate_h_encode_dev(mi_ctx *ctx, const mi_lz_params *p,
     return lz_encode_impl(ctx, p, d_in, n, d_out, cap_bytes, d_block_bits, stream, 1);
 }
 
+mi_status mi_encode_again_if_unstable(mi_ctx *ctx, uint32_t seen_before, mi_status st, mi_status (*again)(void *), void *arg);     // host_api.hip
+static mi_status lz_encode_host_once(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *h_in, uint64_t n,
+                                     uint8_t *h_out, uint64_t cap_bytes, uint64_t *h_block_bits);
+struct LzHostEncArgs { mi_ctx *ctx; const mi_lz_params *p; const uint8_t *h_in; uint64_t n; uint8_t *h_out; uint64_t cap; uint64_t *bits; };
+
 extern "C" mi_status mi_lz_encode(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *h_in, uint64_t n,
                                   uint8_t *h_out, uint64_t cap_bytes, uint64_t *h_block_bits)
 {
     if (!ctx || !h_out || !h_block_bits || (n && !h_in) || !p) return MI_ERR_ARG;
+    mi_order_poll(ctx);
+    const uint32_t seen = ctx->order_violations;
+    LzHostEncArgs a{ctx, p, h_in, n, h_out, cap_bytes, h_block_bits};
+    return mi_encode_again_if_unstable(ctx, seen, lz_encode_host_once(ctx, p, h_in, n, h_out, cap_bytes, h_block_bits),
+        [](void *v) { LzHostEncArgs *q = (LzHostEncArgs *)v; return lz_encode_host_once(q->ctx, q->p, q->h_in, q->n, q->h_out, q->cap, q->bits); }, &a);
+}
+
+static mi_status lz_encode_host_once(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *h_in, uint64_t n,
+                                     uint8_t *h_out, uint64_t cap_bytes, uint64_t *h_block_bits)
+{
     const uint64_t nblocks = p->block ? (n + p->block - 1) / p->block : 0;
     const uint64_t bound = mi_lz_bound_bytes(n, p);
     if (cap_bytes < bound) return MI_ERR_CAPACITY;
@@ -679,7 +694,7 @@ mi_status mi_lz_decode_launch(mi_ctx *ctx, const mi_lz_params *p, const uint8_t 
     mi_status st = lz_check_params(p);
     if (st) return st;
     if (n == 0) return MI_OK;
-    const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block, ctx->lds_rank_ok ? LZP_ARANK : 0u};
+    const LzP P = lz_params_of(ctx, p);
     const uint64_t nblocks = (n + P.block - 1) / P.block;
     mi_prof_scope pr(ctx, "k_lz_decode", s, n);
     lz_launch_decode(d_stream, stream_bytes, d_block_bits, P, d_out, n, nblocks, err, s);       // any block size

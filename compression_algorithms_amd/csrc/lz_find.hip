@@ -631,7 +631,7 @@ extern "C" mi_status mi_lz_find_all_dev(mi_ctx *ctx, const mi_lz_params *p, cons
     if (st) return st;
     if (n == 0) return MI_OK;
     hipStream_t s = (hipStream_t)stream;
-    const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block, ctx->lds_rank_ok ? LZP_ARANK : 0u};
+    const LzP P = lz_params_of(ctx, p);
     const uint64_t nblocks = (n + P.block - 1) / P.block;
     const uint32_t nbmax = lz_batch_blocks(nblocks);
     st = mi_ws_reserve(ctx, lz_scratch_bytes(nbmax));
@@ -670,7 +670,7 @@ extern "C" mi_status mi_lz_find_all32_dev(mi_ctx *ctx, const mi_lz_params *p, co
     if (p->block <= LZ_MAX_BLOCK) return MI_ERR_ARG;
     if (n == 0) return MI_OK;
     hipStream_t s = (hipStream_t)stream;
-    const LzP P{p->wbits, p->lbits, p->tbits, p->deflate, p->block, ctx->lds_rank_ok ? LZP_ARANK : 0u};
+    const LzP P = lz_params_of(ctx, p);
     const uint64_t nblocks = (n + P.block - 1) / P.block;
     uint32_t nbw = lzw_batch_blocks(ctx, nblocks, P.block);
     while ((st = mi_ws_reserve(ctx, lzw_scratch_bytes(nbw, P.block) + 4096)) == MI_ERR_NOMEM && nbw > 1) nbw = (nbw + 1) / 2;

@@ -257,7 +257,7 @@ void k_lzs_part(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     radix_pass_1024<LZS_PARTBITS, uint32_t>(NE, s_cnt,
         [&](uint32_t i) { return i | ((uint32_t)part_in[i] << 24); },
         [&](uint32_t e) { return e >> 24; },
-        [&](uint32_t j, uint32_t e) { if ((e >> 24) != LZS_MAXPARTS - 1u) plist[j] = e & 0xFFFFFFu; }, (P.flags & LZP_ARANK) != 0);
+        [&](uint32_t j, uint32_t e) { if ((e >> 24) != LZS_MAXPARTS - 1u) plist[j] = e & 0xFFFFFFu; }, P.flags & (LZP_ARANK | LZP_BREAK));
 }
 
 // =============================================================================================
@@ -343,8 +343,9 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     const uint32_t *slot_old = sc.slot + (size_t)lb * sc.S + (t0 - (step ? W : 0u));
     uint32_t *slot_new = sc.slot + (size_t)lb * sc.S + t0;
     uint32_t *cand = sc.cand + (size_t)lb * sc.S + t0;
-    const bool arank = (P.flags & LZP_ARANK) != 0;
+    const uint32_t arank = P.flags & (LZP_ARANK | LZP_BREAK);
     constexpr uint32_t CH = LZS_CAP / LZS_THREADS;
+    bool viol = false;                                   // order checks (lz_common.h lz_order_violation)
 
     // the sort's digits are counted where they are in hand (k_lz2_find): the first pass's here, while the coordinates are put
     // together, each later pass's while the one before it scatters; the second counter array sits in the idle s_g / s_r
@@ -358,7 +359,11 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     {
         uint32_t ge[CH], gk[CH], gs[CH];
 #pragma unroll
-        for (uint32_t c = 0; c < CH; ++c) { const uint32_t j = tid + c * LZS_THREADS; ge[c] = j < m ? plist[j] : 0u; }
+        for (uint32_t c = 0; c < CH; ++c) {
+            const uint32_t j = tid + c * LZS_THREADS;
+            ge[c] = j < m ? plist[j] : 0u;
+            if (j > 0 && j < m) viol |= plist[j - 1] >= ge[c];          // a part's list is in event order: k_lzs_part's stable pass
+        }
 #pragma unroll
         for (uint32_t c = 0; c < CH; ++c) {
             const uint32_t j = tid + c * LZS_THREADS, t = ge[c] >> 1;
@@ -449,6 +454,8 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
         uint32_t cur_gs = 0, cur_gid = gid_base; int32_t cur_base = 0;
         if (k0 < m && gs_carry >= 0) { cur_gs = (uint32_t)gs_carry; cur_base = (int32_t)keyp(s_j0[cur_gs]); cur_gid = gid_base - 1u; }
         uint32_t seen = 0;
+        int32_t prev_h = 0; uint32_t prev_j = 0;
+        if (k0 > 0 && k0 < m) { prev_j = s_j0[k0 - 1]; prev_h = (int32_t)keyp(prev_j); }
 #pragma unroll
         for (uint32_t c = 0; c < CH; ++c) {
             const uint32_t k = k0 + c;
@@ -457,6 +464,8 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
                 const int32_t h = rh[c], g = h - (int32_t)k;
                 const bool head = (k == 0) || (g >= run);
                 run = g > run ? g : run;
+                if (k > 0 && (h < prev_h || (h == prev_h && j < prev_j))) viol = true;      // (coordinate, event) ascending
+                prev_h = h; prev_j = j;
                 if (head) { cur_gs = k; cur_base = h; cur_gid = gid_base + seen; ++seen; cur16[cur_gid] = (uint16_t)k; }
                 s_g[j] = (uint16_t)cur_gid;
                 s_r[j] = (uint16_t)(cur_gs + (uint32_t)(h - cur_base));
@@ -469,7 +478,7 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
 
     // ---- (cluster, event) order: an entry's place is its cluster's cursor, post-incremented in event order (lz2_find.hip:
     //      every cursor pair is advanced by one wave only; LDS is in order, returning adds are served in lane order)
-    if (arank) {
+    if (arank & LZP_ARANK) {
         uint32_t *cur32 = &s_cnt[0][0];
         const uint32_t wv = (uint32_t)tid >> 6, ln = (uint32_t)tid & 63u;
         for (uint32_t j0 = 0; j0 < m; j0 += 256u) {
@@ -521,10 +530,15 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
             rk[c] = 0; rr[c] = 0;
             if (i < m) {
                 const uint32_t j = s_j1[i], cf = s_c[j];
+                if (i > 0) {                                 // the (cluster, event) order, however it was made
+                    const uint32_t jp = s_j1[i - 1], gp = s_g[jp], gj = s_g[j];
+                    if (gp > gj || (gp == gj && jp > j)) viol = true;
+                }
                 rk[c] = s_key[j];
                 rr[c] = (uint32_t)s_r[j] | ((cf & CF_OLD) ? RF_OLD : 0u) | ((cf & CF_DEAD) ? RF_DEAD : 0u);
             }
         }
+        if (viol) lz_order_violation(P);
         __syncthreads();
 #pragma unroll
         for (uint32_t c = 0; c < CH; ++c) {

@@ -72,7 +72,9 @@ void k_lzw_sort(uint64_t n_total, LzP P, LzwScratch sc, uint64_t block0, uint32_
         for (uint32_t p = threadIdx.x; p < n; p += 1024) a[p] = ((uint64_t)g[p] << 32) | p;
         __syncthreads();
     }
-    const bool arank = (P.flags & LZP_ARANK) != 0;
+    // ballots always: this finder is the exact fallback behind lzs.hip (and what MI_LZW_SLICED=0 selects) — it must not
+    // lean on the lane order of LDS atomics that the fast paths use and check (lz_common.h lz_order_violation)
+    const uint32_t arank = 0u;
     for (uint32_t pass = 0; pass < npass; ++pass) {
         const uint64_t *src = (pass & 1u) ? b : a;
         uint64_t *dst = (pass & 1u) ? a : b;

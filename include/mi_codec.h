@@ -45,7 +45,8 @@ typedef enum {
     MI_ERR_SINGLE_SYMBOL = 6,  /* reference: "ERROR: No code for character" exit(1) huffman.c:278-281 */
     MI_ERR_CODE_TOO_LONG = 7,  /* a Huffman code > 32 bits: the reference silently emits garbage (u32 code) */
     MI_ERR_CORRUPT = 8,        /* decoder: malformed stream                                  */
-    MI_ERR_NO_DEVICE = 9       /* no gfx950 device / HIP runtime: there is NO CPU fallback   */
+    MI_ERR_NO_DEVICE = 9,      /* no gfx950 device / HIP runtime: there is NO CPU fallback   */
+    MI_ERR_UNSTABLE = 10       /* a kernel found one of its sorts out of (key, time) order: see mi_order_violations */
 } mi_status;
 
 typedef struct mi_ctx mi_ctx;
@@ -56,8 +57,17 @@ void        mi_ctx_destroy(mi_ctx *ctx);
 const char *mi_status_str(mi_status s);
 int         mi_last_hip_error(const mi_ctx *ctx);
 const char *mi_version(void);
-/* blocks until everything queued on `stream` has finished */
+/* blocks until everything queued on `stream` has finished.  Returns MI_ERR_UNSTABLE once if an encoder kernel reported a
+ * sort out of order since the last call (below): the stream it was building is valid but may not be the reference's. */
 mi_status   mi_sync(mi_ctx *ctx, void *stream);
+/* The match finders sort positions by bucket with LDS radix passes whose ranks come from returning LDS atomics — stable
+ * only if the hardware serves the lanes of one such instruction in lane order.  gfx950 does (probed when the context is
+ * created; MI_LZ_NO_ARANK=1 forces the ballot ranking), the ISA does not promise it, and an unstable sort would still
+ * round-trip.  So every consumer of a sort checks its order, and a violation is never silent: it is counted here, the
+ * context ranks with ballots from its next call on, mi_sync() returns MI_ERR_UNSTABLE once, and the host-buffer entry points
+ * (mi_lz_encode, mi_deflate_h_encode — what the drop-ins call) encode again before they return.  A caller of the
+ * asynchronous *_dev encoders re-encodes when mi_sync says so.  Returns the number of violations seen by this context. */
+uint32_t    mi_order_violations(mi_ctx *ctx);
 /* Host-side check of a block table (exclusive prefix of per-block stream lengths in BITS, nblocks+1 entries) that came
  * from a file or a peer: non-decreasing, every entry a multiple of align_bits (1: bit-packed lz77; 8: deflate tokens;
  * 32: mode-H and FSE records), last entry <= 8 * stream_bytes.  MI_OK or MI_ERR_CORRUPT.  The host-buffer decoders call

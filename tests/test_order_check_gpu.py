@@ -1,0 +1,100 @@
+"""The stable radix scatters rank by the order in which one returning LDS atomic serves its lanes (lz_common.h radix_pass,
+LZP_ARANK) — lane order on gfx950, not an ISA promise.  Every consumer of a sort checks the
+final (key, time) order; a violation must never be silent.  MI_LZ_TEST_BREAK_RANK=1 makes the scatter mis-rank on purpose
+(neighbouring lanes with one digit trade places: what an out-of-order atomic would do):
+
+  * the asynchronous device encoders report it (mi_order_violations, mi_sync -> MI_ERR_UNSTABLE) and the context ranks
+    with ballots from its next call on — the second encode is the oracle's stream;
+  * the host-buffer entry points (what the drop-ins call) encode again by themselves and return the oracle's stream;
+  * an undisturbed context counts no violation on any flavour."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from compression_algorithms_amd import _lib, lz, synth
+from compression_algorithms_amd.context import Context
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_deflate(data):
+    from oracle import orc
+    return orc.deflate_stream(data, 65536, True)[0]
+
+
+@pytest.mark.parametrize("shape", ["deflate", "lz77w14", "lz77w16-256k"])
+def test_broken_ranking_is_noticed_and_the_context_recovers(monkeypatch, shape):
+    from oracle import orc
+    monkeypatch.setenv("MI_LZ_TEST_BREAK_RANK", "1")
+    ctx = Context(0)
+    if not ctx.L.mi_order_violations:
+        pytest.skip("no order check in this build")
+    p = {"deflate": lz.params("deflate"), "lz77w14": lz.params("lz77", 14), "lz77w16-256k": lz.params("lz77", 16, 262144)}[shape]
+    data = synth.enwik_like(3 * p.block + 1234, seed=91).numpy()
+
+    def want_of(p):
+        if p.deflate:
+            return _oracle_deflate(data), None
+        blocks = [orc.lz77_encode(data[a:a + p.block], p.wbits, 4) for a in range(0, len(data), p.block)]
+        return blocks, np.concatenate([[0], np.cumsum([nb for _, nb in blocks])])
+
+    first = lz.compress(data, p, ctx)
+    torch.cuda.synchronize()
+    assert ctx.order_violations() >= 1, "the mis-ranked scatter went unnoticed"
+    with pytest.raises(_lib.MiError) as e:
+        ctx.sync()
+    assert e.value.status == 10                              # MI_ERR_UNSTABLE, once
+    ctx.sync()
+    assert np.array_equal(lz.decompress(first, ctx).cpu().numpy(), data)      # (an unstable sort still round-trips: why it must be checked)
+    seen = ctx.order_violations()
+    second = lz.compress(data, p, ctx)                         # ballots now: the reference's stream
+    ctx.sync()
+    assert ctx.order_violations() == seen
+    want, tb = want_of(p)
+    if p.deflate:
+        assert np.array_equal(second.data[: second.nbytes].cpu().numpy(), want)
+    else:
+        assert np.array_equal(second.block_bits.cpu().numpy(), tb)
+        bits = np.unpackbits(second.data[: second.nbytes].cpu().numpy(), bitorder="little")
+        for b, (s, nb) in enumerate(want):
+            assert np.array_equal(bits[tb[b]:tb[b + 1]], np.unpackbits(s, bitorder="little")[:nb]), b
+
+
+@pytest.mark.parametrize("mode_h", [False, True])
+def test_host_entry_points_encode_again_by_themselves(monkeypatch, mode_h):
+    from oracle import orc
+    monkeypatch.setenv("MI_LZ_TEST_BREAK_RANK", "1")
+    ctx = Context(0)
+    p = lz.params("deflate")
+    data = synth.enwik_like(5 * 65536 + 99, seed=92).numpy()
+    n = len(data)
+    nblocks = (n + 65535) // 65536
+    cap = (int(ctx.L.mi_deflate_h_bound_bytes(n, C.byref(p))) if mode_h else lz.bound_bytes(n, p)) + 64
+    out = np.zeros(cap, np.uint8)
+    bits = np.zeros(nblocks + 1, np.uint64)
+    fn = ctx.L.mi_deflate_h_encode if mode_h else ctx.L.mi_lz_encode
+    rc = fn(ctx.h, C.byref(p), C.c_void_p(data.ctypes.data), C.c_uint64(n), C.c_void_p(out.ctypes.data), C.c_uint64(cap), C.c_void_p(bits.ctypes.data))
+    assert rc == 0
+    assert ctx.order_violations() >= 1
+    ctx.sync()                                                  # handled inside the call: nothing left to report
+    tok, sizes = orc.deflate_stream(data, 65536, True)
+    if not mode_h:
+        assert np.array_equal(out[: int(bits[-1]) // 8], tok)
+    else:
+        at = 0
+        for b, s in enumerate(sizes):
+            want = orc.defh_encode_block(tok[at:at + int(s)])
+            at += int(s)
+            assert np.array_equal(out[int(bits[b]) // 8:int(bits[b + 1]) // 8], want), b
+
+
+def test_an_undisturbed_context_counts_nothing():
+    ctx = Context(0)
+    x = synth.enwik_like(40 * 65536 + 5, seed=93, device="cuda")
+    for p in (lz.params("deflate"), lz.params("lz77", 14), lz.params("lz77", 16), lz.params("lz77", 16, 262144)):
+        lz.compress(x, p, ctx)
+    lz.compress_h(x, lz.params("deflate"), ctx)
+    ctx.sync()
+    assert ctx.order_violations() == 0
