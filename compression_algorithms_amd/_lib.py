@@ -87,8 +87,9 @@ def lib():
         L.mi_version.restype = C.c_char_p
         L.mi_last_hip_error.argtypes = [vp]
         L.mi_sync.argtypes = [vp, vp]
-        L.mi_order_violations.restype = C.c_uint32
-        L.mi_order_violations.argtypes = [vp]
+        if hasattr(L, "mi_order_violations"):                 # (absent from older builds used in A/B runs through MI_CODEC_LIB)
+            L.mi_order_violations.restype = C.c_uint32
+            L.mi_order_violations.argtypes = [vp]
         L.mi_validate_block_table.argtypes = [vp, u64, u64, C.c_uint32]
         L.mi_set_profiling.argtypes = [vp, C.c_int]
         L.mi_get_kernel_times.argtypes = [vp, C.POINTER(KernelTime), C.c_int]

@@ -257,7 +257,7 @@ void k_lzs_part(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     radix_pass_1024<LZS_PARTBITS, uint32_t>(NE, s_cnt,
         [&](uint32_t i) { return i | ((uint32_t)part_in[i] << 24); },
         [&](uint32_t e) { return e >> 24; },
-        [&](uint32_t j, uint32_t e) { if ((e >> 24) != LZS_MAXPARTS - 1u) plist[j] = e & 0xFFFFFFu; }, P.flags & (LZP_ARANK | LZP_BREAK));
+        [&](uint32_t j, uint32_t e) { if ((e >> 24) != LZS_MAXPARTS - 1u) plist[j] = e & 0xFFFFFFu; }, P.flags & LZP_ARANK);
 }
 
 // =============================================================================================
@@ -343,7 +343,7 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     const uint32_t *slot_old = sc.slot + (size_t)lb * sc.S + (t0 - (step ? W : 0u));
     uint32_t *slot_new = sc.slot + (size_t)lb * sc.S + t0;
     uint32_t *cand = sc.cand + (size_t)lb * sc.S + t0;
-    const uint32_t arank = P.flags & (LZP_ARANK | LZP_BREAK);
+    const uint32_t arank = P.flags & LZP_ARANK;          // (the test hook LZP_BREAK is for the 64 KiB pipeline only: this replay trusts event order for its indices)
     constexpr uint32_t CH = LZS_CAP / LZS_THREADS;
     bool viol = false;                                   // order checks (lz_common.h lz_order_violation)
 
