@@ -192,6 +192,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     const uint32_t seg = radix_seg<LZ2_NWAVES>(m), seg_inv = (uint32_t)((0x100000000ull + seg - 1u) / seg);   // i / seg = umulhi(i, seg_inv) for i < 2^16
     for (uint32_t i = tid; i < 256u * RST; i += LZ2_THREADS) { cntA[i] = 0; cntB[i] = 0; }
 
+    bool viol = false;
     // ---- gather: positions (coalesced) and their words (4 unaligned bytes each from the block; bytes
     //      past the block end read as zero, the parity definition of the reference's over-read)
     {
@@ -202,6 +203,15 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
         const bool aligned = (((uintptr_t)src) & 3u) == 0;
 #pragma unroll
         for (uint32_t c = 0; c < GCH; ++c) { const uint32_t j = tid + c * LZ2_THREADS; gp[c] = j < m ? (uint32_t)plist[j] : 0u; }
+        // order check 1 of 3 (lz_common.h lz_order_violation): a part's list must be in time order — the partition's stable
+        // pass.  The neighbour's position comes from the lane below (the first lane of a wave reads it from the list).
+#pragma unroll
+        for (uint32_t c = 0; c < GCH; ++c) {
+            const uint32_t j = tid + c * LZ2_THREADS;
+            uint32_t prev = __shfl_up(gp[c], 1);
+            if ((tid & 63) == 0 && j > 0 && j < m) prev = plist[j - 1];
+            if (j > 0 && j < m && prev >= gp[c]) viol = true;
+        }
 #pragma unroll
         for (uint32_t c = 0; c < GCH; ++c) {
             const uint32_t j = tid + c * LZ2_THREADS, p = gp[c];
@@ -242,9 +252,6 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     if (tid == 0) { s_zslot = ~0u; s_zgid = ~0u; s_nbigl = 0; }
     __syncthreads();
     auto homep = [&](uint32_t j) -> uint32_t { return ((s_word[j] & Tmask) - base) & Tmask; };
-    // order checks (lz_common.h lz_order_violation): a part's list must be in time order — the partition's stable pass —
-    bool viol = false;
-    for (uint32_t j = tid + 1; j < m; j += LZ2_THREADS) viol |= s_pos[j - 1] >= s_pos[j];
     LZ2_TICK(0);
 
     // ---- sort time indices by home', stable

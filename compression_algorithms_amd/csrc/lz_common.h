@@ -29,7 +29,7 @@ struct LzP {
     uint32_t *order_flag;  // host-visible word of the context: a consumer that finds a sort out of order sets it (below)
 };
 #define LZP_ARANK 1u
-#define LZP_BREAK 2u       // TEST ONLY (MI_LZ_TEST_BREAK_RANK=1): the scatter swaps the ranks of neighbouring lanes with equal digits
+#define LZP_BREAK 2u       // TEST BUILD ONLY (-DMI_TEST_HOOKS, MI_LZ_TEST_BREAK_RANK=1): the scatter swaps the ranks of neighbouring lanes with equal digits
 
 // The stable radix scatter under LZP_ARANK ranks by the order in which ONE returning LDS add serves the lanes that hit one
 // address — lane order on gfx950, measured (scripts/micro/lds_atomic_order.hip) and probed once per context (ctx.hip), but
@@ -265,6 +265,7 @@ __device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load,
             for (int u = 0; u < 4; ++u) { ee[u] = E{}; dg[u] = 0; if (i + 64u * u < b) { ee[u] = load(i + 64u * u); dg[u] = digit(ee[u]); } }
 #pragma unroll
             for (int u = 0; u < 4; ++u) sl[u] = (i + 64u * u < b) ? atomicAdd(&cnt[dg[u] * ST + wave], 1u) : 0u;
+#ifdef MI_TEST_HOOKS                                       /* compiled only into lib_test/ (csrc/Makefile): the hook cost the shipped scatter 2.5 % */
             if (arank & LZP_BREAK) {
                 // test hook: what an out-of-order atomic would do — neighbours with one digit trade places (still a permutation)
 #pragma unroll
@@ -275,6 +276,7 @@ __device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load,
                     if (v && vn && dn == dg[u]) sl[u] = sn;
                 }
             }
+#endif
 #pragma unroll
             for (int u = 0; u < 4; ++u) if (i + 64u * u < b) { store(sl[u], ee[u]); hook(sl[u], (uint32_t)ee[u]); }
         }
