@@ -203,15 +203,6 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
         const bool aligned = (((uintptr_t)src) & 3u) == 0;
 #pragma unroll
         for (uint32_t c = 0; c < GCH; ++c) { const uint32_t j = tid + c * LZ2_THREADS; gp[c] = j < m ? (uint32_t)plist[j] : 0u; }
-        // order check 1 of 3 (lz_common.h lz_order_violation): a part's list must be in time order — the partition's stable
-        // pass.  The neighbour's position comes from the lane below (the first lane of a wave reads it from the list).
-#pragma unroll
-        for (uint32_t c = 0; c < GCH; ++c) {
-            const uint32_t j = tid + c * LZ2_THREADS;
-            uint32_t prev = __shfl_up(gp[c], 1);
-            if ((tid & 63) == 0 && j > 0 && j < m) prev = plist[j - 1];
-            if (j > 0 && j < m && prev >= gp[c]) viol = true;
-        }
 #pragma unroll
         for (uint32_t c = 0; c < GCH; ++c) {
             const uint32_t j = tid + c * LZ2_THREADS, p = gp[c];
@@ -252,6 +243,9 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     if (tid == 0) { s_zslot = ~0u; s_zgid = ~0u; s_nbigl = 0; }
     __syncthreads();
     auto homep = [&](uint32_t j) -> uint32_t { return ((s_word[j] & Tmask) - base) & Tmask; };
+    // order check 1 of 3 (lz_common.h lz_order_violation): a part's list must be in time order — the partition's stable pass.
+    // (Through LDS: taking the neighbour's position from the lane below and the list cost the gather twice as much.)
+    for (uint32_t j = tid + 1; j < m; j += LZ2_THREADS) viol |= s_pos[j - 1] >= s_pos[j];
     LZ2_TICK(0);
 
     // ---- sort time indices by home', stable

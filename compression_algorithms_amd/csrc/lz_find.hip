@@ -27,6 +27,7 @@
 // (rocprofv3, round 1: 1024-workgroup empty launches spent 4.8 ms each queueing).  So the bodies loop over the listed
 // blocks and the fallback launches use a small grid (LZ_FB_GRID workgroups).
 #define LZ_FB_GRID 128u
+#define DOM_DONE 0x80000000u                          // giant_list entry handled by k_lz_emulate_dom: k_lz_emulate_giant skips it
 __device__ __forceinline__ void lz_sort_home_block(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, LzScratch sc, uint64_t block0,
                                                    uint32_t lb)
 {
@@ -401,6 +402,7 @@ void k_lz_emulate_giant(LzP P, LzScratch sc)
     const uint32_t count = *sc.giant_count;
     for (uint32_t g = blockIdx.x; g < count; g += gridDim.x) {
         const uint32_t lb = sc.giant_list[2 * g], a = sc.giant_list[2 * g + 1];
+        if (a & DOM_DONE) continue;                      // k_lz_emulate_dom has replayed it
         const LzBlockMeta mt = sc.meta[lb];
         const uint32_t n = mt.n;
         const uint64_t *E = sc.eA + (size_t)lb * LZ_MAX_BLOCK;
@@ -486,6 +488,168 @@ void k_lz_emulate_giant(LzP P, LzScratch sc)
             for (uint32_t i = tid; i < m; i += 256) { const uint32_t c = gc[i]; if (c != LZ_NONE16) cand[gp[i]] = (uint16_t)c; }
         }
         __syncthreads();
+    }
+}
+
+// =============================================================================================
+// k_lz_emulate_dom — giant clusters that ONE word dominates (the "pages" cliff)
+// =============================================================================================
+// A block of binary data — zero pages, padding, a repeated record — puts 13 000 .. 60 000 copies of one 4-byte word X
+// into one cluster, with a few hundred entries of other words whose homes fall inside X's run of buckets (measured on
+// the "pages" family: 97.5 % of the largest cluster are X).  The general wave replay (lz_replay.h) needs per slot the
+// occupant's word id and position and per entry its slot: 6 bytes x the cluster, LDS for 18 432 entries, HBM round
+// trips on the serial chain beyond that (huge_replay: ~3 us per entry, 0.14 GB/s on the family).
+//
+// With a dominant word nearly all of that state is redundant.  find(X) only ever looks at X's home slot rX, whose
+// occupant — while it is a copy of X — is "the anchor": one register.  A slot that holds some other copy of X needs no
+// record at all: a foreign word's find() walks past it (different word), and nobody asks for its position.  What is
+// left:  one occupancy BIT per slot (8 KiB),  the slot of every LIVE entry for its retirement (a ring of W u16: entries
+// are retired in insertion order, at most W are alive),  and {word id, position, slot} of the live FOREIGN entries (a
+// FIFO of a few hundred).  78 KiB for any cluster size: two workgroups per CU, nothing on the serial chain but LDS.
+//   find(Y), Y foreign, home r: nothing if slot r is free; else the occupied run [r, e) ends at the first free slot e
+//            (one wave-wide bitmap scan) and the answer is the live copy of Y with the smallest slot inside it (one
+//            wave-wide pass over the foreign FIFO).
+//   insert: first free slot from the home (the same scan; for X it starts at a hint: every slot between rX and the
+//            hint word is known to be full, retirements pull the hint back).
+// Two things this representation cannot express end the attempt: a foreign entry landing ON rX (find(X) would have to
+// walk to the next copy of X and return its position), and more live foreign entries than the FIFO holds.  The cluster is
+// then left — its partial results wiped — to k_lz_emulate_giant, as is every cluster that is not dominated or that covers
+// bucket 0 / T (spurious clear, non-wrapping find).  Exactness: tests/test_fuzz_gpu.py ("pages", "runs" at every position
+// against the oracle's literal table), tests/test_lz_find_gpu.py::test_dominated_giant_clusters.
+#define DOM_FCAP 768u
+#define DOM_RING 32768u
+
+__device__ __forceinline__ uint32_t dom_first_zero(const uint32_t *occ, uint32_t from, uint32_t lane)
+{
+    const uint32_t w0 = from >> 5;
+    for (uint32_t base = w0;; base += 64u) {                                   // (the array ends in 64 zero words)
+        const uint32_t wi = base + lane;
+        uint32_t v = occ[wi];
+        if (wi == w0) v |= (1u << (from & 31u)) - 1u;
+        const uint64_t nz = __ballot(v != 0xFFFFFFFFu);
+        if (nz) {
+            const uint32_t ln = (uint32_t)__builtin_ctzll(nz);
+            return ((base + ln) << 5) + (uint32_t)__builtin_ctz(~RLANE(v, ln));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256)
+void k_lz_emulate_dom(LzP P, LzScratch sc)
+{
+    __shared__ uint32_t s_occ[LZ_MAX_BLOCK / 32 + 72];
+    __shared__ uint16_t s_ring[DOM_RING];
+    __shared__ uint16_t s_fid[DOM_FCAP], s_fpos[DOM_FCAP], s_fslot[DOM_FCAP];
+    __shared__ uint32_t s_end, s_votes[3], s_result;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t W = 1u << P.wbits;
+    if (W > DOM_RING) return;
+    const uint32_t count = *sc.giant_count;
+    for (uint32_t g = blockIdx.x; g < count; g += gridDim.x) {
+        const uint32_t lb = sc.giant_list[2 * g], a = sc.giant_list[2 * g + 1];
+        const LzBlockMeta mt = sc.meta[lb];
+        const uint32_t n = mt.n;
+        const uint64_t *E = sc.eA + (size_t)lb * LZ_MAX_BLOCK;
+        if (a == 0 && (mt.anom_idx != ~0u || mt.limit_idx != ~0u)) continue;      // the cluster that covers bucket 0 / T
+        const uint32_t gid = (uint32_t)E[a] & 0xFFFFu;
+        __syncthreads();
+        if (tid == 0) { s_end = n; s_votes[0] = s_votes[1] = s_votes[2] = 0; s_result = 0; }
+        __syncthreads();
+        for (uint32_t i = a + 1 + tid; i < n; i += 256) if (((uint32_t)E[i] & 0xFFFFu) != gid) { atomicMin(&s_end, i); break; }
+        __syncthreads();
+        const uint32_t m = s_end - a;
+        // the dominant word: three entries vote (one of them may be foreign), every entry is counted against them
+        const uint32_t cidx[3] = {m / 2, m / 4, (3 * m) / 4};
+        const uint32_t cpid[3] = {(uint32_t)(E[a + cidx[0]] >> 48), (uint32_t)(E[a + cidx[1]] >> 48), (uint32_t)(E[a + cidx[2]] >> 48)};
+        {
+            uint32_t v0 = 0, v1 = 0, v2 = 0;
+            for (uint32_t i = tid; i < m; i += 256) { const uint32_t q = (uint32_t)(E[a + i] >> 48); v0 += q == cpid[0]; v1 += q == cpid[1]; v2 += q == cpid[2]; }
+            if (v0) atomicAdd(&s_votes[0], v0);
+            if (v1) atomicAdd(&s_votes[1], v1);
+            if (v2) atomicAdd(&s_votes[2], v2);
+        }
+        for (uint32_t i = tid; i < (m + 31u) / 32u + 70u; i += 256) s_occ[i] = 0;
+        __syncthreads();
+        const uint32_t best = s_votes[0] >= s_votes[1] ? (s_votes[0] >= s_votes[2] ? 0u : 2u) : (s_votes[1] >= s_votes[2] ? 1u : 2u);
+        if ((uint64_t)s_votes[best] * 4u < (uint64_t)m * 3u) continue;              // not dominated: the general replay
+        const uint32_t X = cpid[best];
+        const uint32_t rX = ((uint32_t)(E[a + cidx[best]] >> 32) & 0xFFFFu) - a;
+        uint16_t *cand = sc.cand + (size_t)lb * LZ_MAX_BLOCK;
+        uint32_t done_upto = m;                                                     // entries whose results were written
+        if (tid < 64) {
+            uint32_t ev = 0, f_ev = 0, f_n = 0, anchor_pos = 0, hintw = rX >> 5;
+            bool anchor_ok = false, bailed = false;
+            uint64_t ne = lane < m ? E[a + lane] : 0ull;
+            uint32_t e_pos = (uint32_t)(ne >> 16) & 0xFFFFu, e_pid = (uint32_t)(ne >> 48);   // the retirement stream: entries [ev & ~63, +64)
+            uint32_t pe = RLANE(e_pos, 0);
+            for (uint32_t i0 = 0; i0 < m && !bailed; i0 += 64) {
+                const uint64_t ce = ne;
+                if (i0 + 64u + lane < m) ne = E[a + i0 + 64u + lane];
+                const uint32_t c_pos = (uint32_t)(ce >> 16) & 0xFFFFu, c_r = ((uint32_t)(ce >> 32) & 0xFFFFu) - a, c_pid = (uint32_t)(ce >> 48);
+                const uint32_t lim = (m - i0) < 64u ? (m - i0) : 64u;
+                uint32_t out_acc = LZ_NONE16;
+                for (uint32_t t = 0; t < lim; ++t) {
+                    const uint32_t i = i0 + t;
+                    const uint32_t p = RLANE(c_pos, t), r = RLANE(c_r, t), id = RLANE(c_pid, t);
+                    while (ev < i && pe + W < p) {                                  // FIFO retirement (lz77.c:70-76): clears the bucket
+                        const uint32_t sl = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ring[ev & (W - 1u)]);
+                        s_occ[sl >> 5] &= ~(1u << (sl & 31u));                      // (every lane, the same word and value)
+                        if (RLANE(e_pid, ev & 63u) != X) ++f_ev;                    // foreign entries leave their FIFO in order
+                        else if (sl == rX) anchor_ok = false;
+                        if (sl >= rX && (sl >> 5) < hintw) hintw = sl >> 5;
+                        ++ev;
+                        if ((ev & 63u) == 0) { const uint32_t q = ev + lane; const uint64_t x = q < m ? E[a + q] : 0ull; e_pos = (uint32_t)(x >> 16) & 0xFFFFu; e_pid = (uint32_t)(x >> 48); }
+                        pe = RLANE(e_pos, ev & 63u);
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    uint32_t res = LZ_NONE16;
+                    if (ev == 0) {
+                        if (id != p) res = id;                                      // nothing retired yet: the first occurrence
+                    } else if (id != p) {                                           // (a word's first occurrence finds nothing, ever)
+                        if (id == X) { if (anchor_ok) res = anchor_pos; }           // rX holds a copy of X, or nothing
+                        else if ((s_occ[r >> 5] >> (r & 31u)) & 1u) {
+                            const uint32_t e = dom_first_zero(s_occ, r, lane);
+                            uint32_t key = ~0u;
+                            for (uint32_t k0 = f_ev; k0 < f_n; k0 += 64u) {
+                                const uint32_t k = k0 + lane;
+                                if (k < f_n) {
+                                    const uint32_t x = k % DOM_FCAP;
+                                    const uint32_t fs = s_fslot[x];
+                                    if (s_fid[x] == id && fs >= r && fs < e) { const uint32_t c = (fs << 16) | s_fpos[x]; key = c < key ? c : key; }
+                                }
+                            }
+#pragma unroll
+                            for (int o = 32; o >= 1; o >>= 1) { const uint32_t c = __shfl_xor(key, o); key = c < key ? c : key; }
+                            if (key != ~0u) res = key & 0xFFFFu;
+                        }
+                    }
+                    // insert: first fit from the home (for X from the hint: everything between rX and it is full)
+                    const bool isx = id == X;
+                    const uint32_t from = isx ? ((hintw > (rX >> 5)) ? (hintw << 5) : rX) : r;
+                    const uint32_t b = dom_first_zero(s_occ, from, lane);
+                    s_occ[b >> 5] |= 1u << (b & 31u);
+                    s_ring[i & (W - 1u)] = (uint16_t)b;
+                    if (isx) { hintw = b >> 5; if (b == rX) { anchor_ok = true; anchor_pos = p; } }
+                    else {
+                        if (b == rX || f_n - f_ev >= DOM_FCAP) { bailed = true; done_upto = i0; break; }
+                        const uint32_t x = f_n % DOM_FCAP;
+                        s_fid[x] = (uint16_t)id; s_fpos[x] = (uint16_t)p; s_fslot[x] = (uint16_t)b;
+                        ++f_n;
+                    }
+                    if (lane == t) out_acc = res;
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (!bailed && i0 + lane < m && out_acc != LZ_NONE16) cand[c_pos] = (uint16_t)out_acc;
+            }
+            if (lane == 0) s_result = bailed ? (1u | (done_upto << 1)) : 0u;
+        }
+        __syncthreads();
+        const uint32_t rs_ = s_result;
+        if (rs_ & 1u) {
+            // given up: wipe what was written (k_lz_emulate_giant only writes the positions that find something)
+            const uint32_t upto = rs_ >> 1;
+            for (uint32_t i = tid; i < upto; i += 256) cand[(uint32_t)(E[a + i] >> 16) & 0xFFFFu] = (uint16_t)LZ_NONE16;
+        } else if (tid == 0) sc.giant_list[2 * g + 1] = a | DOM_DONE;
     }
 }
 
@@ -602,6 +766,12 @@ mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t
         mi_prof_scope p(ctx, "k_lz_emulate", s, (uint64_t)nb * P.block);
         const uint32_t tiles = (P.block + LZ_TILE_NOM - 1) / LZ_TILE_NOM;
         hipLaunchKernelGGL(k_lz_emulate, dim3(tiles, fgrid), dim3(512), 0, s, P, sc, nb, blist, bcount);
+    }
+    {
+        // dominated giant clusters first (78 KiB of LDS: two workgroups per CU); what it leaves goes to the general kernel
+        mi_prof_scope p(ctx, "k_lz_emulate_dom", s, (uint64_t)nb * P.block);
+        const uint32_t grid = blist ? 2u * LZ_FB_GRID : (nb < 512 ? nb : 512);
+        hipLaunchKernelGGL(k_lz_emulate_dom, dim3(grid), dim3(256), 0, s, P, sc);
     }
     {
         mi_prof_scope p(ctx, "k_lz_emulate_giant", s, (uint64_t)nb * P.block);

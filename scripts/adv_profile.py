@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Kernel times of the headline workload on a non-text input family (bench.py `adversarial`): where a cliff comes from.
+    python scripts/adv_profile.py pages|runs|lowent|phrases|zeros [workload] [bytes]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import bench
+from compression_algorithms_amd import synth
+from compression_algorithms_amd.context import Context
+
+kind = sys.argv[1] if len(sys.argv) > 1 else "pages"
+wl = sys.argv[2] if len(sys.argv) > 2 else "deflate-h"
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 100_000_000
+ctx = Context(0)
+a = np.zeros(1 << 24, np.uint8) if kind == "zeros" else synth.family(kind, 4242, 1 << 24)
+x = torch.from_numpy(a).cuda().repeat((n + len(a) - 1) // len(a))[:n].contiguous()
+r = bench.measure(ctx, wl, x, 2, 1, None, False)
+print(kind, wl, r["value"], "GB/s", r["ms_per_step"], "ms  ratio", r["ratio"], "rt", r["roundtrip"])
+for k, v in sorted(r["roofline"]["all_kernels_ms_per_step"].items(), key=lambda kv: -kv[1]):
+    print(f"   {k:28s} {v:10.3f} ms")
+if os.environ.get("MI_LZ_DEBUG"):
+    import ctypes as C
+    out = (C.c_uint64 * 64)()
+    ctx.L.mi_lz_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
+    ctx.L.mi_lz_debug_counters(ctx.h, out)
+    print("dbg", list(out)[:48])

@@ -78,6 +78,37 @@ def test_zero_run_inside_random(flavour, wbits, run):
     _check(data, flavour, wbits)
 
 
+@pytest.mark.parametrize("flavour,wbits", [("deflate", None), ("lz77", 14)])
+@pytest.mark.parametrize("shape", ["pages", "sparse_foreign", "several_runs", "crowded", "half"])
+def test_dominated_giant_clusters(flavour, wbits, shape):
+    """giant clusters that one word dominates take k_lz_emulate_dom (occupancy bits + the slots of live entries + a FIFO of
+    live foreign entries, lz_find.hip); "crowded" has more live foreign entries than that FIFO holds and "half" is not
+    dominated: both must fall through to the general replay.  find() at every position against the oracle's literal table."""
+    rng = np.random.default_rng(len(shape) * 7 + (wbits or 15))
+    n = 2 * 65536 + 12345
+    if shape == "pages":
+        data = synth.family("pages", 99, n)
+    elif shape == "sparse_foreign":                 # zeros with a few hundred stray bytes: every one makes <= 4 foreign words
+        data = np.zeros(n, np.uint8)
+        at = rng.integers(0, n, 300)
+        data[at] = rng.integers(1, 256, 300, dtype=np.uint8)
+    elif shape == "several_runs":                   # runs of different byte values, 6 000 .. 30 000 long, separated by text
+        data = synth.enwik_like(n, seed=77).numpy().copy()
+        at = 1000
+        for ln in (6000, 30000, 9000, 14000, 22000):
+            data[at:at + ln] = int(rng.integers(0, 256))
+            at += ln + int(rng.integers(500, 4000))
+    elif shape == "crowded":                        # 85 % zeros, 15 % random bytes in short bursts: thousands of live foreign entries
+        data = np.zeros(n, np.uint8)
+        for at in rng.integers(0, n - 8, n // 40):
+            data[at:at + 6] = rng.integers(1, 256, 6, dtype=np.uint8)
+    else:                                           # half zeros, half random: a giant cluster nobody dominates
+        data = rng.integers(0, 256, n, dtype=np.uint8)
+        data[::2] = 0
+        data[20000:52000] = 0
+    _check(data, flavour, wbits)
+
+
 @pytest.mark.parametrize("flavour,wbits", CONFIGS)
 def test_pure_runs_closed_form(flavour, wbits):
     """blocks that are one byte value throughout (closed form: anchors) next to a block that is not"""
