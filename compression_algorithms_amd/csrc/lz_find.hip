@@ -519,7 +519,7 @@ void k_lz_emulate_giant(LzP P, LzScratch sc)
 #define DOM_FCAP 768u
 #define DOM_RING 32768u
 
-__device__ __forceinline__ uint32_t dom_first_zero(const uint32_t *occ, uint32_t from, uint32_t lane)
+__device__ __forceinline__ uint32_t dom_first_zero(const volatile uint32_t *occ, uint32_t from, uint32_t lane)
 {
     const uint32_t w0 = from >> 5;
     for (uint32_t base = w0;; base += 64u) {                                   // (the array ends in 64 zero words)
@@ -535,7 +535,7 @@ __device__ __forceinline__ uint32_t dom_first_zero(const uint32_t *occ, uint32_t
 }
 
 __global__ __launch_bounds__(256)
-void k_lz_emulate_dom(LzP P, LzScratch sc)
+void k_lz_emulate_dom(LzP P, LzScratch sc, uint64_t *dbg)
 {
     __shared__ uint32_t s_occ[LZ_MAX_BLOCK / 32 + 72];
     __shared__ uint16_t s_ring[DOM_RING];
@@ -545,7 +545,16 @@ void k_lz_emulate_dom(LzP P, LzScratch sc)
     const uint32_t W = 1u << P.wbits;
     if (W > DOM_RING) return;
     const uint32_t count = *sc.giant_count;
-    for (uint32_t g = blockIdx.x; g < count; g += gridDim.x) {
+    const long long tk_wg = dbg ? clock64() : 0;
+    // clusters are handed out by a cursor (they differ in size by a factor of 70: a static stride left the longest workgroup
+    // 3.4 x the average); every workgroup reaches the exit: the cursor only grows
+    __shared__ uint32_t s_next;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_next = atomicAdd(&sc.giant_count[1], 1u);
+        __syncthreads();
+        const uint32_t g = s_next;
+        if (g >= count) break;
         const uint32_t lb = sc.giant_list[2 * g], a = sc.giant_list[2 * g + 1];
         const LzBlockMeta mt = sc.meta[lb];
         const uint32_t n = mt.n;
@@ -558,6 +567,8 @@ void k_lz_emulate_dom(LzP P, LzScratch sc)
         for (uint32_t i = a + 1 + tid; i < n; i += 256) if (((uint32_t)E[i] & 0xFFFFu) != gid) { atomicMin(&s_end, i); break; }
         __syncthreads();
         const uint32_t m = s_end - a;
+        long long tk0 = dbg ? clock64() : 0;
+        if (dbg && tid == 0) { atomicAdd((unsigned long long *)&dbg[48], 1ull); atomicAdd((unsigned long long *)&dbg[49], (unsigned long long)m); }
         // the dominant word: three entries vote (one of them may be foreign), every entry is counted against them
         const uint32_t cidx[3] = {m / 2, m / 4, (3 * m) / 4};
         const uint32_t cpid[3] = {(uint32_t)(E[a + cidx[0]] >> 48), (uint32_t)(E[a + cidx[1]] >> 48), (uint32_t)(E[a + cidx[2]] >> 48)};
@@ -571,14 +582,47 @@ void k_lz_emulate_dom(LzP P, LzScratch sc)
         for (uint32_t i = tid; i < (m + 31u) / 32u + 70u; i += 256) s_occ[i] = 0;
         __syncthreads();
         const uint32_t best = s_votes[0] >= s_votes[1] ? (s_votes[0] >= s_votes[2] ? 0u : 2u) : (s_votes[1] >= s_votes[2] ? 1u : 2u);
-        if ((uint64_t)s_votes[best] * 4u < (uint64_t)m * 3u) continue;              // not dominated: the general replay
+        if ((uint64_t)s_votes[best] * 5u < (uint64_t)m * 3u) continue;              // below 60 %: the general replay
+        if (s_votes[best] == m) continue;                                          // one word only: the closed form of k_lz_emulate_giant
         const uint32_t X = cpid[best];
         const uint32_t rX = ((uint32_t)(E[a + cidx[best]] >> 32) & 0xFFFFu) - a;
         uint16_t *cand = sc.cand + (size_t)lb * LZ_MAX_BLOCK;
         uint32_t done_upto = m;                                                     // entries whose results were written
+        if (dbg && tid == 0) { atomicAdd((unsigned long long *)&dbg[50], 1ull); atomicAdd((unsigned long long *)&dbg[51], (unsigned long long)m); atomicAdd((unsigned long long *)&dbg[52], (unsigned long long)(clock64() - tk0)); tk0 = clock64(); }
+        uint32_t n_fast = 0, n_scan = 0, n_fgn = 0;
         if (tid < 64) {
-            uint32_t ev = 0, f_ev = 0, f_n = 0, anchor_pos = 0, hintw = rX >> 5;
+            uint32_t ev = 0, f_ev = 0, f_n = 0, anchor_pos = 0, stash = 0, stash_of = ~0u;
             bool anchor_ok = false, bailed = false;
+            // X always takes the FIRST FREE SLOT at or above rX: that slot is tracked (`nx`, exact) together with a bound `lf`
+            // up to which everything above it is known to be free, so that a copy of X is placed without looking at the
+            // bitmap: b = nx++.  Only when the free run is used up is the bitmap scanned (next free slot, then the next taken
+            // one).  A retirement below nx opens a one-slot run in front of the current one, which is kept aside (`sv_*`) and
+            // comes back when that slot has been re-taken — the steady state of a long run (retire one copy, insert one)
+            // never scans.  `sv_dirty`: something else was freed in between; then the scan decides.
+            constexpr uint32_t BIG = 0x7FFFFFFFu;
+            const uint32_t nw_all = (m + 31u) / 32u + 64u;
+            uint32_t nx = rX, lf = BIG, sv_nx = 0, sv_lf = 0;
+            bool sv = false, sv_dirty = false;
+            // bitmap updates are single LDS atomics issued by one lane (no read on the chain; LDS executes a wave's
+            // instructions in order, so the scans that follow see them)
+            auto bit_clear = [&](uint32_t sl) { if (lane == 0) atomicAnd(&s_occ[sl >> 5], ~(1u << (sl & 31u))); };
+            auto bit_set = [&](uint32_t sl) { if (lane == 0) atomicOr(&s_occ[sl >> 5], 1u << (sl & 31u)); };
+            auto first_one = [&](uint32_t from) -> uint32_t {
+                const volatile uint32_t *occ = s_occ;
+                const uint32_t w0 = from >> 5;
+                for (uint32_t base = w0; base < nw_all; base += 64u) {
+                    const uint32_t wi = base + lane;
+                    uint32_t v = wi < nw_all ? occ[wi] : 0u;
+                    if (wi == w0) v &= ~((1u << (from & 31u)) - 1u);
+                    const uint64_t nz = __ballot(v != 0u);
+                    if (nz) { const uint32_t ln = (uint32_t)__builtin_ctzll(nz); return ((base + ln) << 5) + (uint32_t)__builtin_ctz(RLANE(v, ln)); }
+                }
+                return BIG;
+            };
+            auto refill = [&]() {                                                     // the free run [nx, lf) is used up
+                if (sv && !sv_dirty) { nx = sv_nx; lf = sv_lf; sv = false; }
+                else { sv = false; nx = dom_first_zero(s_occ, nx, lane); lf = first_one(nx + 1u); ++n_scan; }
+            };
             uint64_t ne = lane < m ? E[a + lane] : 0ull;
             uint32_t e_pos = (uint32_t)(ne >> 16) & 0xFFFFu, e_pid = (uint32_t)(ne >> 48);   // the retirement stream: entries [ev & ~63, +64)
             uint32_t pe = RLANE(e_pos, 0);
@@ -588,34 +632,64 @@ void k_lz_emulate_dom(LzP P, LzScratch sc)
                 const uint32_t c_pos = (uint32_t)(ce >> 16) & 0xFFFFu, c_r = ((uint32_t)(ce >> 32) & 0xFFFFu) - a, c_pid = (uint32_t)(ce >> 48);
                 const uint32_t lim = (m - i0) < 64u ? (m - i0) : 64u;
                 uint32_t out_acc = LZ_NONE16;
+                // 64 copies of X in a row, nothing to retire before the last of them, 64 free slots in a row: they take them in
+                // order and all find the same thing — one wave-wide step instead of 64 serial ones (every run in the first W
+                // positions of a block, where nothing retires at all)
+                if (lim == 64u && nx + 64u <= lf && __ballot(c_pid == X) == ~0ull && !(ev < i0 && pe + W < RLANE(c_pos, 63))
+                    && i0 + 64u - ev <= W) {
+                    const uint32_t b = nx + lane;
+                    uint32_t res = LZ_NONE16;
+                    if (c_pid != c_pos) { if (ev == 0) res = c_pid; else if (anchor_ok) res = anchor_pos; }
+                    if (nx == rX) {                                                 // the first of them takes X's home
+                        if (ev != 0 && !anchor_ok && lane > 0 && c_pid != c_pos) res = RLANE(c_pos, 0);
+                        anchor_ok = true; anchor_pos = RLANE(c_pos, 0);
+                    }
+                    atomicOr(&s_occ[b >> 5], 1u << (b & 31u));
+                    ((volatile uint16_t *)s_ring)[(i0 + lane) & (W - 1u)] = (uint16_t)b;
+                    nx += 64u;
+                    if (nx >= lf) refill();
+                    n_fast += 64u;
+                    if (res != LZ_NONE16) cand[c_pos] = (uint16_t)res;
+                    __builtin_amdgcn_wave_barrier();
+                    continue;
+                }
                 for (uint32_t t = 0; t < lim; ++t) {
                     const uint32_t i = i0 + t;
                     const uint32_t p = RLANE(c_pos, t), r = RLANE(c_r, t), id = RLANE(c_pid, t);
                     while (ev < i && pe + W < p) {                                  // FIFO retirement (lz77.c:70-76): clears the bucket
-                        const uint32_t sl = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ring[ev & (W - 1u)]);
-                        s_occ[sl >> 5] &= ~(1u << (sl & 31u));                      // (every lane, the same word and value)
+                        const uint32_t sl = ev == stash_of ? stash : (uint32_t)__builtin_amdgcn_readfirstlane((int)((const volatile uint16_t *)s_ring)[ev & (W - 1u)]);
+                        bit_clear(sl);
                         if (RLANE(e_pid, ev & 63u) != X) ++f_ev;                    // foreign entries leave their FIFO in order
                         else if (sl == rX) anchor_ok = false;
-                        if (sl >= rX && (sl >> 5) < hintw) hintw = sl >> 5;
+                        if (sl >= rX) {
+                            if (sl < nx) {
+                                if (sl + 1u == nx) nx = sl;                         // the free run grows downwards
+                                else {
+                                    if (!sv) { sv = true; sv_nx = nx; sv_lf = lf; sv_dirty = false; } else sv_dirty = true;
+                                    nx = sl; lf = sl + 1u;
+                                }
+                            } else if (sv && sl < sv_nx) sv_dirty = true;
+                        }
                         ++ev;
                         if ((ev & 63u) == 0) { const uint32_t q = ev + lane; const uint64_t x = q < m ? E[a + q] : 0ull; e_pos = (uint32_t)(x >> 16) & 0xFFFFu; e_pid = (uint32_t)(x >> 48); }
                         pe = RLANE(e_pos, ev & 63u);
                         __builtin_amdgcn_wave_barrier();
                     }
+                    const bool isx = id == X;
                     uint32_t res = LZ_NONE16;
                     if (ev == 0) {
                         if (id != p) res = id;                                      // nothing retired yet: the first occurrence
                     } else if (id != p) {                                           // (a word's first occurrence finds nothing, ever)
-                        if (id == X) { if (anchor_ok) res = anchor_pos; }           // rX holds a copy of X, or nothing
-                        else if ((s_occ[r >> 5] >> (r & 31u)) & 1u) {
+                        if (isx) { if (anchor_ok) res = anchor_pos; }               // rX holds a copy of X, or nothing
+                        else if ((((const volatile uint32_t *)s_occ)[r >> 5] >> (r & 31u)) & 1u) {
                             const uint32_t e = dom_first_zero(s_occ, r, lane);
                             uint32_t key = ~0u;
                             for (uint32_t k0 = f_ev; k0 < f_n; k0 += 64u) {
                                 const uint32_t k = k0 + lane;
                                 if (k < f_n) {
                                     const uint32_t x = k % DOM_FCAP;
-                                    const uint32_t fs = s_fslot[x];
-                                    if (s_fid[x] == id && fs >= r && fs < e) { const uint32_t c = (fs << 16) | s_fpos[x]; key = c < key ? c : key; }
+                                    const uint32_t fs = ((const volatile uint16_t *)s_fslot)[x];
+                                    if (((const volatile uint16_t *)s_fid)[x] == id && fs >= r && fs < e) { const uint32_t c = (fs << 16) | ((const volatile uint16_t *)s_fpos)[x]; key = c < key ? c : key; }
                                 }
                             }
 #pragma unroll
@@ -623,25 +697,42 @@ void k_lz_emulate_dom(LzP P, LzScratch sc)
                             if (key != ~0u) res = key & 0xFFFFu;
                         }
                     }
-                    // insert: first fit from the home (for X from the hint: everything between rX and it is full)
-                    const bool isx = id == X;
-                    const uint32_t from = isx ? ((hintw > (rX >> 5)) ? (hintw << 5) : rX) : r;
-                    const uint32_t b = dom_first_zero(s_occ, from, lane);
-                    s_occ[b >> 5] |= 1u << (b & 31u);
-                    s_ring[i & (W - 1u)] = (uint16_t)b;
-                    if (isx) { hintw = b >> 5; if (b == rX) { anchor_ok = true; anchor_pos = p; } }
-                    else {
+                    // insert: first fit from the home
+                    uint32_t b;
+                    if (isx) {
+                        b = nx; bit_set(b); ++nx; ++n_fast;
+                        if (nx >= lf) refill();
+                        if (b == rX) { anchor_ok = true; anchor_pos = p; }
+                    } else {
+                        b = dom_first_zero(s_occ, r, lane);
+                        bit_set(b);
                         if (b == rX || f_n - f_ev >= DOM_FCAP) { bailed = true; done_upto = i0; break; }
+                        if (b >= rX) {                                              // (then b >= nx: nx is the first free slot from rX)
+                            if (b == nx) { ++nx; if (nx >= lf) refill(); }
+                            else if (b < lf) lf = b;
+                            else if (sv) {
+                                if (b == sv_nx) { ++sv_nx; if (sv_nx >= sv_lf) sv_dirty = true; }
+                                else if (b > sv_nx && b < sv_lf) sv_lf = b;
+                            }
+                        }
                         const uint32_t x = f_n % DOM_FCAP;
-                        s_fid[x] = (uint16_t)id; s_fpos[x] = (uint16_t)p; s_fslot[x] = (uint16_t)b;
-                        ++f_n;
+                        if (lane == 0) { ((volatile uint16_t *)s_fid)[x] = (uint16_t)id; ((volatile uint16_t *)s_fpos)[x] = (uint16_t)p; ((volatile uint16_t *)s_fslot)[x] = (uint16_t)b; }
+                        ++f_n; ++n_fgn;
                     }
+                    // the ring holds W slots, but W + 1 entries are alive for a moment (insertion k retires k - W AFTER it
+                    // has written, lz77.c:70-76): when this entry takes the place of the oldest one, that one's slot moves
+                    // to a register (there can only be one such entry: positions are distinct)
+                    if (i - ev == W) { stash = (uint32_t)__builtin_amdgcn_readfirstlane((int)((const volatile uint16_t *)s_ring)[ev & (W - 1u)]); stash_of = ev; }
+                    if (lane == 0) ((volatile uint16_t *)s_ring)[i & (W - 1u)] = (uint16_t)b;
                     if (lane == t) out_acc = res;
                     __builtin_amdgcn_wave_barrier();
                 }
                 if (!bailed && i0 + lane < m && out_acc != LZ_NONE16) cand[c_pos] = (uint16_t)out_acc;
             }
             if (lane == 0) s_result = bailed ? (1u | (done_upto << 1)) : 0u;
+            if (dbg && lane == 0) { atomicAdd((unsigned long long *)&dbg[53], (unsigned long long)(clock64() - tk0)); atomicAdd((unsigned long long *)&dbg[54], (unsigned long long)n_fast);
+                                    atomicAdd((unsigned long long *)&dbg[55], (unsigned long long)n_scan); atomicAdd((unsigned long long *)&dbg[56], (unsigned long long)n_fgn);
+                                    if (bailed) atomicAdd((unsigned long long *)&dbg[57], 1ull); }
         }
         __syncthreads();
         const uint32_t rs_ = s_result;
@@ -650,7 +741,9 @@ void k_lz_emulate_dom(LzP P, LzScratch sc)
             const uint32_t upto = rs_ >> 1;
             for (uint32_t i = tid; i < upto; i += 256) cand[(uint32_t)(E[a + i] >> 16) & 0xFFFFu] = (uint16_t)LZ_NONE16;
         } else if (tid == 0) sc.giant_list[2 * g + 1] = a | DOM_DONE;
+        if (dbg && tid == 0) atomicMax((unsigned long long *)&dbg[58], (unsigned long long)m);
     }
+    if (dbg && tid == 0) { atomicMax((unsigned long long *)&dbg[59], (unsigned long long)(clock64() - tk_wg)); atomicMax((unsigned long long *)&dbg[60], (unsigned long long)count); }
 }
 
 // =============================================================================================
@@ -751,8 +844,9 @@ mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t
     // as the fallback of the LDS-resident finder these launches are normally empty and merely wait for LDS behind
     // k_lz2_find: timing them would report that wait as kernel time
     const int saved_prof = ctx->profiling;
-    if (blist) ctx->profiling = 0;
-    MI_HIP(ctx, hipMemsetAsync(sc.giant_count, 0, 4, s));
+    static const bool prof_fb = getenv("MI_LZ_PROF_FALLBACK") != nullptr;      // inputs that live in the fallback (scripts/adv_profile.py)
+    if (blist && !prof_fb) ctx->profiling = 0;
+    MI_HIP(ctx, hipMemsetAsync(sc.giant_count, 0, 8, s));        // [0] clusters listed, [1] cursor of k_lz_emulate_dom
     const uint32_t fgrid = (blist && nb > LZ_FB_GRID) ? LZ_FB_GRID : nb;     // fallback: few looping workgroups (see LZ_FB_GRID)
     {
         mi_prof_scope p(ctx, "k_lz_sort_home", s, (uint64_t)nb * P.block);
@@ -770,8 +864,8 @@ mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t
     {
         // dominated giant clusters first (78 KiB of LDS: two workgroups per CU); what it leaves goes to the general kernel
         mi_prof_scope p(ctx, "k_lz_emulate_dom", s, (uint64_t)nb * P.block);
-        const uint32_t grid = blist ? 2u * LZ_FB_GRID : (nb < 512 ? nb : 512);
-        hipLaunchKernelGGL(k_lz_emulate_dom, dim3(grid), dim3(256), 0, s, P, sc);
+        const uint32_t grid = nb < 512 ? nb : 512;          // two per CU; a workgroup that finds the list empty leaves at once
+        hipLaunchKernelGGL(k_lz_emulate_dom, dim3(grid), dim3(256), 0, s, P, sc, ctx->lz_dbg);
     }
     {
         mi_prof_scope p(ctx, "k_lz_emulate_giant", s, (uint64_t)nb * P.block);
