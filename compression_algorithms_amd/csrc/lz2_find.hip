@@ -130,6 +130,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     __shared__ uint16_t s_pid[LZ2_CAP + 2];             // word id by j (position of the first occurrence); then s_gstart; last cand by j
     __shared__ uint32_t s_cnt[LZ2_NWAVES + 1][256];   // radix counters, [digit][wave + pad] (lz_common.h)
     __shared__ uint32_t s_bm[LZ2_CAP / 32 + 2];
+    __shared__ uint32_t s_mix[LZ2_CAP / 32 + 2];        // bit g: cluster g holds more than one home or more than one word ("mixed")
     __shared__ int32_t  s_i32[18];
     __shared__ uint32_t s_zslot, s_zgid, s_nbigl, s_ngroups;
     // LDS diet: two of these workgroups share a CU, and whatever they leave (160 KiB - 2 x this kernel) is all that the
@@ -239,7 +240,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
             }
         }
     }
-    for (uint32_t i = tid; i < LZ2_CAP / 32 + 2; i += LZ2_THREADS) s_bm[i] = 0;
+    for (uint32_t i = tid; i < LZ2_CAP / 32 + 2; i += LZ2_THREADS) { s_bm[i] = 0; s_mix[i] = 0; }
     if (tid == 0) { s_zslot = ~0u; s_zgid = ~0u; s_nbigl = 0; }
     __syncthreads();
     auto homep = [&](uint32_t j) -> uint32_t { return ((s_word[j] & Tmask) - base) & Tmask; };
@@ -356,13 +357,17 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
                 else {                                      // two different words share a home bucket: rare
                     id = j;
                     for (uint32_t kk = cur_hs + 1; kk < k; ++kk) { const uint32_t j2 = s_j0[kk]; if (s_word[j2] == w) { id = j2; break; } }
+                    atomicOr(&s_mix[cur_gid >> 5], 1u << (cur_gid & 31u));
                 }
                 prev_h = h;
                 s_g[j] = (uint16_t)cur_gid;
                 s_r[j] = (uint16_t)(cur_gs + (uint32_t)(h - cur_base));
                 // a cluster whose entries do not all share one home needs its (home, time) order re-sorted by time below;
                 // the others (nearly all) are in time order as they stand.  s_bm is free until the replay.
-                if ((arank & LZP_ARANK) && h != cur_base) atomicOr(&s_bm[cur_gid >> 5], 1u << (cur_gid & 31u));
+                if (h != cur_base) {
+                    if (arank & LZP_ARANK) atomicOr(&s_bm[cur_gid >> 5], 1u << (cur_gid & 31u));
+                    atomicOr(&s_mix[cur_gid >> 5], 1u << (cur_gid & 31u));
+                }
                 // the word's identity is the POSITION of its first occurrence in the block (the home order is stable in
                 // time).  While nothing of a cluster has been evicted that position is also what find() returns: the first
                 // copy sits at the lowest slot of the word and every slot between the home and it stays occupied.
@@ -513,11 +518,13 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
             const uint32_t i = tid + c * (uint32_t)LZ2_THREADS;
             my_n[c] = 0; my_s[c] = i;
             if (i < m && (e_rs[i] & RS_HEAD)) {
-                const uint32_t e = s_gstart[(regs[c][2] >> 16) + 1];      // clusters are contiguous and in cluster-number order
+                const uint32_t g_ = regs[c][2] >> 16;
+                const uint32_t e = s_gstart[g_ + 1];                      // clusters are contiguous and in cluster-number order
                 const uint32_t size = e - i;
                 my_n[c] = size;
                 // a cluster whose entries all lie within one window never evicts: no replay, find() = first occurrence
                 if (size == 1) cand_i[i] = LZ_NONE16;
+                else if (!((s_mix[g_ >> 5] >> (g_ & 31u)) & 1u) && i != s_zhead) my_n[c] = 0;     // ONE word: the closed form below, no replay
                 else if (size < LZ2_BIG) atomicAdd(&s_bin[size], 1u);          // (replay_small notices a quiet cluster itself)
                 else if ((uint32_t)e_pos[e - 1] <= (uint32_t)e_pos[i] + W && i != s_zhead) { const uint32_t q = atomicAdd(&s_nquiet, 1u); s_quiet[2 * q] = (uint16_t)i; s_quiet[2 * q + 1] = (uint16_t)e; }
                 else {
@@ -574,6 +581,29 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
         if (sc.dbg && tid == 0) { atomicAdd((unsigned long long *)&sc.dbg[23], (unsigned long long)ncl); atomicAdd((unsigned long long *)&sc.dbg[24], (unsigned long long)nbig);
                                   atomicAdd((unsigned long long *)&sc.dbg[25], (unsigned long long)s_ent); atomicAdd((unsigned long long *)&sc.dbg[26], (unsigned long long)s_nquiet);
                                   atomicAdd((unsigned long long *)&sc.dbg[27], (unsigned long long)m); atomicAdd((unsigned long long *)&sc.dbg[28], (unsigned long long)s_ngroups); }
+        // ---- clusters of ONE word (one home, every entry the same word: most clusters of a text) have a closed form.  find()
+        //      for that word only ever looks at the home slot: it holds the "anchor", the copy that was inserted when the slot
+        //      was free — the first entry, then, once the anchor has been retired (lz77.c:70-76: its position + W < p), the
+        //      next entry, which itself finds the slot empty (nothing) and takes it.  a(0) = first entry, a(k+1) = first entry
+        //      after a(k) + W: at most block / W anchors, each a binary search in the cluster's time-ordered positions.  Every
+        //      entry on its own, no table, no order: neither the lane replay nor an export (k_lz_emulate_giant uses the same
+        //      form for giant clusters).  The cluster that covers bucket 0 / T keeps the general path.
+        for (uint32_t c = 0; c < CH; ++c) {
+            const uint32_t i = tid + c * (uint32_t)LZ2_THREADS;
+            if (i >= m) continue;
+            const uint32_t g_ = regs[c][2] >> 16;
+            if ((s_mix[g_ >> 5] >> (g_ & 31u)) & 1u) continue;
+            const uint32_t s = s_gstart[g_];
+            if (s == s_zhead || s_gstart[g_ + 1] - s < 2u) continue;
+            const uint32_t p = regs[c][0];
+            uint32_t a = e_pos[s], lo = s + 1u;
+            while (a + W < p) {                                           // (e_pos[i] = p is beyond a + W: the search ends at i at the latest)
+                uint32_t hi = i;
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)e_pos[mid] > a + W) hi = mid; else lo = mid + 1u; }
+                a = e_pos[lo]; ++lo;
+            }
+            cand_i[i] = (a == p) ? (uint16_t)LZ_NONE16 : (uint16_t)a;
+        }
         for (uint32_t q = tid; q < ncl; q += LZ2_THREADS) {
             const uint32_t s = c_start[q];
             uint32_t e = s + 1;

@@ -598,6 +598,12 @@ static mi_status lz_encode_impl(mi_ctx *ctx, const mi_lz_params *p, const uint8_
     // one workgroup and the partition is on the chain the pipeline waits for).  Measured: no difference (12.66 vs 12.65
     // GB/s, partition 22.2 vs 22.6 ms) — the pipeline is bound by the total work, not by one chain.  Left as a switch.
     const bool hold_parse = overlap && lz_use_v2() && getenv("MI_LZ_SCHED") != nullptr;
+#ifdef MI_MEASURE
+    // measurement builds only (make EXTRA=-DMI_MEASURE): what would the step cost if a stage were free?  The stream is WRONG.
+    const int skip = getenv("MI_LZ_SKIP") ? atoi(getenv("MI_LZ_SKIP")) : 0;       // 1: no stage B, 2: no stage C, 3: neither
+#else
+    const int skip = 0;
+#endif
     uint64_t batch = 0, prev_b0 = 0; uint32_t prev_nb = 0; int prev_k = -1;
     for (uint64_t b0 = 0; b0 < nblocks; b0 += nbmax, ++batch) {
         const uint32_t nb = (uint32_t)((nblocks - b0) < nbmax ? (nblocks - b0) : nbmax);
@@ -611,7 +617,7 @@ static mi_status lz_encode_impl(mi_ctx *ctx, const mi_lz_params *p, const uint8_
             if (st) return st;
         }
         if (overlap) { MI_HIP(ctx, hipEventRecord(ctx->ev_find[k], s)); MI_HIP(ctx, hipStreamWaitEvent(sb, ctx->ev_find[k], 0)); }
-        st = lz_find_stage_b(ctx, P, nb, sc2[k], sb);
+        if (!(skip & 1)) st = lz_find_stage_b(ctx, P, nb, sc2[k], sb);
         if (st) return st;
         if (overlap) {
             MI_HIP(ctx, hipEventRecord(ctx->ev_replay[k], sb));
@@ -619,7 +625,8 @@ static mi_status lz_encode_impl(mi_ctx *ctx, const mi_lz_params *p, const uint8_
             if (lz_use_v2()) MI_HIP(ctx, hipStreamWaitEvent(sp, ctx->ev_fb[k], 0));      // the fallback blocks' candidates
         }
         if (hold_parse) { prev_k = k; prev_b0 = b0; prev_nb = nb; }
-        else { st = stage_c(k, b0, nb); if (st) return st; }
+        else if (!(skip & 2)) { st = stage_c(k, b0, nb); if (st) return st; }
+        else if (overlap) MI_HIP(ctx, hipEventRecord(ctx->ev_done[k], sp));
     }
     if (hold_parse && prev_k >= 0) { st = stage_c(prev_k, prev_b0, prev_nb); if (st) return st; }
     if (overlap) {                                                 // join: the last stage finishes everything
