@@ -99,13 +99,47 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
         }
     };
     // token lengths of a list, eight pairs at a time: the first compare step (bytes 4..7 — where most matches of a text
-    // end) of all eight is issued together; a per-pair loop would walk its LDS round trips one pair after the other
+    // end) of all eight is issued together; a per-pair loop would walk its LDS round trips one pair after the other.
+    // Matches that go on past byte 7 are QUEUED and extended 64 at a time: the extension is a data-dependent loop, and run in
+    // place every wave paid its longest match (up to seven rounds) for each of its eight pair slots with a handful of lanes
+    // alive — the phase was VALU-bound on those rounds (~1000 instructions per thread and step, 4 waves per SIMD: half of
+    // this kernel).  The queue is one register per lane: a ballot ranks the lanes that have a pair to extend, ds_permute (the
+    // LDS crossbar, no LDS memory) sends pair number r to lane (fill + r) mod 64 — the other lanes send to the slots that are
+    // left, so the whole thing is a permutation — and whenever 64 pairs are together they are extended by a full wave.
+    uint32_t q_cur = 0, q_nxt = 0, q_fill = 0;                   // queued (position | candidate << 16) of this lane; pairs queued (uniform)
+    const uint32_t lane = (uint32_t)tid & 63u;
+    auto extend = [&](uint32_t item, bool on) {
+        if (on) {
+            const uint32_t p = item & 0xFFFFu, c = item >> 16;
+            uint32_t len = 8;
+            while (len < max_len) {
+                const uint32_t x = lds_word(s_r0, c + len) ^ lds_word(s_r0, p + len);
+                if (x) { len += (uint32_t)__builtin_ctz(x) >> 3; break; }
+                len += 4;
+            }
+            s_L[p] = (uint8_t)(len > max_len ? max_len : len);
+        }
+    };
+    auto enqueue = [&](bool ext, uint32_t item) {
+        const uint64_t mk = __ballot(ext);
+        if (mk == 0ull) return;                                    // (uniform)
+        const uint32_t cnt = (uint32_t)__popcll(mk);
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));   // queued lanes below this one
+        const uint32_t slot = ext ? below : cnt + (lane - below);  // a stable partition of the 64 lanes: a permutation
+        const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)(((slot + q_fill) & 63u) << 2), (int)item);
+        const uint32_t rel = (lane - q_fill) & 63u;                // lane q_fill + r received queued pair r
+        if (rel < cnt) { if (lane >= q_fill) q_cur = got; else q_nxt = got; }
+        q_fill += cnt;
+        if (q_fill >= 64u) { extend(q_cur, true); q_cur = q_nxt; q_fill -= 64u; }
+    };
     auto lengths_of_list = [&](const uint16_t *lp, const uint16_t *lc, uint32_t cnt) {
         uint4 np = make_uint4(0, 0, 0, 0), nc = make_uint4(0, 0, 0, 0);
         uint32_t j0 = tid * 8u;
         if (j0 + 8u <= cnt) { np = *reinterpret_cast<const uint4 *>(lp + j0); nc = *reinterpret_cast<const uint4 *>(lc + j0); }
-        for (; j0 < cnt; j0 += 1024u * 8u) {
-            if (j0 + 8u <= cnt) {
+        // (the trip count is the same for every lane of a wave — the queue's ballots need the whole wave: 512 pairs per wave and step)
+        for (uint32_t w0 = ((uint32_t)tid & ~63u) * 8u; w0 < cnt; w0 += 1024u * 8u, j0 += 1024u * 8u) {
+            const bool full = j0 + 8u <= cnt;                       // (every lane runs the body: the queue works on whole waves)
+            {
                 const uint4 vp = np, vc = nc;
                 const uint32_t j1 = j0 + 1024u * 8u;
                 if (j1 + 8u <= cnt) { np = *reinterpret_cast<const uint4 *>(lp + j1); nc = *reinterpret_cast<const uint4 *>(lc + j1); }
@@ -117,37 +151,31 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
                     pp[k] = (wp[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu; cc[k] = (wc[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
                     const uint32_t dist = pp[k] - cc[k];
                     // a candidate that the literal rule does not reject (deflate lz77.c:223 / lz77.c:290); c == p: pending or pad
-                    act[k] = cc[k] != LZ_NONE16 && cc[k] != pp[k] && !(P.deflate ? (dist >= W - 1u) : (dist == W));
+                    act[k] = full && cc[k] != LZ_NONE16 && cc[k] != pp[k] && !(P.deflate ? (dist >= W - 1u) : (dist == W));
                     xx[k] = 0;
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) if (act[k]) xx[k] = lds_word(s_r0, cc[k] + 4u) ^ lds_word(s_r0, pp[k] + 4u);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    if (cc[k] == pp[k]) continue;                      // pending / pad: the other list (or nobody) writes it
-                    uint32_t len = 0;
-                    if (act[k]) {
-                        if (xx[k]) len = 4u + ((uint32_t)__builtin_ctz(xx[k]) >> 3);
-                        else {
-                            len = 8;
-                            while (len < max_len) {
-                                const uint32_t x = lds_word(s_r0, cc[k] + len) ^ lds_word(s_r0, pp[k] + len);
-                                if (x) { len += (uint32_t)__builtin_ctz(x) >> 3; break; }
-                                len += 4;
-                            }
-                        }
-                        if (len > max_len) len = max_len;
+                    const bool ext = act[k] && xx[k] == 0u && max_len > 8u;
+                    if (full && cc[k] != pp[k] && !ext) {              // (pending / pad: the other list, or nobody, writes it)
+                        uint32_t len = 0;
+                        if (act[k]) { len = xx[k] ? 4u + ((uint32_t)__builtin_ctz(xx[k]) >> 3) : 8u; if (len > max_len) len = max_len; }
+                        s_L[pp[k]] = (uint8_t)len;
                     }
-                    s_L[pp[k]] = (uint8_t)len;
+                    enqueue(ext, pp[k] | (cc[k] << 16));
                 }
-            } else {
-                for (uint32_t j = j0; j < cnt; ++j) { const uint32_t p = lp[j], c = lc[j]; if (c != p) s_L[p] = (uint8_t)token_len(p, c); }
             }
+            if (!full)
+                for (uint32_t j = j0; j < cnt && j < j0 + 8u; ++j) { const uint32_t p = lp[j], c = lc[j]; if (c != p) s_L[p] = (uint8_t)token_len(p, c); }
         }
     };
+    auto flush_queue = [&]() { extend(q_cur, lane < q_fill); q_fill = 0; };
     if (lists) {
         lengths_of_list(l_pos, l_cand, n);
         lengths_of_list(b_pos, b_cand, nbig);
+        flush_queue();
     } else {
         for (uint32_t p = tid; p < n; p += 1024u) s_L[p] = (uint8_t)token_len(p, cand[p]);
     }
