@@ -9,7 +9,7 @@
 // 3584 / 512 threads 11.29 GB/s; 2048 / 3072 / 768 threads 11.03; 2048 / 3072 / 1024 threads 11.07 — the kernel is not
 // short of waves.  Parts are now cut greedily up to the capacity (lz2_partition.hip).
 #ifndef LZ2_CAP
-#define LZ2_CAP       4096u                 // LDS capacity of a part (entries): 2 workgroups of k_lz2_find per CU
+#define LZ2_CAP       2560u                 // LDS capacity of a part (entries): 51 KiB, THREE workgroups of k_lz2_find per CU (4096: two; same-box A/B 18.46 -> 19.05 GB/s)
 #endif
 #ifndef LZ2_THREADS
 #define LZ2_THREADS   512                   // k_lz2_find workgroup
