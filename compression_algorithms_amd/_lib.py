@@ -55,6 +55,7 @@ EXPORTS = [
     "mi_huffman_num_tiles", "mi_huffman_hist_dev", "mi_huffman_build_dev", "mi_huffman_encode_with_tree_dev",
     "mi_huffman_build", "mi_huffman_encode_with_codes",
     "mi_lz_encode_dev", "mi_lz_encode", "mi_lz_decode_dev", "mi_lz_decode", "mi_lz_find_all_dev", "mi_lz_find_all32_dev",
+    "mi_lz77_old_bound_bytes", "mi_lz77_old_encode_dev", "mi_lz77_old_encode", "mi_lz77_whole_decode_dev", "mi_lz77_whole_decode",
     "mi_deflate_h_bound_bytes", "mi_deflate_h_encode_dev", "mi_deflate_h_decode_dev", "mi_deflate_h_encode", "mi_deflate_h_decode",
     "mi_fse_block_bound", "mi_fse_encode_dev", "mi_fse_decode_dev", "mi_fse_encode", "mi_fse_decode", "mi_fse_normalise_dev",
     "mi_set_profiling", "mi_get_kernel_times",
@@ -111,6 +112,14 @@ def lib():
             L.mi_lz_decode.argtypes = [vp, C.POINTER(LzParams), vp, u64, vp, vp, u64]
             L.mi_lz_find_all_dev.argtypes = [vp, C.POINTER(LzParams), vp, u64, vp, vp]
             L.mi_lz_find_all32_dev.argtypes = [vp, C.POINTER(LzParams), vp, u64, vp, vp]
+        if hasattr(L, "mi_lz77_old_encode_dev"):
+            u32 = C.c_uint32
+            L.mi_lz77_old_bound_bytes.restype = u64
+            L.mi_lz77_old_bound_bytes.argtypes = [u64]
+            L.mi_lz77_old_encode_dev.argtypes = [vp, u32, u32, vp, u64, vp, u64, vp, vp]
+            L.mi_lz77_old_encode.argtypes = [vp, u32, u32, vp, u64, vp, u64, vp]
+            L.mi_lz77_whole_decode_dev.argtypes = [vp, u32, u32, vp, u64, u64, vp, u64, vp]
+            L.mi_lz77_whole_decode.argtypes = [vp, u32, u32, vp, u64, u64, vp, u64]
         if hasattr(L, "mi_deflate_h_encode_dev"):
             L.mi_deflate_h_bound_bytes.restype = u64
             L.mi_deflate_h_bound_bytes.argtypes = [u64, C.POINTER(LzParams)]

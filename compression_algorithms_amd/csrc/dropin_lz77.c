@@ -162,6 +162,26 @@ BitStream *lz77_compress(const char *buffer, uint64_t size)
     return s;
 }
 
+/* lz77.c:185-262: the brute-force parser; a whole-buffer stream, registered with block 0 so that lz77_decompress knows */
+BitStream *lz77_compress_old(const char *buffer, uint64_t size)
+{
+    mi_ctx *ctx = dropin_ctx();
+    const uint32_t wbits = cur_wbits();
+    const uint64_t cap = mi_lz77_old_bound_bytes(size);
+    uint8_t *data = (uint8_t *)calloc(1, cap + 8);
+    BitStream *s = (BitStream *)malloc(sizeof *s);
+    if (!data || !s) { fprintf(stderr, "lz77_compress_old: out of memory\n"); exit(1); }
+    uint64_t bits = 0;
+    mi_status st = mi_lz77_old_encode(ctx, wbits, 4, (const uint8_t *)buffer, size, data, cap, &bits);
+    if (st != MI_OK) { fprintf(stderr, "lz77_compress_old: %s\n", mi_status_str(st)); exit(1); }
+    s->bit_index = bits;
+    s->data = (uint8_t *)realloc(data, s->bit_index / 8 + 1);  /* lz77.c:258-259 */
+    if (!s->data) { fprintf(stderr, "lz77_compress_old: out of memory\n"); exit(1); }
+    const uint64_t table[2] = {0, bits};
+    dropin_side_put(s->data, s->bit_index, size, (uint64_t)wbits << 32, table, 2);
+    return s;
+}
+
 char *lz77_decompress(BitStream *cs, uint64_t size, uint64_t *decompressed_size)
 {
     mi_ctx *ctx = dropin_ctx();
@@ -179,6 +199,13 @@ char *lz77_decompress(BitStream *cs, uint64_t size, uint64_t *decompressed_size)
             fprintf(stderr, "lz77_decompress: no block table is registered for this stream: it was not produced by this process's "
                             "lz77_compress, or it was released (mi_lz77_release).  Streams that cross processes are framed: mi_frame.h\n");
             exit(1);
+        }
+        if ((uint32_t)e.aux == 0) {                             /* a whole-buffer stream (lz77_compress_old) */
+            mi_status sw = mi_lz77_whole_decode(ctx, (uint32_t)(e.aux >> 32), 4, cs->data, total / 8 + 1, total, (uint8_t *)out, size);
+            if (sw != MI_OK) { fprintf(stderr, "lz77_decompress: %s\n", mi_status_str(sw)); exit(1); }
+            cs->bit_index = total;
+            *decompressed_size = size;
+            return out;
         }
         p.wbits = (uint32_t)(e.aux >> 32); p.tbits = p.wbits + 6; p.block = (uint32_t)e.aux;
         if (e.count != mi_lz_num_blocks(size, &p) + 1) { fprintf(stderr, "lz77_decompress: block table does not match the size\n"); exit(1); }

@@ -128,3 +128,44 @@ def decompress_h(stream, ctx=None):
                                        ctx.stream_ptr())
     _lib.check(st, "mi_deflate_h_decode_dev")
     return out[: stream.n]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the reference's first parser: lz77_compress_old (algorithms/lz77/lz77.h:51-54, lz77.c:185-262)
+class WholeStream:
+    """ONE lz77 stream over a whole buffer (no blocks): `data` uint8 tensor, `total_bits` = the reference's bit_index"""
+
+    def __init__(self, data, total_bits, n, wbits, lbits):
+        self.data, self.total_bits, self.n, self.wbits, self.lbits = data, total_bits, n, wbits, lbits
+
+    @property
+    def nbytes(self):
+        return self.total_bits // 8 + 1                   # lz77.c:258
+
+    def tobytes(self):
+        return self.data[: self.nbytes].cpu().numpy().tobytes()
+
+
+def compress_old(data, wbits=14, lbits=4, ctx=None):
+    """lz77_compress_old on the GPU: longest match of the whole 2^wbits - 1 window at every token, first-longest wins, one
+    stream over the whole buffer (lz_old.hip).  O(n * 2^wbits) like the reference."""
+    ctx = ctx or default_context()
+    d_in = as_device_bytes(data, ctx.device)
+    n = d_in.numel()
+    cap = int(ctx.L.mi_lz77_old_bound_bytes(n))
+    out = torch.empty(cap, dtype=torch.uint8, device=ctx.device)
+    bits = torch.zeros(1, dtype=torch.int64, device=ctx.device)
+    st = ctx.L.mi_lz77_old_encode_dev(ctx.h, wbits, lbits, C.c_void_p(d_in.data_ptr() if n else 0), n, C.c_void_p(out.data_ptr()), cap,
+                                      C.c_void_p(bits.data_ptr()), ctx.stream_ptr())
+    _lib.check(st, "mi_lz77_old_encode_dev")
+    return WholeStream(out, int(bits.item()), n, wbits, lbits)
+
+
+def decompress_whole(stream, ctx=None):
+    """decode a whole-buffer lz77 stream (lz77.c:347-377) on one wave"""
+    ctx = ctx or default_context()
+    out = torch.empty(max(stream.n, 1), dtype=torch.uint8, device=ctx.device)
+    st = ctx.L.mi_lz77_whole_decode_dev(ctx.h, stream.wbits, stream.lbits, C.c_void_p(stream.data.data_ptr()), stream.data.numel(),
+                                        stream.total_bits, C.c_void_p(out.data_ptr()), stream.n, ctx.stream_ptr())
+    _lib.check(st, "mi_lz77_whole_decode_dev")
+    return out[: stream.n]

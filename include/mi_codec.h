@@ -226,6 +226,23 @@ mi_status mi_lz_find_all_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *
 mi_status mi_lz_find_all32_dev(mi_ctx *ctx, const mi_lz_params *p, const uint8_t *d_in, uint64_t n,
                                uint32_t *d_cand, void *stream);
 
+/* The reference's first, brute-force parser — lz77_compress_old, algorithms/lz77/lz77.h:51-54, lz77.c:185-262 (its call is
+ * commented out at lz77/main.c:26): the whole window of 2^wbits - 1 bytes is searched at every token start, first-longest
+ * match wins, ONE stream over the whole buffer in lz77_compress's token format.  O(n * 2^wbits) by definition; on the GPU
+ * the best match of every position is found independently (lz_old.hip).  d_out: mi_lz77_old_bound_bytes(n) bytes, 4-byte
+ * aligned, zeroed by the call; *total_bits = the reference's bit_index (the stream is total_bits / 8 + 1 bytes, lz77.c:258).
+ * wbits 8..16, lbits 3..5 (the reference: 14, 4).  mi_lz77_whole_decode* decodes a whole-buffer stream (this parser's, or
+ * lz77_compress's for a buffer of one block): lz77.c:347-377 on one wave; n < 2^32. */
+uint64_t  mi_lz77_old_bound_bytes(uint64_t n);
+mi_status mi_lz77_old_encode_dev(mi_ctx *ctx, uint32_t wbits, uint32_t lbits, const uint8_t *d_in, uint64_t n,
+                                 uint8_t *d_out, uint64_t cap_bytes, uint64_t *d_total_bits, void *stream);
+mi_status mi_lz77_old_encode(mi_ctx *ctx, uint32_t wbits, uint32_t lbits, const uint8_t *h_in, uint64_t n,
+                             uint8_t *h_out, uint64_t cap_bytes, uint64_t *h_total_bits);
+mi_status mi_lz77_whole_decode_dev(mi_ctx *ctx, uint32_t wbits, uint32_t lbits, const uint8_t *d_stream, uint64_t stream_bytes,
+                                   uint64_t total_bits, uint8_t *d_out, uint64_t n, void *stream);
+mi_status mi_lz77_whole_decode(mi_ctx *ctx, uint32_t wbits, uint32_t lbits, const uint8_t *h_stream, uint64_t stream_bytes,
+                               uint64_t total_bits, uint8_t *h_out, uint64_t n);
+
 /* ------------------------------------------------------------------------------------
  * Deflate "mode H": the entropy stage algorithms/deflate/lz77.c:279 leaves as a TODO
  * ("Build huffman tree and encode compressed buffer").  The token sequence is the

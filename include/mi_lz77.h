@@ -68,8 +68,11 @@ void init_hash_table(HashTableArray *table);
  * reference they stop at the last bucket and exit(1) where the reference's unbounded probe would write past the array. */
 void     insert_hash_table(HashTableArray *table, uint32_t pattern, uint64_t index);
 uint64_t find(HashTableArray *table, uint32_t pattern);
-/* NOT exported: lz77_compress_old (lz77.h:51-54), the reference's unused brute-force parser (commented out at
- * lz77/main.c:26): a different stream, O(n * W) by design. */
+/* lz77.h:51-54, lz77.c:185-262: the reference's first, brute-force parser (its call is commented out at lz77/main.c:26) —
+ * a different stream from lz77_compress: longest match of the whole window at every token, first-longest wins, one stream
+ * over the whole buffer.  On the GPU: lz_old.hip (mi_lz77_old_encode).  Same ownership as lz77_compress; lz77_decompress
+ * decodes it (the stream is registered as a whole-buffer stream). */
+BitStream *lz77_compress_old(const char *buffer, uint64_t size);
 void  print_bit_string(const char *buffer, uint64_t size);
 char *read_input_buffer(const char *filename, uint64_t *size);
 bool  check_buffer_equivalence(const char *buffer1, const char *buffer2, uint64_t size);

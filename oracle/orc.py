@@ -110,6 +110,18 @@ def lz77_encode(data, wbits=14, lbits=4, tbits=None, trace=False):
     return (stream, nbits, tr[:n]) if trace else (stream, nbits)
 
 
+def lz77_old_encode(data, wbits=14, lbits=4):
+    """the reference's brute-force parser (lz77_compress_old, lz77.c:185-262) -> (stream bytes, nbits); O(n * 2^wbits)"""
+    n = len(data)
+    src = _padded(data)
+    out = np.zeros(2 * n + 8, dtype=np.uint8)
+    L = lib()
+    L.orc_lz77_old_encode.restype = C.c_uint64
+    L.orc_lz77_old_encode.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
+    nbits = L.orc_lz77_old_encode(_p(src), n, wbits, lbits, _p(out))
+    return out[: nbits // 8 + 1].copy(), nbits
+
+
 def lz77_decode(stream, nbits, n, wbits=14, lbits=4):
     s = np.ascontiguousarray(np.frombuffer(bytes(stream), dtype=np.uint8))
     s = np.concatenate([s, np.zeros(8, np.uint8)])

@@ -128,6 +128,40 @@ uint64_t orc_lz77_decode(const uint8_t *stream, uint64_t nbits, uint32_t wbits, 
     return o;
 }
 
+/* The reference's first, brute-force parser: lz77_compress_old, algorithms/lz77/lz77.c:185-262.  At every token start the
+ * window of 2^wbits - 1 bytes is searched from its far end; a candidate counts when its 4-byte word equals the word at the
+ * position (lz77.c:215-221: both words may reach up to 3 bytes past `size`; the zero tail behind `in` defines them), its
+ * length is the common prefix, stopped at the maximum and at `size` (lz77.c:223-233), and it replaces the best so far only when
+ * strictly longer (lz77.c:236-239).  For the first 2^wbits - 1 positions `buffer_index - window_size` wraps around (uint64_t;
+ * max() on unsigned operands, lz77.c:208): the loop over the window never runs and the token is a literal.  Returns the
+ * stream's length in bits; `out` (2 n + 8 bytes) is zeroed first.  `in` needs >= 34 readable zero bytes after n. */
+uint64_t orc_lz77_old_encode(const uint8_t *in, uint64_t n, uint32_t wbits, uint32_t lbits, uint8_t *out)
+{
+    const uint64_t ws = (1ull << wbits) - 1, max_len = (1ull << lbits) - 1;
+    memset(out, 0, 2 * n + 8);
+    orc_bits s = { out, 0 };
+    uint64_t p = 0;
+    while (p < n) {
+        uint64_t best = 0, off = 0;
+        if (p >= ws) {
+            for (uint64_t q = p - ws; q < p; ++q) {
+                if (memcmp(in + q, in + p, 4) != 0) continue;
+                uint64_t len = 0;
+                while (p + len < n && in[q + len] == in[p + len]) { ++len; if (len >= max_len) break; }
+                if (len > best) { best = len; off = p - q; }
+            }
+        }
+        if (best) {
+            orc_put(&s, 1, 1); orc_put(&s, off, wbits); orc_put(&s, best, lbits);
+            p += best;
+        } else {
+            orc_put(&s, 0, 1); orc_put(&s, in[p], 8);
+            p += 1;
+        }
+    }
+    return s.nbits;
+}
+
 /* ---------- deflate per-block tokeniser ---------- */
 
 typedef struct {

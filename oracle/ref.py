@@ -75,6 +75,25 @@ def lz77_compress(data, wbits=14):
     return raw, nbits
 
 
+def lz77_compress_old(data, wbits=14):
+    """the reference's lz77_compress_old (lz77.c:185-262) -> (stream bytes, pad bits masked to 0, bit_index)"""
+    L = _lz77(wbits)
+    L.lz77_compress_old.restype = C.POINTER(_BitStream)
+    L.lz77_compress_old.argtypes = [C.c_void_p, C.c_uint64]
+    src = _padded(data)
+    bs = L.lz77_compress_old(_p(src), len(data))
+    nbits = int(bs.contents.bit_index)
+    nbytes = nbits // 8 + 1
+    raw = np.ctypeslib.as_array(bs.contents.data, shape=(nbytes,)).copy()
+    if nbits % 8:
+        raw[nbits // 8] &= (1 << (nbits % 8)) - 1
+    else:
+        raw[nbits // 8] = 0
+    _libc.free(C.cast(bs.contents.data, C.c_void_p))
+    _libc.free(C.cast(bs, C.c_void_p))
+    return raw, nbits
+
+
 def lz77_hash(word, wbits=14):
     return int(_lz77(wbits).hash(word))
 
