@@ -589,7 +589,7 @@ void k_lz_emulate_dom(LzP P, LzScratch sc, uint64_t *dbg)
         uint16_t *cand = sc.cand + (size_t)lb * LZ_MAX_BLOCK;
         uint32_t done_upto = m;                                                     // entries whose results were written
         if (dbg && tid == 0) { atomicAdd((unsigned long long *)&dbg[50], 1ull); atomicAdd((unsigned long long *)&dbg[51], (unsigned long long)m); atomicAdd((unsigned long long *)&dbg[52], (unsigned long long)(clock64() - tk0)); tk0 = clock64(); }
-        uint32_t n_fast = 0, n_scan = 0, n_fgn = 0;
+        uint32_t n_fast = 0, n_scan = 0, n_fgn = 0, n_bulk = 0;
         if (tid < 64) {
             uint32_t ev = 0, f_ev = 0, f_n = 0, anchor_pos = 0, stash = 0, stash_of = ~0u;
             bool anchor_ok = false, bailed = false;
@@ -653,9 +653,79 @@ void k_lz_emulate_dom(LzP P, LzScratch sc, uint64_t *dbg)
                     __builtin_amdgcn_wave_barrier();
                     continue;
                 }
-                for (uint32_t t = 0; t < lim; ++t) {
+                for (uint32_t t = 0; t < lim; ) {
                     const uint32_t i = i0 + t;
                     const uint32_t p = RLANE(c_pos, t), r = RLANE(c_r, t), id = RLANE(c_pid, t);
+                    // The STEADY STATE of a long run of X — consecutive positions, each retiring exactly the oldest live entry, which
+                    // is itself a copy of X from a run of consecutive positions — goes k entries at a time: the slot a retirement
+                    // opens lies below the first free slot, so the new copy takes exactly that slot (the serial code below: save the
+                    // free run, take the slot, restore the free run) — the bitmap and the free run do not change, the slots move
+                    // down the ring k places, and find() changes only where the retired slot is X's home (the new copy becomes
+                    // the anchor).  One wave-wide step for up to 64 entries instead of ~700 cycles each.
+                    // ... and the stretches in which nothing retires (the window's far edge lies in other data): k copies of X take the
+                    // next k free slots and all find the same thing — the partial form of the 64-entry step above
+                    if (id == X && !(ev < i && pe + W < p)) {
+                        const uint32_t u = lane - t;
+                        const uint32_t room = lf - nx;
+                        const bool ok = lane >= t && lane < lim && c_pid == X && !(ev < i0 + lane && pe + W < c_pos) && u < room && (i0 + lane - ev) < W;
+                        const uint64_t okm = __ballot(ok) >> t;
+                        const uint32_t k = (~okm) ? (uint32_t)__builtin_ctzll(~okm) : 64u;
+                        if (k >= 2u) {
+                            uint32_t res = LZ_NONE16;
+                            if (c_pid != c_pos) { if (ev == 0) res = c_pid; else if (anchor_ok) res = anchor_pos; }
+                            if (nx == rX) {                                         // the first of them takes X's home
+                                if (ev != 0 && !anchor_ok && u > 0 && c_pid != c_pos) res = p;
+                                anchor_ok = true; anchor_pos = p;
+                            }
+                            if (lane >= t && u < k) {
+                                const uint32_t b = nx + u;
+                                atomicOr(&s_occ[b >> 5], 1u << (b & 31u));
+                                ((volatile uint16_t *)s_ring)[(i0 + lane) & (W - 1u)] = (uint16_t)b;
+                                out_acc = res;
+                            }
+                            nx += k;
+                            if (nx >= lf) refill();
+                            n_fast += k; n_bulk += k; t += k;
+                            __builtin_amdgcn_wave_barrier();
+                            continue;
+                        }
+                    }
+                    if (id == X && ev > 0 && ev < i && pe + W + 1u == p && !sv) {
+                        const uint32_t u = lane - t, eoff = ev & 63u;
+                        const uint32_t maxk = (lim - t) < (64u - eoff) ? (lim - t) : (64u - eoff);
+                        const bool in = lane >= t && u < maxk;
+                        const uint32_t rl = (eoff + u) & 63u;
+                        const uint32_t rp = (uint32_t)__shfl((int)e_pos, (int)rl), rid = (uint32_t)__shfl((int)e_pid, (int)rl);
+                        const bool alias = (i - ev - 1u) == W;                      // the ring is full: entry i + u takes the place of entry ev + u + 1
+                        uint32_t su = in ? (uint32_t)((const volatile uint16_t *)s_ring)[(ev + u) & (W - 1u)] : 0u;
+                        if (alias && lane == t) su = stash;
+                        const bool ok = in && c_pid == X && c_pos == p + u && rid == X && rp == pe + u && su < nx && su >= rX;
+                        const uint64_t okm = __ballot(ok) >> t;
+                        const uint32_t k = (~okm) ? (uint32_t)__builtin_ctzll(~okm) : 64u;
+                        if (k >= 2u && (!alias || stash_of == ev)) {
+                            uint32_t new_stash = 0;
+                            if (alias) new_stash = (uint32_t)__builtin_amdgcn_readfirstlane((int)((const volatile uint16_t *)s_ring)[(ev + k) & (W - 1u)]);
+                            const bool mine = lane >= t && u < k;
+                            const uint64_t hit = __ballot(mine && su == rX);
+                            const uint32_t ts = hit ? (uint32_t)__builtin_ctzll(hit) : 64u;     // the entry that retires the anchor and takes its place
+                            if (mine) {
+                                uint32_t res = LZ_NONE16;
+                                if (lane < ts) { if (anchor_ok) res = anchor_pos; }
+                                else if (lane > ts) res = p + (ts - t);
+                                if (c_pid == c_pos) res = LZ_NONE16;                // (a word's first occurrence finds nothing, ever)
+                                ((volatile uint16_t *)s_ring)[(i0 + lane) & (W - 1u)] = (uint16_t)su;
+                                out_acc = res;
+                            }
+                            if (hit) { anchor_ok = true; anchor_pos = p + (ts - t); }
+                            if (alias) { stash = new_stash; stash_of = ev + k; }
+                            ev += k;
+                            if ((ev & 63u) == 0) { const uint32_t q = ev + lane; const uint64_t x = q < m ? E[a + q] : 0ull; e_pos = (uint32_t)(x >> 16) & 0xFFFFu; e_pid = (uint32_t)(x >> 48); }
+                            pe = RLANE(e_pos, ev & 63u);
+                            n_fast += k; n_bulk += k; t += k;
+                            __builtin_amdgcn_wave_barrier();
+                            continue;
+                        }
+                    }
                     while (ev < i && pe + W < p) {                                  // FIFO retirement (lz77.c:70-76): clears the bucket
                         const uint32_t sl = ev == stash_of ? stash : (uint32_t)__builtin_amdgcn_readfirstlane((int)((const volatile uint16_t *)s_ring)[ev & (W - 1u)]);
                         bit_clear(sl);
@@ -726,13 +796,15 @@ void k_lz_emulate_dom(LzP P, LzScratch sc, uint64_t *dbg)
                     if (lane == 0) ((volatile uint16_t *)s_ring)[i & (W - 1u)] = (uint16_t)b;
                     if (lane == t) out_acc = res;
                     __builtin_amdgcn_wave_barrier();
+                    ++t;
                 }
                 if (!bailed && i0 + lane < m && out_acc != LZ_NONE16) cand[c_pos] = (uint16_t)out_acc;
             }
             if (lane == 0) s_result = bailed ? (1u | (done_upto << 1)) : 0u;
             if (dbg && lane == 0) { atomicAdd((unsigned long long *)&dbg[53], (unsigned long long)(clock64() - tk0)); atomicAdd((unsigned long long *)&dbg[54], (unsigned long long)n_fast);
                                     atomicAdd((unsigned long long *)&dbg[55], (unsigned long long)n_scan); atomicAdd((unsigned long long *)&dbg[56], (unsigned long long)n_fgn);
-                                    if (bailed) atomicAdd((unsigned long long *)&dbg[57], 1ull); }
+                                    if (bailed) atomicAdd((unsigned long long *)&dbg[57], 1ull);
+                                    atomicAdd((unsigned long long *)&dbg[61], (unsigned long long)n_bulk); }
         }
         __syncthreads();
         const uint32_t rs_ = s_result;
