@@ -9,7 +9,12 @@
 // 3584 / 512 threads 11.29 GB/s; 2048 / 3072 / 768 threads 11.03; 2048 / 3072 / 1024 threads 11.07 — the kernel is not
 // short of waves.  Parts are now cut greedily up to the capacity (lz2_partition.hip).
 #ifndef LZ2_CAP
-#define LZ2_CAP       2560u                 // LDS capacity of a part (entries): 51 KiB, THREE workgroups of k_lz2_find per CU (4096: two; same-box A/B 18.46 -> 19.05 GB/s)
+#define LZ2_CAP       4096u                 // largest part stage 2 takes (entries): k_lz2_find_wide, 76 KiB of LDS, two workgroups per CU
+#endif
+#ifndef LZ2_CAP_S
+#define LZ2_CAP_S     2560u                 // what the partition aims for: k_lz2_find, 51 KiB, THREE workgroups per CU (same-box A/B against
+                                            // parts of 4096 everywhere: 19.7 -> 20.4 GB/s).  A part between the two exists only where no
+                                            // certified cut lies within 2560 entries (one cluster of 2561..4096 entries: runs of one byte).
 #endif
 #ifndef LZ2_THREADS
 #define LZ2_THREADS   512                   // k_lz2_find workgroup
@@ -19,7 +24,7 @@
 #define LZ2_PARTBITS  5                     // parts per block <= 2^LZ2_PARTBITS (one radix digit of stage 1)
 #endif
 #define LZ2_MAXPARTS  (1u << LZ2_PARTBITS)
-static_assert(LZ2_CAP % LZ2_THREADS == 0, "entries per thread must be whole");
+static_assert(LZ2_CAP % LZ2_THREADS == 0 && LZ2_CAP_S % LZ2_THREADS == 0 && LZ2_CAP_S <= LZ2_CAP, "entries per thread must be whole");
 #ifndef LZ2_BIG
 #define LZ2_BIG       8u                    // clusters of at least this many entries leave k_lz2_find (8 or 16: the register replay holds < 16)
 #endif
@@ -69,8 +74,10 @@ struct Lz2Scratch {
     uint16_t     *cand;         // [nb][65536] find() result aligned with plist (own position = pending: see bigcand)
     Lz2BlockMeta *meta;         // [nb]
     uint32_t     *fallback_count, *fallback_list;    // blocks the first pipeline has to do
-    uint32_t     *work_count;
-    uint64_t     *work;                              // parts of the batch, appended by the partition: block | part << 16 | entries << 24 | list start << 40
+    uint32_t     *work_count;                        // [0] parts listed from the front, [1] parts above LZ2_CAP_S entries listed from the end
+    uint32_t      work_slots;                        // entries of `work`
+    uint64_t     *work;                              // [nb * LZ2_MAXPARTS] parts of the batch, appended by the partition (parts above LZ2_CAP_S entries from the END
+                                                     // of the array backwards, counted in work_count[1]: k_lz2_find_wide takes those): block | part << 16 | entries << 24 | list start << 40
                                                      // (k_lz2_find starts its list loads from the item alone: one dependent round trip less)
     uint16_t     *bigpos, *bigrs, *bigpid, *bigcand; // [nb][LZ2_BIG_STRIDE] entries of exported clusters, (cluster, time) order
     Lz2BigDesc   *desc[LZ2_NCLASS];                  // per class: [nb * capacity of the class]

@@ -117,20 +117,21 @@ __device__ __forceinline__ void replay_small_reg(const uint16_t *pos, const uint
     }
 }
 
-__global__ __launch_bounds__(LZ2_THREADS)
-void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scratch sc, uint64_t block0)
+// one part: `item` = block | part << 16 | entries << 24 | list start << 40 (lz2.h).  CAP = LDS capacity in entries.
+template <uint32_t CAP>
+__device__ __forceinline__ void lz2_find_part(const uint8_t *__restrict__ in, uint64_t n_total, const LzP &P, const Lz2Scratch &sc, uint64_t block0, const uint64_t item)
 {
     // 16 bytes per entry + radix counters
-    __shared__ uint16_t s_pos[LZ2_CAP];                 // position by time index j
-    __shared__ uint32_t s_word[LZ2_CAP];                // mix32(word) by j; later e_pos / e_rs (replay order)
-    __shared__ uint16_t s_j0[LZ2_CAP], s_j1[LZ2_CAP];   // sort ping-pong; later e_pid / (free)
-    __shared__ __attribute__((aligned(16))) uint16_t s_gr[2 * LZ2_CAP];   // s_g | s_r; during the home sort: the second pass's counters
+    __shared__ uint16_t s_pos[CAP];                 // position by time index j
+    __shared__ uint32_t s_word[CAP];                // mix32(word) by j; later e_pos / e_rs (replay order)
+    __shared__ uint16_t s_j0[CAP], s_j1[CAP];   // sort ping-pong; later e_pid / (free)
+    __shared__ __attribute__((aligned(16))) uint16_t s_gr[2 * CAP];   // s_g | s_r; during the home sort: the second pass's counters
     uint16_t *const s_g = s_gr;                          // cluster number by j; later occ
-    uint16_t *const s_r = s_gr + LZ2_CAP;                // dense home slot by j; later cand by replay index
-    __shared__ uint16_t s_pid[LZ2_CAP + 2];             // word id by j (position of the first occurrence); then s_gstart; last cand by j
+    uint16_t *const s_r = s_gr + CAP;                // dense home slot by j; later cand by replay index
+    __shared__ uint16_t s_pid[CAP + 2];             // word id by j (position of the first occurrence); then s_gstart; last cand by j
     __shared__ uint32_t s_cnt[LZ2_NWAVES + 1][256];   // radix counters, [digit][wave + pad] (lz_common.h)
-    __shared__ uint32_t s_bm[LZ2_CAP / 32 + 2];
-    __shared__ uint32_t s_mix[LZ2_CAP / 32 + 2];        // bit g: cluster g holds more than one home or more than one word ("mixed")
+    __shared__ uint32_t s_bm[CAP / 32 + 2];
+    __shared__ uint32_t s_mix[CAP / 32 + 2];        // bit g: cluster g holds more than one home or more than one word ("mixed")
     __shared__ int32_t  s_i32[18];
     __shared__ uint32_t s_zslot, s_zgid, s_nbigl, s_ngroups;
     // LDS diet: two of these workgroups share a CU, and whatever they leave (160 KiB - 2 x this kernel) is all that the
@@ -141,22 +142,10 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     //            entries) live in the radix counters, dead after the second sort.
     uint16_t *const s_gstart = s_pid;
     uint32_t *const s_big = &s_cnt[0][0];
-    uint16_t *const s_quiet = reinterpret_cast<uint16_t *>(&s_cnt[0][0] + 3 * LZ2_MAXBIG);
-    static_assert(3 * LZ2_MAXBIG * 4 + 2 * LZ2_MAXBIG * 2 <= sizeof(uint32_t) * LZ2_NWAVES * 256, "export lists must fit the radix counters");
+    uint16_t *const s_quiet = reinterpret_cast<uint16_t *>(&s_cnt[0][0] + 3 * (CAP / LZ2_BIG));
+    static_assert(3 * (CAP / LZ2_BIG) * 4 + 2 * (CAP / LZ2_BIG) * 2 <= sizeof(uint32_t) * LZ2_NWAVES * 256, "export lists must fit the radix counters");
 
     const int tid = threadIdx.x;
-    // The grid covers the worst case (32 parts per block) and the listed parts come first; a surplus workgroup reads the
-    // count and leaves.  Measured (round 2, same box, 10^9 bytes): a persistent grid of 2 workgroups per CU pulling parts
-    // off a cursor made this kernel 30.3 -> 51 ms per GB on its own — the loop keeps every scratch pointer live across
-    // the whole body: 84 -> 176 VGPRs, one workgroup per CU instead of two (forced back to 128 VGPRs it spills) — and the
-    // hardware dispatcher already IS a dynamic scheduler: ~13 k empty workgroups per batch cost nothing measurable.
-    // XCD-aware order: workgroup ids go round the 8 XCDs (each with its own L2), the work list holds a block's parts one
-    // after the other — so give every XCD a CONTIGUOUS eighth of the list: the ~19 parts of a block then gather their
-    // words from one L2 instead of pulling the block's 64 KiB into all eight (HBM fetch of this kernel: profiles/).
-    const uint32_t nwork = *sc.work_count;
-    const uint32_t cpx = (nwork + 7u) >> 3, item_idx = (blockIdx.x & 7u) * cpx + (blockIdx.x >> 3);
-    if ((blockIdx.x >> 3) >= cpx || item_idx >= nwork) return;
-    const uint64_t item = sc.work[item_idx];
     const uint32_t lb = (uint32_t)item & 0xFFFFu, part = (uint32_t)(item >> 16) & 0xFFu;
     Lz2BlockMeta *mt = sc.meta + lb;
     long long tk = clock64();
@@ -199,7 +188,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     {
         // all of a thread's positions first, then all of their words, then the hashing: the two dependent global loads of
         // every entry are in flight together instead of one entry at a time
-        constexpr uint32_t GCH = LZ2_CAP / LZ2_THREADS;
+        constexpr uint32_t GCH = CAP / LZ2_THREADS;
         uint32_t gp[GCH], glo[GCH], ghi[GCH];
         const bool aligned = (((uintptr_t)src) & 3u) == 0;
 #pragma unroll
@@ -240,7 +229,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
             }
         }
     }
-    for (uint32_t i = tid; i < LZ2_CAP / 32 + 2; i += LZ2_THREADS) { s_bm[i] = 0; s_mix[i] = 0; }
+    for (uint32_t i = tid; i < CAP / 32 + 2; i += LZ2_THREADS) { s_bm[i] = 0; s_mix[i] = 0; }
     if (tid == 0) { s_zslot = ~0u; s_zgid = ~0u; s_nbigl = 0; }
     __syncthreads();
     auto homep = [&](uint32_t j) -> uint32_t { return ((s_word[j] & Tmask) - base) & Tmask; };
@@ -274,7 +263,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
 
     LZ2_TICK(1);
     // ---- parking sweep over the sorted order: CH consecutive entries per thread
-    constexpr uint32_t CH = LZ2_CAP / LZ2_THREADS;
+    constexpr uint32_t CH = CAP / LZ2_THREADS;
     const uint32_t k0 = tid * CH, k1 = (k0 + CH < m) ? k0 + CH : m;
     {
         // the thread's CH entries live in registers for the three passes below (time index, mixed word, home')
@@ -409,10 +398,10 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
 
     LZ2_TICK(2);
     // ---- sort time indices by cluster number (they start in time order): identity -> j0 -> j1
-    //      (cluster numbers are < LZ2_CAP <= 4096: two 6-bit passes, fewer ballots and a shorter offset scan than 8 + 8)
-    static_assert(LZ2_CAP <= 8192, "cluster numbers must fit 13 bits");
-    constexpr int GB2 = LZ2_CAP > 4096 ? 7 : 6;          // bits of the second cluster-number pass
-    static_assert(2 * LZ2_CAP <= sizeof(uint32_t) * (LZ2_NWAVES + 1) * 256, "the cluster cursors live in the radix counters");
+    //      (cluster numbers are < CAP <= 4096: two 6-bit passes, fewer ballots and a shorter offset scan than 8 + 8)
+    static_assert(CAP <= 8192, "cluster numbers must fit 13 bits");
+    constexpr int GB2 = CAP > 4096 ? 7 : 6;          // bits of the second cluster-number pass
+    static_assert(2 * CAP <= sizeof(uint32_t) * (LZ2_NWAVES + 1) * 256, "the cluster cursors live in the radix counters");
     if (arank & LZP_ARANK) {
         // ONE pass, no counting: the sweep left every cluster's first replay index as a 16-bit cursor; an entry's place is its
         // cluster's cursor, post-incremented — in TIME order.  Time order needs every cursor to be advanced by one wave only
@@ -451,7 +440,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
                 if (gg[u] != 0xFFFFFFFFu && ((gg[u] >> 1) % (uint32_t)LZ2_NWAVES) == wv) s_j1[(old[u] >> (16u * (gg[u] & 1u))) & 0xFFFFu] = (uint16_t)jj[u];
         }
         __syncthreads();
-        for (uint32_t i = tid; i < LZ2_CAP / 32 + 2; i += LZ2_THREADS) s_bm[i] = 0;     // back to the replay's empty bitmap (barriers follow)
+        for (uint32_t i = tid; i < CAP / 32 + 2; i += LZ2_THREADS) s_bm[i] = 0;     // back to the replay's empty bitmap (barriers follow)
     } else {
         radix_pass<LZ2_NWAVES, 6, uint32_t>(m, s_cnt, [&](uint32_t i) { return i; },
             [&](uint32_t e) { return (uint32_t)s_g[e] & 63u; }, [&](uint32_t d, uint32_t e) { s_j0[d] = (uint16_t)e; }, arank);
@@ -462,7 +451,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     LZ2_TICK(3);
     // ---- permute into replay order (cluster, time).  e_pos / e_rs overlay the dead word array.
     uint16_t *e_pos = reinterpret_cast<uint16_t *>(s_word);
-    uint16_t *e_rs = e_pos + LZ2_CAP;
+    uint16_t *e_rs = e_pos + CAP;
     uint16_t *e_pid = s_j0;
     uint32_t regs[CH][3];
     for (uint32_t c = 0; c < CH; ++c) {
@@ -500,7 +489,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
 
     LZ2_TICK(4);
     __shared__ uint32_t s_cls[LZ2_NCLASS], s_clsbase[LZ2_NCLASS], s_ent, s_entbase;
-    uint32_t my_rank[(LZ2_MAXBIG + LZ2_THREADS - 1) / LZ2_THREADS], my_dst[(LZ2_MAXBIG + LZ2_THREADS - 1) / LZ2_THREADS];
+    uint32_t my_rank[((CAP / LZ2_BIG) + LZ2_THREADS - 1) / LZ2_THREADS], my_dst[((CAP / LZ2_BIG) + LZ2_THREADS - 1) / LZ2_THREADS];
     uint32_t nbig = 0;
     // ---- replay.  Clusters below LZ2_BIG entries: one lane each, lanes sorted by cluster size so that the
     //      64 lanes of a wave run the same number of steps.  Larger clusters are exported by size class.
@@ -529,7 +518,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
                 else if ((uint32_t)e_pos[e - 1] <= (uint32_t)e_pos[i] + W && i != s_zhead) { const uint32_t q = atomicAdd(&s_nquiet, 1u); s_quiet[2 * q] = (uint16_t)i; s_quiet[2 * q + 1] = (uint16_t)e; }
                 else {
                     const uint32_t q = atomicAdd(&s_nbigl, 1u);
-                    if (q < LZ2_MAXBIG) { s_big[3 * q] = i; s_big[3 * q + 1] = e; }
+                    if (q < (CAP / LZ2_BIG)) { s_big[3 * q] = i; s_big[3 * q + 1] = e; }
                 }
             }
         }
@@ -548,7 +537,7 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
         // reserve the output space of the clusters this part exports NOW — ONE global atomic per part and class (the class
         // counters are shared by every workgroup of the batch), local ranks first in LDS — so that the round trips of
         // those atomics pass while the lanes replay
-        nbig = s_nbigl < LZ2_MAXBIG ? s_nbigl : LZ2_MAXBIG;          // LZ2_CAP / LZ2_BIG clusters at most
+        nbig = s_nbigl < (CAP / LZ2_BIG) ? s_nbigl : (CAP / LZ2_BIG);          // CAP / LZ2_BIG clusters at most
         {
             uint32_t it = 0;
             for (uint32_t q = tid; q < nbig; q += LZ2_THREADS, ++it) {
@@ -659,6 +648,35 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
     for (uint32_t j = tid; j < m; j += LZ2_THREADS) cout[j] = cand_j[j];
     LZ2_TICK(6);
     if (sc.dbg && tid == 0) atomicAdd((unsigned long long *)&sc.dbg[15], 1ull);
+}
+
+
+// The grid covers the worst case (32 parts per block) and the listed parts come first; a surplus workgroup reads the
+// count and leaves.  Measured (round 2, same box, 10^9 bytes): a persistent grid of 2 workgroups per CU pulling parts
+// off a cursor made this kernel 30.3 -> 51 ms per GB on its own — the loop keeps every scratch pointer live across
+// the whole body: 84 -> 176 VGPRs, one workgroup per CU instead of two (forced back to 128 VGPRs it spills) — and the
+// hardware dispatcher already IS a dynamic scheduler: ~13 k empty workgroups per batch cost nothing measurable.
+// XCD-aware order: workgroup ids go round the 8 XCDs (each with its own L2), the work list holds a block's parts one
+// after the other — so give every XCD a CONTIGUOUS eighth of the list: the ~26 parts of a block then gather their
+// words from one L2 instead of pulling the block's 64 KiB into all eight (HBM fetch of this kernel: profiles/).
+__global__ __launch_bounds__(LZ2_THREADS)
+void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scratch sc, uint64_t block0)
+{
+    const uint32_t nwork = *sc.work_count;
+    const uint32_t cpx = (nwork + 7u) >> 3, item_idx = (blockIdx.x & 7u) * cpx + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= cpx || item_idx >= nwork) return;
+    lz2_find_part<LZ2_CAP_S>(in, n_total, P, sc, block0, sc.work[item_idx]);
+}
+
+// the parts above LZ2_CAP_S entries (rare: listed from the end of the work array backwards): a small grid that loops
+__global__ __launch_bounds__(LZ2_THREADS)
+void k_lz2_find_wide(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scratch sc, uint64_t block0)
+{
+    const uint32_t nwide = sc.work_count[1];
+    for (uint32_t k = blockIdx.x; k < nwide; k += gridDim.x) {
+        lz2_find_part<LZ2_CAP>(in, n_total, P, sc, block0, sc.work[sc.work_slots - 1u - k]);
+        __syncthreads();
+    }
 }
 
 // =============================================================================================
@@ -852,6 +870,7 @@ void lz2_carve(mi_carver &cv, uint32_t nb, Lz2Scratch *sc)
     sc->big_count = sc->fallback_count + 16;
     sc->work_count = sc->fallback_count + 32;            // zeroed with the other counters by stage 1
     sc->work = cv.take<uint64_t>((size_t)nb * LZ2_MAXPARTS);
+    sc->work_slots = nb * LZ2_MAXPARTS;
     sc->dbg = getenv("MI_LZ_DEBUG") ? cv.take<uint64_t>(64) : nullptr;
     sc->wave_min = LZ2_WAVE;
 #ifdef MI_MEASURE
@@ -899,6 +918,8 @@ mi_status lz2_stage_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_
     // the partition cuts at most LZ2_MAXPARTS parts per block (greedy, data dependent: ~19 for a full block) and lists them
     const uint32_t parts = P.block / 64u + 1u < LZ2_MAXPARTS ? P.block / 64u + 1u : LZ2_MAXPARTS;
     hipLaunchKernelGGL(k_lz2_find, dim3(parts * nb), dim3(LZ2_THREADS), 0, s, d_in, n, P, sc, block0);
+    // parts of 2561..4096 entries (none in text): 256 looping workgroups, gone at once when the list is empty
+    hipLaunchKernelGGL(k_lz2_find_wide, dim3(256), dim3(LZ2_THREADS), 0, s, d_in, n, P, sc, block0);
     MI_HIP(ctx, hipGetLastError());
     return MI_OK;
 }

@@ -136,8 +136,8 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
         uint32_t k = 0, cur = 0, glo = 0;               // parts so far, entries before the current part, its first rotated group
         bool bad = false;
         if (lane == 0) s_thr[0] = 0;
-        while (n - cur > LZ2_CAP) {
-            const uint32_t limit = cur + LZ2_CAP;
+        // last certified group g in [glo, .) with at most `limit` entries in rotated groups 0..g, or -1
+        auto cut_below = [&](uint32_t limit) -> int32_t {
             // (a part of a 2^20-bucket table is also kept below 2^16 homes: stage 2 then sorts 16-bit keys in two radix
             //  passes instead of three; a 2^22-bucket table spreads 4096 entries over ~2^18 homes whatever the cut)
             const uint32_t span = (gshift <= 6u) ? (65536u >> gshift) : LZ2_NG;
@@ -156,11 +156,20 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
                 }
             }
             // boundary after the last certified group before it, inside this part: 64 groups per look
-            int32_t gr = -1;
             for (int32_t g = (int32_t)lo - 1; g >= (int32_t)glo; g -= 64) {
                 const int32_t c = g - (int32_t)lane;
                 const uint64_t mk = __ballot(c >= (int32_t)glo && is_safe((uint32_t)c));
-                if (mk) { gr = g - (int32_t)__builtin_ctzll(mk); break; }
+                if (mk) return g - (int32_t)__builtin_ctzll(mk);
+            }
+            return -1;
+        };
+        // parts of at most LZ2_CAP_S entries (three workgroups of stage 2 per CU); where no certified cut lies that close — one
+        // cluster of more entries — a part of up to LZ2_CAP entries (k_lz2_find_wide: two per CU)
+        while (n - cur > LZ2_CAP_S) {
+            int32_t gr = cut_below(cur + LZ2_CAP_S);
+            if (gr < (int32_t)glo) {
+                if (n - cur <= LZ2_CAP) break;                                     // the rest is one wide part
+                gr = cut_below(cur + LZ2_CAP);
             }
             if (gr < (int32_t)glo || k + 2 > LZ2_MAXPARTS) { bad = true; break; }     // one cluster larger than stage 2 can hold
             cur = cum_incl((uint32_t)gr);
@@ -207,11 +216,19 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     // blocks x "most parts a block can have" interleaved a third of empty workgroups with the real ones; each still had to
     // be given stage 2's 67 KiB of LDS before it could leave: 14.65 -> 11.4 GB/s.)
     {
-        __shared__ uint32_t s_wbase;
-        if (tid == 0) s_wbase = atomicAdd(sc.work_count, K);
+        __shared__ uint32_t s_wbase, s_wbase2;
+        __shared__ uint8_t s_wrank[LZ2_MAXPARTS];
+        if (tid == 0) {
+            uint32_t ns = 0, nw = 0;
+            for (uint32_t k = 0; k < K; ++k) s_wrank[k] = (uint8_t)(mt->part_count[k] <= LZ2_CAP_S ? ns++ : nw++);
+            s_wbase = atomicAdd(sc.work_count, ns);
+            s_wbase2 = nw ? atomicAdd(sc.work_count + 1, nw) : 0u;
+        }
         __syncthreads();
         if (tid < (int)K) {
-            sc.work[s_wbase + tid] = (uint64_t)lb | ((uint64_t)tid << 16) | ((uint64_t)mt->part_count[tid] << 24) | ((uint64_t)mt->part_start[tid] << 40);
+            const uint64_t item = (uint64_t)lb | ((uint64_t)tid << 16) | ((uint64_t)mt->part_count[tid] << 24) | ((uint64_t)mt->part_start[tid] << 40);
+            if (mt->part_count[tid] <= LZ2_CAP_S) sc.work[s_wbase + s_wrank[tid]] = item;
+            else sc.work[sc.work_slots - 1u - (s_wbase2 + s_wrank[tid])] = item;          // the wide list grows from the end (lz2.h)
         }
     }
 
