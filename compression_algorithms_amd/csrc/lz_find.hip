@@ -583,7 +583,37 @@ void k_lz_emulate_dom(LzP P, LzScratch sc, uint64_t *dbg)
         __syncthreads();
         const uint32_t best = s_votes[0] >= s_votes[1] ? (s_votes[0] >= s_votes[2] ? 0u : 2u) : (s_votes[1] >= s_votes[2] ? 1u : 2u);
         if ((uint64_t)s_votes[best] * 5u < (uint64_t)m * 3u) continue;              // below 60 %: the general replay
-        if (s_votes[best] == m) continue;                                          // one word only: the closed form of k_lz_emulate_giant
+        if (s_votes[best] == m) {
+            // ONE word only: the closed form (k_lz_emulate_giant has the derivation) — here, where two workgroups share a CU and the
+            // clusters come off a cursor, instead of in the 128 KiB kernel behind this one.  anchors: a(0) = first entry,
+            // a(k+1) = first entry more than W positions after a(k); an entry finds its anchor, an anchor finds nothing.
+            uint32_t *s_anch = s_occ;                                              // (<= block / W + 1 anchors)
+            __shared__ uint32_t s_nanch;
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t k = 0, cur = 0;
+                s_anch[0] = 0;
+                for (;;) {
+                    const uint32_t lim = ((uint32_t)(E[a + cur] >> 16) & 0xFFFFu) + W;
+                    uint32_t lo = cur + 1, hi = m;
+                    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (((uint32_t)(E[a + mid] >> 16) & 0xFFFFu) > lim) hi = mid; else lo = mid + 1; }
+                    if (lo >= m) break;
+                    cur = lo; s_anch[++k] = cur;
+                }
+                s_nanch = k + 1;
+            }
+            __syncthreads();
+            const uint32_t na = s_nanch;
+            uint16_t *cand1 = sc.cand + (size_t)lb * LZ_MAX_BLOCK;
+            for (uint32_t i = tid; i < m; i += 256) {
+                uint32_t lo = 0, hi = na - 1;                                       // last anchor <= i
+                while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (s_anch[mid] <= i) lo = mid; else hi = mid - 1; }
+                const uint32_t an = s_anch[lo];
+                if (an != i) cand1[(uint32_t)(E[a + i] >> 16) & 0xFFFFu] = (uint16_t)((uint32_t)(E[a + an] >> 16) & 0xFFFFu);
+            }
+            if (tid == 0) sc.giant_list[2 * g + 1] = a | DOM_DONE;
+            continue;
+        }
         const uint32_t X = cpid[best];
         const uint32_t rX = ((uint32_t)(E[a + cidx[best]] >> 32) & 0xFFFFu) - a;
         uint16_t *cand = sc.cand + (size_t)lb * LZ_MAX_BLOCK;
