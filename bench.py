@@ -46,7 +46,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BLOCK = 65536
-WORKLOADS = ["deflate-h", "deflate", "lz77w16", "lz77w14", "lz77w16-256k", "lz77w16-1m", "huffman", "fse"]
+WORKLOADS = ["deflate-h", "deflate", "lz77w16", "lz77w14", "lz77w16-256k", "lz77w16-1m", "lz77old", "huffman", "fse"]
 
 
 def parse_args():
@@ -77,6 +77,7 @@ DESC = {
     "lz77w14": "lz77 (W=16 KiB, len<=15, bit-packed), independent 64 KiB blocks",
     "lz77w16-256k": "lz77 (W=64 KiB, len<=15, bit-packed), independent 256 KiB blocks: the window slides (time-sliced finder, lzs.hip)",
     "lz77w16-1m": "lz77 (W=64 KiB, len<=15, bit-packed), independent 1 MiB blocks: the window slides (time-sliced finder, lzs.hip)",
+    "lz77old": "lz77_compress_old (lz77.c:185-262): brute-force longest match of the whole 16 KiB window at every token, ONE stream over the buffer",
     "huffman": "whole-buffer Huffman, one tree",
     "fse": "FSE/tANS table_log 8, independent 64 KiB blocks x 64 sub-streams",
 }
@@ -91,6 +92,7 @@ class Codec:
         self.lz, self.huffman, self.fse = lz, huffman, fse
         self.p = {"deflate": lz.params("deflate"), "deflate-h": lz.params("deflate"), "lz77w16": lz.params("lz77", 16),
                   "lz77w14": lz.params("lz77", 14), "lz77w16-256k": lz.params("lz77", 16, 262144), "lz77w16-1m": lz.params("lz77", 16, 1 << 20),
+                  "lz77old": None,
                   "fse": fse.params(), "huffman": None}[workload]
 
     def encode(self, x):
@@ -100,6 +102,8 @@ class Codec:
             return self.lz.compress(x, self.p, self.ctx)
         if self.w == "huffman":
             return self.huffman.huffman_compress(x, self.ctx)
+        if self.w == "lz77old":
+            return self.lz.compress_old(x, 14, 4, self.ctx)
         return self.fse.compress(x, self.p, self.ctx)
 
     def nbytes(self, h):
@@ -112,11 +116,13 @@ class Codec:
             return self.lz.decompress(h, self.ctx)
         if self.w == "huffman":
             return self.huffman.huffman_decompress(h, ctx=self.ctx)
+        if self.w == "lz77old":
+            return self.lz.decompress_whole(h, self.ctx)
         return self.fse.decompress(h, self.ctx)
 
     def stream_and_table(self, h):
         """(uint8 stream tensor, int64 block table in bits) for the gather; None for the whole-buffer Huffman"""
-        if self.w == "huffman":
+        if self.w in ("huffman", "lz77old"):
             return None
         return h.data, (h.block_bits if hasattr(h, "block_bits") else h.offsets)
 
@@ -181,6 +187,15 @@ def cpu_encode(workload, sample):
         extra = {"tokeniser_only_gbs": round(n / max(t_tok, 1e-9) / 1e9, 5),
                  "note": "tokeniser = " + ("the compiled reference" if rd else "oracle port") +
                          "; entropy stage = oracle port (the reference has none)"}
+    elif workload == "lz77old":
+        # O(n * 2^14) by definition (lz77.c:205-241): the sample is small
+        if have_ref:
+            kind = "reference"
+            t0 = time.perf_counter()
+            ref.lz77_compress_old(sample, 14)
+        else:
+            t0 = time.perf_counter()
+            orc.lz77_old_encode(sample, 14, 4)
     elif workload.startswith("lz77w"):
         wb = 14 if workload == "lz77w14" else 16
         blk = {"lz77w16-256k": 262144, "lz77w16-1m": 1 << 20}.get(workload, BLOCK)
@@ -311,7 +326,7 @@ class CpuPool:
 
 
 # single-core CPU rates (GB/s) used only to size the samples so that each leg takes ~2-3 s
-CPU_RATE = {"deflate": 0.045, "deflate-h": 0.029, "lz77w16": 0.012, "lz77w14": 0.014, "lz77w16-256k": 0.012, "lz77w16-1m": 0.012,
+CPU_RATE = {"lz77old": 0.0004, "deflate": 0.045, "deflate-h": 0.029, "lz77w16": 0.012, "lz77w14": 0.014, "lz77w16-256k": 0.012, "lz77w16-1m": 0.012,
             "huffman": 0.23, "fse": 0.04}
 
 
@@ -562,7 +577,7 @@ def main():
                                  ("config2_lz77_w14_1e8", "lz77w14", 100_000_000),
                                  ("config2_lz77_w16_256KiB_blocks_1e8", "lz77w16-256k", 100_000_000),
                                  ("config2_lz77_w16_1MiB_blocks_1e8", "lz77w16-1m", 100_000_000),
-                                 ("config3_fse_1e9", "fse", 1_000_000_000)):
+                                 ("config3_fse_1e9", "fse", 1_000_000_000), ("lz77_compress_old_w14_2e7", "lz77old", 20_000_000)):
                 try:
                     others[key] = measure(ctx, wl, x[:nb_], max(args.steps, 5), 1, pool, cpu_on)
                 except Exception as e:
