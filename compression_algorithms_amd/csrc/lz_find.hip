@@ -177,6 +177,9 @@ void k_lz_sort_home(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, LzS
                     const uint32_t *__restrict__ blist, const uint32_t *__restrict__ bcount)
 {
     const uint32_t count = bcount ? *bcount : nb;          // only the listed blocks when there is a list
+    // how many blocks fell back, left where the host sees it (pinned word behind the order flag): the NEXT batch sizes its
+    // fallback grids by it — no synchronisation, a hint that is one batch old
+    if (bcount && blockIdx.x == 0 && threadIdx.x == 0 && P.order_flag) P.order_flag[1] = count;
     for (uint32_t bi = blockIdx.x; bi < count; bi += gridDim.x) {
         lz_sort_home_block(in, n_total, P, sc, block0, blist ? blist[bi] : bi);
         __syncthreads();
@@ -370,6 +373,22 @@ __device__ __forceinline__ void lz_emulate_tile(LzP P, LzScratch sc, uint32_t lb
             continue;
         }
         const bool first = (a + s) == 0;
+        // a cluster of ONE word (most of them): find() only ever looks at the home slot, whose occupant — the anchor — is the
+        // first entry, then the first entry after anchor + W, which itself finds the slot empty: one pass over
+        // the positions, no table.  Not for the cluster that covers bucket 0 / T.
+        if (!(first && (mt.anom_idx != ~0u || mt.limit_idx != ~0u))) {
+            const uint32_t id0 = s_pid[s];
+            bool one = true;
+            for (uint32_t i = s + 1; i < e && one; ++i) one = s_pid[i] == id0;
+            if (one) {
+                uint32_t an = s_pos[s];
+                for (uint32_t i = s + 1; i < e; ++i) {
+                    const uint32_t p = s_pos[i];
+                    if (an + W < p) an = p; else cand[p] = (uint16_t)an;
+                }
+                continue;
+            }
+        }
         replay_cluster(v, s, e, W, first ? mt.anom_idx : ~0u, first ? mt.limit_idx : ~0u, cand);
     }
 }
@@ -949,7 +968,11 @@ mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t
     static const bool prof_fb = getenv("MI_LZ_PROF_FALLBACK") != nullptr;      // inputs that live in the fallback (scripts/adv_profile.py)
     if (blist && !prof_fb) ctx->profiling = 0;
     MI_HIP(ctx, hipMemsetAsync(sc.giant_count, 0, 8, s));        // [0] clusters listed, [1] cursor of k_lz_emulate_dom
-    const uint32_t fgrid = (blist && nb > LZ_FB_GRID) ? LZ_FB_GRID : nb;     // fallback: few looping workgroups (see LZ_FB_GRID)
+    // fallback: few looping workgroups (see LZ_FB_GRID) — unless the previous batch had many blocks here (non-text input): the
+    // count k_lz_sort_home left in pinned memory sizes the grids (pages family: half the chip sat idle behind 128 workgroups)
+    const uint32_t hint = (blist && ctx->h_order) ? __atomic_load_n(ctx->h_order + 1, __ATOMIC_RELAXED) : 0u;
+    const uint32_t fb_want = hint > LZ_FB_GRID ? hint : LZ_FB_GRID;
+    const uint32_t fgrid = (blist && nb > fb_want) ? fb_want : nb;
     {
         mi_prof_scope p(ctx, "k_lz_sort_home", s, (uint64_t)nb * P.block);
         hipLaunchKernelGGL(k_lz_sort_home, dim3(fgrid), dim3(1024), 0, s, d_in, n, P, sc, block0, nb, blist, bcount);
@@ -971,7 +994,8 @@ mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t
     }
     {
         mi_prof_scope p(ctx, "k_lz_emulate_giant", s, (uint64_t)nb * P.block);
-        const uint32_t grid = blist ? (nb < LZ_FB_GRID ? nb : LZ_FB_GRID) : (nb < 1024 ? nb : 1024);
+        const uint32_t cap = blist ? (hint > LZ_FB_GRID ? 512u : LZ_FB_GRID) : 1024u;
+        const uint32_t grid = nb < cap ? nb : cap;
         hipLaunchKernelGGL(k_lz_emulate_giant, dim3(grid), dim3(256), 0, s, P, sc);
     }
     ctx->profiling = saved_prof;
