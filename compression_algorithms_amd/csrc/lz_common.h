@@ -20,7 +20,7 @@
 #define LZ_GIANT_MIN   (LZ_TILE_CAP - LZ_TILE_NOM)   // a cluster larger than this is replayed by k_lz_emulate_giant
 #define LZ_GIANT_CAP   18432u         // LDS capacity of the giant kernel; above: global-memory path
 #define LZ_MAX_TILES   (LZ_MAX_BLOCK / LZ_TILE_NOM)
-#define LZ_WAVE_MIN    512u           // fallback pipeline: clusters from this size on are replayed by a wave, not a lane
+#define LZ_WAVE_MIN    128u           // fallback pipeline: clusters from this size on are replayed by a wave, not a lane
 #define LZ_MAX_GIANTS_PER_BLOCK (LZ_MAX_BLOCK / LZ_WAVE_MIN + 32u)
 
 struct LzP {

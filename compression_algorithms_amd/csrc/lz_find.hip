@@ -684,7 +684,7 @@ void k_lz_emulate_dom(LzP P, LzScratch sc, uint64_t *dbg)
                 // 64 copies of X in a row, nothing to retire before the last of them, 64 free slots in a row: they take them in
                 // order and all find the same thing — one wave-wide step instead of 64 serial ones (every run in the first W
                 // positions of a block, where nothing retires at all)
-                if (lim == 64u && nx + 64u <= lf && __ballot(c_pid == X) == ~0ull && !(ev < i0 && pe + W < RLANE(c_pos, 63))
+                if (lim == 64u && nx + 64u <= lf && __ballot(c_pid == X) == ~0ull && !(ev < i0 + 63u && pe + W < RLANE(c_pos, 63))
                     && i0 + 64u - ev <= W) {
                     const uint32_t b = nx + lane;
                     uint32_t res = LZ_NONE16;
