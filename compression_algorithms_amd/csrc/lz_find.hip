@@ -638,7 +638,7 @@ void k_lz_emulate_dom(LzP P, LzScratch sc, uint64_t *dbg)
         uint16_t *cand = sc.cand + (size_t)lb * LZ_MAX_BLOCK;
         uint32_t done_upto = m;                                                     // entries whose results were written
         if (dbg && tid == 0) { atomicAdd((unsigned long long *)&dbg[50], 1ull); atomicAdd((unsigned long long *)&dbg[51], (unsigned long long)m); atomicAdd((unsigned long long *)&dbg[52], (unsigned long long)(clock64() - tk0)); tk0 = clock64(); }
-        uint32_t n_fast = 0, n_scan = 0, n_fgn = 0, n_bulk = 0;
+        uint32_t n_fast = 0, n_scan = 0, n_fgn = 0, n_bulk = 0, n_bulk1 = 0, n_ret = 0;
         if (tid < 64) {
             uint32_t ev = 0, f_ev = 0, f_n = 0, anchor_pos = 0, stash = 0, stash_of = ~0u;
             bool anchor_ok = false, bailed = false;
@@ -748,36 +748,85 @@ void k_lz_emulate_dom(LzP P, LzScratch sc, uint64_t *dbg)
                         const bool alias = (i - ev - 1u) == W;                      // the ring is full: entry i + u takes the place of entry ev + u + 1
                         uint32_t su = in ? (uint32_t)((const volatile uint16_t *)s_ring)[(ev + u) & (W - 1u)] : 0u;
                         if (alias && lane == t) su = stash;
-                        const bool ok = in && c_pid == X && c_pos == p + u && rid == X && rp == pe + u && su < nx && su >= rX;
+                        // two regimes: the retired slot lies BELOW the first free one (the new copy takes it) or ABOVE the free run
+                        // (occupied, so not inside it: the new copy takes the free run's next slot) — a stretch is one or the other
+                        const bool below = RLANE(su, t) < nx;
+                        const uint32_t room = lf - nx;
+                        const bool ok = in && c_pid == X && c_pos == p + u && rid == X && rp == pe + u && su >= rX &&
+                                        (below ? su < nx : (su >= nx && u < room));
                         const uint64_t okm = __ballot(ok) >> t;
                         const uint32_t k = (~okm) ? (uint32_t)__builtin_ctzll(~okm) : 64u;
                         if (k >= 2u && (!alias || stash_of == ev)) {
                             uint32_t new_stash = 0;
                             if (alias) new_stash = (uint32_t)__builtin_amdgcn_readfirstlane((int)((const volatile uint16_t *)s_ring)[(ev + k) & (W - 1u)]);
                             const bool mine = lane >= t && u < k;
-                            const uint64_t hit = __ballot(mine && su == rX);
-                            const uint32_t ts = hit ? (uint32_t)__builtin_ctzll(hit) : 64u;     // the entry that retires the anchor and takes its place
-                            if (mine) {
+                            if (below) {
+                                const uint64_t hit = __ballot(mine && su == rX);
+                                const uint32_t ts = hit ? (uint32_t)__builtin_ctzll(hit) : 64u;     // the entry that retires the anchor and takes its place
+                                if (mine) {
+                                    uint32_t res = LZ_NONE16;
+                                    if (lane < ts) { if (anchor_ok) res = anchor_pos; }
+                                    else if (lane > ts) res = p + (ts - t);
+                                    if (c_pid == c_pos) res = LZ_NONE16;                // (a word's first occurrence finds nothing, ever)
+                                    ((volatile uint16_t *)s_ring)[(i0 + lane) & (W - 1u)] = (uint16_t)su;
+                                    out_acc = res;
+                                }
+                                if (hit) { anchor_ok = true; anchor_pos = p + (ts - t); }
+                            } else {
                                 uint32_t res = LZ_NONE16;
-                                if (lane < ts) { if (anchor_ok) res = anchor_pos; }
-                                else if (lane > ts) res = p + (ts - t);
-                                if (c_pid == c_pos) res = LZ_NONE16;                // (a word's first occurrence finds nothing, ever)
-                                ((volatile uint16_t *)s_ring)[(i0 + lane) & (W - 1u)] = (uint16_t)su;
-                                out_acc = res;
+                                if (c_pid != c_pos && anchor_ok) res = anchor_pos;
+                                if (nx == rX) {                                     // the first of them takes X's (free) home
+                                    if (!anchor_ok && u > 0 && c_pid != c_pos) res = p;
+                                    anchor_ok = true; anchor_pos = p;
+                                }
+                                const uint32_t b = nx + u;
+                                uint32_t *const wc = s_occ + (mine ? su >> 5 : 0u), *const ws = s_occ + (mine ? b >> 5 : 0u);
+                                __hip_atomic_fetch_and(wc, mine ? ~(1u << (su & 31u)) : 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                __hip_atomic_fetch_or(ws, mine ? 1u << (b & 31u) : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if (mine) {
+                                    ((volatile uint16_t *)s_ring)[(i0 + lane) & (W - 1u)] = (uint16_t)b;
+                                    out_acc = res;
+                                }
+                                nx += k;
                             }
-                            if (hit) { anchor_ok = true; anchor_pos = p + (ts - t); }
                             if (alias) { stash = new_stash; stash_of = ev + k; }
+                            n_bulk1 += k;
                             ev += k;
                             if ((ev & 63u) == 0) { const uint32_t q = ev + lane; const uint64_t x = q < m ? E[a + q] : 0ull; e_pos = (uint32_t)(x >> 16) & 0xFFFFu; e_pid = (uint32_t)(x >> 48); }
                             pe = RLANE(e_pos, ev & 63u);
                             n_fast += k; n_bulk += k; t += k;
                             __builtin_amdgcn_wave_barrier();
+                            if (nx >= lf) refill();                                 // (here, not inside the branch above: the backend trips over it there)
                             continue;
+                        }
+                    }
+                    // catch-up after a gap (the window's far edge ran through a whole old run while the cluster had no entry): up to 64
+                    // retirements in one step — their slots' bits cleared by the lanes, then ONE scan for the first free slot
+                    if (ev + 4u <= i && pe + W < p) {
+                        const uint32_t eoff = ev & 63u, u = lane;
+                        const uint32_t rl = (eoff + u) & 63u;
+                        const uint32_t rp = (uint32_t)__shfl((int)e_pos, (int)rl), rid = (uint32_t)__shfl((int)e_pid, (int)rl);
+                        const bool ok = u < 64u - eoff && ev + u < i && rp + W < p;
+                        const uint64_t okm = __ballot(ok);
+                        const uint32_t kr = (~okm) ? (uint32_t)__builtin_ctzll(~okm) : 64u;      // positions ascend: a prefix
+                        if (kr >= 4u) {
+                            const bool mine = u < kr;
+                            uint32_t su = mine ? (uint32_t)((const volatile uint16_t *)s_ring)[(ev + u) & (W - 1u)] : 0u;
+                            if (u == 0 && ev == stash_of) su = stash;
+                            if (mine) atomicAnd(&s_occ[su >> 5], ~(1u << (su & 31u)));
+                            f_ev += (uint32_t)__popcll(__ballot(mine && rid != X));
+                            if (__ballot(mine && rid == X && su == rX)) anchor_ok = false;
+                            if (__ballot(mine && su >= rX)) { sv = false; nx = dom_first_zero(s_occ, rX, lane); lf = first_one(nx + 1u); ++n_scan; }
+                            ev += kr; n_ret += kr;
+                            if ((ev & 63u) == 0) { const uint32_t q = ev + lane; const uint64_t x = q < m ? E[a + q] : 0ull; e_pos = (uint32_t)(x >> 16) & 0xFFFFu; e_pid = (uint32_t)(x >> 48); }
+                            pe = RLANE(e_pos, ev & 63u);
+                            __builtin_amdgcn_wave_barrier();
+                            continue;                                               // (the same entry again: more to retire, or its turn)
                         }
                     }
                     while (ev < i && pe + W < p) {                                  // FIFO retirement (lz77.c:70-76): clears the bucket
                         const uint32_t sl = ev == stash_of ? stash : (uint32_t)__builtin_amdgcn_readfirstlane((int)((const volatile uint16_t *)s_ring)[ev & (W - 1u)]);
-                        bit_clear(sl);
+                        bit_clear(sl); ++n_ret;
                         if (RLANE(e_pid, ev & 63u) != X) ++f_ev;                    // foreign entries leave their FIFO in order
                         else if (sl == rX) anchor_ok = false;
                         if (sl >= rX) {
@@ -853,7 +902,8 @@ void k_lz_emulate_dom(LzP P, LzScratch sc, uint64_t *dbg)
             if (dbg && lane == 0) { atomicAdd((unsigned long long *)&dbg[53], (unsigned long long)(clock64() - tk0)); atomicAdd((unsigned long long *)&dbg[54], (unsigned long long)n_fast);
                                     atomicAdd((unsigned long long *)&dbg[55], (unsigned long long)n_scan); atomicAdd((unsigned long long *)&dbg[56], (unsigned long long)n_fgn);
                                     if (bailed) atomicAdd((unsigned long long *)&dbg[57], 1ull);
-                                    atomicAdd((unsigned long long *)&dbg[61], (unsigned long long)n_bulk); }
+                                    atomicAdd((unsigned long long *)&dbg[61], (unsigned long long)n_bulk);
+                                    atomicAdd((unsigned long long *)&dbg[62], (unsigned long long)n_bulk1); atomicAdd((unsigned long long *)&dbg[63], (unsigned long long)n_ret); }
         }
         __syncthreads();
         const uint32_t rs_ = s_result;
