@@ -597,7 +597,12 @@ def main():
                     xa = torch.from_numpy(gen()).to(dev).repeat(reps)[:100_000_000].contiguous()
                     r = measure(ctx, args.workload, xa, 2, 1, None, False)
                     adv[kind] = {k_: r[k_] for k_ in ("value", "unit", "ms_per_step", "ratio", "roundtrip", "input_bytes")}
-                    del xa
+                    # the same family at the headline's size (15 259 blocks: five batches in the three-stage pipeline, the fallback
+                    # grids sized by the batch before; 10^8 bytes are two batches, the first of them on the small fallback grid)
+                    xb = xa.repeat(10)
+                    rb = measure(ctx, args.workload, xb, 2, 1, None, False)
+                    adv[kind]["at_1e9_bytes"] = {k_: rb[k_] for k_ in ("value", "ms_per_step", "roundtrip", "input_bytes")}
+                    del xa, xb
                 except Exception as e:
                     adv[kind] = {"value": None, "error": repr(e)[:200]}
             extras["adversarial"] = adv
