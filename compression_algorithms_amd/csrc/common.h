@@ -26,6 +26,9 @@ struct mi_ctx {
     hipStream_t stream = nullptr;       // the context's own stream (host-buffer entry points; created on first use: mi_host_stream)
     hipStream_t side = nullptr;         // second stream: overlaps the replay/parse of batch i with the find of batch i+1
     hipStream_t fb = nullptr;           // low priority: the (normally empty) fallback chain must not hold LDS-hungry launches in front of real work
+    hipStream_t fb2 = nullptr;          // a second one, created only while an encode call finds the input living in the fallback (lz_emit.hip): the
+                                        // chains of consecutive batches then run side by side.  NOT kept: one more stream in the process — even
+                                        // idle, whatever the creation order or GPU_MAX_HW_QUEUES — cost the text pipeline 7 % (20.4 -> 19.1 GB/s)
     hipStream_t parse = nullptr;        // third stage: parse / emit / concatenate
 #define MI_SETS 3
     hipEvent_t  ev_find[MI_SETS] = {}, ev_done[MI_SETS] = {}, ev_part[MI_SETS] = {}, ev_fb[MI_SETS] = {}, ev_replay[MI_SETS] = {};

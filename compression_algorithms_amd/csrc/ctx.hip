@@ -125,6 +125,7 @@ void mi_ctx_destroy(mi_ctx *c)
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->side) hipStreamDestroy(c->side);
     if (c->fb) hipStreamDestroy(c->fb);
+    if (c->fb2) hipStreamDestroy(c->fb2);
     if (c->parse) hipStreamDestroy(c->parse);
     for (int i = 0; i < MI_SETS; ++i) {
         if (c->ev_replay[i]) hipEventDestroy(c->ev_replay[i]);
