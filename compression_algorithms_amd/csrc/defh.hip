@@ -110,27 +110,25 @@ __device__ __forceinline__ void defh_canonical(const uint8_t *s_len, uint32_t *s
     __syncthreads();
 }
 
-__global__ __launch_bounds__(DEFH_THREADS)
-void k_defh_encode(const uint32_t *__restrict__ trec_all, uint32_t *__restrict__ slots, uint64_t *__restrict__ block_bits)
+// Two kernels since round 3.  The code LENGTHS wait ~1.4 M cycles per block behind one lane (the reference heap): that kernel is
+// ONE wave per block with 8 KiB of LDS — twenty blocks in flight per CU where the fused kernel (256 threads, the pack stage's
+// 5.6 KiB window) held eight.  It leaves the lengths in the record's header and the canonical codes behind the tally in the
+// block's slot; the pack kernel reads both.
+#define DEFH_CODE_AT (LZ_DEFH_HIST_AT + 288u)          // slot words [.., +288): the canonical codes, from k_defh_lengths to k_defh_pack
+static_assert(DEFH_CODE_AT + 288u <= LZ_SLOT_WORDS, "tally and codes live behind the record in the slot");
+
+__global__ __launch_bounds__(64)
+void k_defh_lengths(uint32_t *__restrict__ slots)
 {
     __shared__ DefhHeap h;
     __shared__ uint32_t s_hist[DEFH_NSYM + 2], s_code[DEFH_NSYM + 2];
-    __shared__ uint8_t  s_len[DEFH_NSYM + 2];
+    __shared__ __attribute__((aligned(16))) uint8_t s_len[DEFH_NSYM + 2];
     __shared__ uint32_t s_count[34], s_next[34];
-    __shared__ uint32_t s_scan[DEFH_THREADS / 64 + 2];
-    __shared__ uint32_t s_stage[DEFH_THREADS * DEFH_PER * DEFH_MAXBITS / 32 + 8];
-
     const int tid = threadIdx.x;
-    const uint32_t lb = blockIdx.x;
-    const uint32_t ntok = (uint32_t)block_bits[lb];                   // k_lz_parse_emit (mode H) left the token count here
-    const uint32_t *trec = trec_all + (size_t)lb * LZ_MAX_BLOCK;
-    uint32_t *out = slots + (size_t)lb * LZ_SLOT_WORDS;
-    auto symbol_of = [](uint32_t r) -> uint32_t { return (r >> 31) ? 256u + clz16(r) : (r & 0xFFu); };
-
+    uint32_t *out = slots + (size_t)blockIdx.x * LZ_SLOT_WORDS;
     // ---- tally (lz77.c:206,231,273): taken by k_lz_parse_emit while it wrote the token records, left at the end of the slot
-    for (int i = tid; i < DEFH_NSYM + 2; i += DEFH_THREADS) { s_hist[i] = out[LZ_DEFH_HIST_AT + i]; s_len[i] = 0; }
+    for (int i = tid; i < DEFH_NSYM + 2; i += 64) { s_hist[i] = out[LZ_DEFH_HIST_AT + i]; s_len[i] = 0; }
     __syncthreads();
-
     // ---- code lengths: the reference heap, leaves enqueued in symbol order (one lane; <= 285 merges)
     if (tid == 0) {
         h.nheap = 0; h.nnodes = 0; h.root = -1;
@@ -155,7 +153,7 @@ void k_defh_encode(const uint32_t *__restrict__ trec_all, uint32_t *__restrict__
         }
     }
     __syncthreads();
-    for (int sy = tid; sy < DEFH_NSYM; sy += DEFH_THREADS) {
+    for (int sy = tid; sy < DEFH_NSYM; sy += 64) {
         if (!s_hist[sy]) continue;
         uint32_t len = 0;
         if (h.nnodes == 1) len = 1;
@@ -164,10 +162,32 @@ void k_defh_encode(const uint32_t *__restrict__ trec_all, uint32_t *__restrict__
     }
     __syncthreads();
     defh_canonical(s_len, s_code, s_count, s_next);
+    for (int i = tid; i < (DEFH_NSYM + 2) / 4; i += 64) out[1 + i] = reinterpret_cast<const uint32_t *>(s_len)[i];     // the record's header
+    for (int i = tid; i < DEFH_NSYM + 2; i += 64) out[DEFH_CODE_AT + i] = s_code[i];
+}
+
+__global__ __launch_bounds__(DEFH_THREADS)
+void k_defh_encode(const uint32_t *__restrict__ trec_all, uint32_t *__restrict__ slots, uint64_t *__restrict__ block_bits)
+{
+    __shared__ uint32_t s_code[DEFH_NSYM + 2];
+    __shared__ __attribute__((aligned(16))) uint8_t s_len[DEFH_NSYM + 2];
+    __shared__ uint32_t s_scan[DEFH_THREADS / 64 + 2];
+    __shared__ uint32_t s_stage[DEFH_THREADS * DEFH_PER * DEFH_MAXBITS / 32 + 8];
+
+    const int tid = threadIdx.x;
+    const uint32_t lb = blockIdx.x;
+    const uint32_t ntok = (uint32_t)block_bits[lb];                   // k_lz_parse_emit (mode H) left the token count here
+    const uint32_t *trec = trec_all + (size_t)lb * LZ_MAX_BLOCK;
+    uint32_t *out = slots + (size_t)lb * LZ_SLOT_WORDS;
+    auto symbol_of = [](uint32_t r) -> uint32_t { return (r >> 31) ? 256u + clz16(r) : (r & 0xFFu); };
+
+    // ---- lengths and codes: k_defh_lengths left them in the header and behind the tally
+    for (int i = tid; i < DEFH_NSYM + 2; i += DEFH_THREADS) s_code[i] = out[DEFH_CODE_AT + i];
+    for (int i = tid; i < (DEFH_NSYM + 2) / 4; i += DEFH_THREADS) reinterpret_cast<uint32_t *>(s_len)[i] = out[1 + i];
+    __syncthreads();
 
     // ---- header
     if (tid == 0) out[0] = ntok;
-    for (int i = tid; i < (DEFH_NSYM + 2) / 4; i += DEFH_THREADS) out[1 + i] = reinterpret_cast<const uint32_t *>(s_len)[i];
     uint32_t *words = out + DEFH_HDR / 4;
 
     // ---- pack, DEFH_THREADS * DEFH_PER tokens per round; a thread owns DEFH_PER consecutive tokens
@@ -225,6 +245,7 @@ void k_defh_encode(const uint32_t *__restrict__ trec_all, uint32_t *__restrict__
 
 void defh_launch_encode(const uint32_t *trec, uint32_t *slots, uint64_t *block_bits, uint32_t nb, hipStream_t s)
 {
+    hipLaunchKernelGGL(k_defh_lengths, dim3(nb), dim3(64), 0, s, slots);
     hipLaunchKernelGGL(k_defh_encode, dim3(nb), dim3(DEFH_THREADS), 0, s, trec, slots, block_bits);
 }
 
