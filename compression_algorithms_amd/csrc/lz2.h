@@ -44,7 +44,8 @@ static_assert(LZ2_CAP % LZ2_THREADS == 0 && LZ2_CAP_S % LZ2_THREADS == 0 && LZ2_
 __host__ __device__ __forceinline__ uint32_t lz2_class_of(uint32_t cnt, uint32_t wave_min)
 {
     // wave replay: 4 = 512..1024 entries and 5 = wave_min..511 share one launch that starts the long chains first
-    if (cnt >= wave_min) return cnt > LZ2_BIG_SMALL ? 6u : cnt >= 512u ? 4u : 5u;
+    // (three wave-replay classes by LDS need: 3 = 128..255 entries (1.5 KiB per wave), 5 = 256..511 (3 KiB), 4 = 512..1024 (6 KiB))
+    if (cnt >= wave_min) return cnt > LZ2_BIG_SMALL ? 6u : cnt >= 512u ? 4u : 5u;      // (class 3 — 128..255 on 1.5 KiB — was measured: slower)
     return cnt < 16 ? 7u : cnt < 32 ? 0u : cnt < 64 ? 1u : cnt < 128 ? 2u : cnt < 256 ? 3u : 4u;
 }
 // cand placeholder of an entry whose cluster was exported: the entry's OWN position (a candidate is always smaller

@@ -690,10 +690,12 @@ void k_lz2_big(LzP P, Lz2Scratch sc, int large)
     __shared__ uint16_t s_slot[LDS_ENTRIES];              // entry -> slot (for its eviction)
     const uint32_t lane = threadIdx.x;
     // a launch lasts as long as its longest cluster: the 512..1024-entry class is dispatched before the 128..511 one
-    const uint32_t nhi = large ? sc.big_count[6] : sc.big_count[4], ncl = nhi + (large ? 0u : sc.big_count[5]);
+    // large: 0 = classes 4 (512..1024 entries) and 5 (128..511) in one launch, 1 = class 6, 2 = class 5 alone, 3 = class 4 alone
+    const uint32_t nhi = large == 1 ? sc.big_count[6] : (large == 2 || large == 4) ? 0u : sc.big_count[4],
+                   ncl = nhi + ((large == 0 || large == 2) ? sc.big_count[5] : large == 4 ? sc.big_count[3] : 0u);
     const uint32_t W = 1u << P.wbits;
     for (uint32_t ci = blockIdx.x; ci < ncl; ci += gridDim.x) {
-        const Lz2BigDesc *dp = large ? &sc.desc[6][ci] : (ci < nhi ? &sc.desc[4][ci] : &sc.desc[5][ci - nhi]);
+        const Lz2BigDesc *dp = large == 1 ? &sc.desc[6][ci] : large == 4 ? &sc.desc[3][ci] : (ci < nhi ? &sc.desc[4][ci] : &sc.desc[5][ci - nhi]);
         const uint32_t d_block = dp->block, d_start = dp->start, n = dp->count;
         const uint32_t d_anom = dp->anom, d_limit = dp->limit;
         const uint16_t *bp = sc.bigpos + (size_t)d_block * LZ2_BIG_STRIDE + d_start;
@@ -835,6 +837,8 @@ template __global__ void k_lz2_mid_direct<32, 64>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_mid_direct<64, 64>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_mid_direct<128, 48>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_big<LZ2_BIG_SMALL, 1>(LzP, Lz2Scratch, int);
+template __global__ void k_lz2_big<512, 1>(LzP, Lz2Scratch, int);
+template __global__ void k_lz2_big<256, 1>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_big<LZ2_CAP, 4>(LzP, Lz2Scratch, int);
 
 
@@ -948,7 +952,15 @@ mi_status lz2_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &
       hipLaunchKernelGGL((k_lz2_mid_direct<128, 48>), dim3(grid_of((uint64_t)nb * lz2_class_cap(2) / 48 + 1)), dim3(64), 0, s, P, sc, 2); }
     { mi_prof_scope p(ctx, "k_lz2_big", s, (uint64_t)nb * P.block);
       // the kernel strides over the two wave classes (long chains first); 6 KiB per wave
-      hipLaunchKernelGGL((k_lz2_big<LZ2_BIG_SMALL, 1>), dim3(grid_of((uint64_t)nb * (lz2_class_cap(4) + lz2_class_cap(5)))), dim3(64), 0, s, P, sc, 0); }
+      // the 512..1024-entry class first and alone (6 KiB of LDS per wave), then the 128..511 class on 3 KiB: twice as many of its
+      // waves fit into what the LDS-filling kernels of the other stages leave on a CU (MI_LZ_BIG_SPLIT=0: one launch, A/B)
+      static const bool split = !(getenv("MI_LZ_BIG_SPLIT") && getenv("MI_LZ_BIG_SPLIT")[0] == '0');
+      if (split && sc.wave_min == LZ2_WAVE) {
+          hipLaunchKernelGGL((k_lz2_big<LZ2_BIG_SMALL, 1>), dim3(grid_of((uint64_t)nb * lz2_class_cap(4))), dim3(64), 0, s, P, sc, 3);
+          hipLaunchKernelGGL((k_lz2_big<512, 1>), dim3(grid_of((uint64_t)nb * lz2_class_cap(5))), dim3(64), 0, s, P, sc, 2);
+      } else {
+          hipLaunchKernelGGL((k_lz2_big<LZ2_BIG_SMALL, 1>), dim3(grid_of((uint64_t)nb * (lz2_class_cap(4) + lz2_class_cap(5)))), dim3(64), 0, s, P, sc, 0);
+      } }
     { mi_prof_scope p(ctx, "k_lz2_big<4096>", s, (uint64_t)nb * P.block);
       hipLaunchKernelGGL((k_lz2_big<LZ2_CAP, 4>), dim3(grid_of((uint64_t)nb * lz2_class_cap(6) < 4096 ? (uint64_t)nb * lz2_class_cap(6) : 4096)), dim3(64), 0, s, P, sc, 1); }   // 24 KiB each, normally none: a small striding grid
     MI_HIP(ctx, hipGetLastError());
