@@ -918,12 +918,18 @@ mi_status lz2_stage_partition(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, ui
 mi_status lz2_stage_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
                          const Lz2Scratch &sc, hipStream_t s)
 {
-    mi_prof_scope p(ctx, "k_lz2_find", s, (uint64_t)nb * P.block);
-    // the partition cuts at most LZ2_MAXPARTS parts per block (greedy, data dependent: ~19 for a full block) and lists them
+    // the partition cuts at most LZ2_MAXPARTS parts per block (greedy, data dependent: ~26 for a full block) and lists them
     const uint32_t parts = P.block / 64u + 1u < LZ2_MAXPARTS ? P.block / 64u + 1u : LZ2_MAXPARTS;
-    hipLaunchKernelGGL(k_lz2_find, dim3(parts * nb), dim3(LZ2_THREADS), 0, s, d_in, n, P, sc, block0);
-    // parts of 2561..4096 entries (none in text): 256 looping workgroups, gone at once when the list is empty
-    hipLaunchKernelGGL(k_lz2_find_wide, dim3(256), dim3(LZ2_THREADS), 0, s, d_in, n, P, sc, block0);
+    {
+        mi_prof_scope p(ctx, "k_lz2_find", s, (uint64_t)nb * P.block);
+        hipLaunchKernelGGL(k_lz2_find, dim3(parts * nb), dim3(LZ2_THREADS), 0, s, d_in, n, P, sc, block0);
+    }
+    {
+        // parts of 2561..4096 entries (none in text): 256 looping workgroups, gone at once when the list is empty (timed apart: an
+        // empty launch still waits for 76 KiB of LDS behind the kernel above)
+        mi_prof_scope p(ctx, "k_lz2_find_wide", s, (uint64_t)nb * P.block);
+        hipLaunchKernelGGL(k_lz2_find_wide, dim3(256), dim3(LZ2_THREADS), 0, s, d_in, n, P, sc, block0);
+    }
     MI_HIP(ctx, hipGetLastError());
     return MI_OK;
 }
