@@ -1,14 +1,16 @@
 // lz2_find.hip — stage 2 and 3 of the LDS-resident match finder.
 //
-//   k_lz2_find        one workgroup per part (<= LZ2_CAP positions whose clusters lie inside the part, certified by
-//                     stage 1).  Everything happens in LDS: words gathered once (mixed: home = mask, equality =
-//                     equality), positions sorted by home (2-3 stable 8-bit radix passes), clusters / dense home
-//                     slots / word ids from the parking sweep, a second sort by (cluster, time).  Then
+//   k_lz2_find        one workgroup per part (<= LZ2_CAP_S = 2560 positions whose clusters lie inside the part, certified by
+//                     stage 1; 51 KiB of LDS, three per CU.  k_lz2_find_wide: the same body for the rare parts of up to
+//                     LZ2_CAP = 4096).  Everything happens in LDS: mixed words (home = mask, equality = equality), positions
+//                     sorted by home (2-3 stable 8-bit radix passes), clusters / dense home slots / word ids / "mixed"
+//                     bits from the parking sweep, (cluster, time) order by cursor placement.  Then
+//                       - a cluster of ONE word is answered by a closed form (anchor chain): most clusters;
 //                       - while a cluster has retired nothing, find() is the first occurrence of the word = the word
 //                         id: quiet clusters are answered without any replay, and lz77 with a window
 //                         that covers the block stops right after the sweep;
-//                       - clusters of 2..7 entries are replayed one lane each, their table in two registers;
-//                       - larger ones are exported on 16-byte boundaries, by size class.
+//                       - mixed clusters of 2..7 entries are replayed one lane each, their table in two registers;
+//                       - larger mixed ones are exported on 16-byte boundaries, by size class.
 //   k_lz2_mid_direct  lane per exported cluster of 8..127 entries (64 clusters per wave, LDS regions per lane),
 //                     eight entries per load.
 //   k_lz2_big         one WAVE per exported cluster of >= 128 entries: occupancy bitmap in registers, first fit by
@@ -914,7 +916,7 @@ mi_status lz2_stage_partition(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, ui
     return MI_OK;
 }
 
-// stage A2: per-part find (LDS heavy: two workgroups per CU)
+// stage A2: per-part find (LDS heavy: three workgroups per CU)
 mi_status lz2_stage_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
                          const Lz2Scratch &sc, hipStream_t s)
 {

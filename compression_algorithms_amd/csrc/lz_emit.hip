@@ -582,9 +582,9 @@ static mi_status lz_encode_impl(mi_ctx *ctx, const mi_lz_params *p, const uint8_
     }
     const uint32_t nbmax = lz_batch_blocks(nblocks);
     // three stages on three streams, MI_SETS scratch sets in rotation:
-    //   `s`          partition + find of batch i+2          (LDS heavy, two workgroups per CU)
+    //   `s`          partition + find of batch i+2          (LDS heavy: one / three workgroups per CU)
     //   ctx->side    replay of the exported clusters of i+1 (almost no LDS: runs beside the find)
-    //   ctx->parse   parse / emit / concatenate of batch i  (one 150 KiB workgroup per CU)
+    //   ctx->parse   parse / emit / concatenate of batch i  (one 150 KiB workgroup per CU; the stream has raised priority)
     // plus ctx->fb for the normally empty fallback chain.  Fork/join with events only: no host synchronisation.
     const bool overlap = nblocks > nbmax && !getenv("MI_LZ_NO_OVERLAP");
     const int nsets = overlap ? MI_SETS : 1;
