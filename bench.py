@@ -405,12 +405,14 @@ def roofline_of(workload, n, c, ktimes, steps, dt):
             "all_kernels_ms_per_step": {k["name"]: round(k["ms"] * k["launches"] / steps, 3) for k in ktimes}}
 
 
-def measure(ctx, workload, x, steps, warmup, pool=None, cpu=True):
+def measure(ctx, workload, x, steps, warmup, pool=None, cpu=True, cold=False):
     """one sub-record: K timed encode steps of `workload` over the resident buffer x (after `warmup` untimed ones), kernel
-    times from HIP events, one decode for the round trip, roofline, CPU baseline"""
+    times from HIP events, one decode for the round trip, roofline, CPU baseline.  cold=True: no warm-up at all — the timed
+    step is this input's first contact with the context (the fallback grid hint is whatever the call before left)"""
     co = Codec(workload, ctx)
     n = x.numel()
-    timed_steps(co, x, 0, max(warmup, 1), torch.cuda.synchronize)
+    if not cold:
+        timed_steps(co, x, 0, max(warmup, 1), torch.cuda.synchronize)
     ctx.set_profiling(True)
     ctx.kernel_times()
     dt, h = timed_steps(co, x, steps, 0, torch.cuda.synchronize)
@@ -506,6 +508,10 @@ def main():
     ctx.set_profiling(False)
     ktimes = ctx.kernel_times()
     c = codec.nbytes(last)
+    # what the timed steps met (mi_lz_path_stats / mi_order_violations): blocks on the fallback pipeline, parts above 2 560
+    # entries, sorts found out of order — all 0 on text; a corpus that lives in the fallback would otherwise only be a slow number
+    path = ctx.path_stats()
+    path["order_violations"] = ctx.order_violations()
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
     if dist is not None:
@@ -595,8 +601,19 @@ def main():
             for kind, gen in kinds:
                 try:
                     xa = torch.from_numpy(gen()).to(dev).repeat(reps)[:100_000_000].contiguous()
+                    # cold first: one text call resets the fallback hint (and sheds the second fallback stream), then ONE timed
+                    # step with no warm-up — what a caller sees who switches from text to this family; then warm
+                    codec.encode(x[:100_000_000]); torch.cuda.synchronize()
+                    ps0 = ctx.path_stats()
+                    rc_ = measure(ctx, args.workload, xa, 1, 0, None, False, cold=True)
+                    ps1 = ctx.path_stats()
                     r = measure(ctx, args.workload, xa, 2, 1, None, False)
                     adv[kind] = {k_: r[k_] for k_ in ("value", "unit", "ms_per_step", "ratio", "roundtrip", "input_bytes")}
+                    adv[kind]["value_cold"] = rc_["value"]
+                    nblk_ = (xa.numel() + BLOCK - 1) // BLOCK
+                    adv[kind]["fallback_blocks_per_pass"] = ps1["fallback_blocks"] - ps0["fallback_blocks"]
+                    adv[kind]["wide_parts_per_pass"] = ps1["wide_parts"] - ps0["wide_parts"]
+                    adv[kind]["blocks"] = nblk_
                     # the same family at the headline's size (15 259 blocks: five batches in the three-stage pipeline, the fallback
                     # grids sized by the batch before; 10^8 bytes are two batches, the first of them on the small fallback grid)
                     xb = xa.repeat(10)
@@ -606,6 +623,37 @@ def main():
                 except Exception as e:
                     adv[kind] = {"value": None, "error": repr(e)[:200]}
             extras["adversarial"] = adv
+        if single and args.workload in ("deflate-h", "deflate"):
+            # config 5 from the C boundary (mi_lz_encode_multi_dev, csrc/multi.hip): ONE process, one context per listed device,
+            # contiguous block ranges, streams gathered into the first device.  This box has one GPU, so the list is {0, 0}: two
+            # contexts share the GPU and the gather is a peer copy — a proof that the path runs and what it costs, not a scaling
+            # figure (the driver's --gpus N run is one process per GPU over torch.distributed / RCCL)
+            try:
+                from compression_algorithms_amd.multi import Multi
+                mm = Multi([local, local])
+                p_ = codec.p
+                nblk = (n + BLOCK - 1) // BLOCK
+                sh = []
+                for g in range(2):
+                    lo_, hi_ = mm.shard(nblk, g)
+                    sh.append(x[lo_ * BLOCK: min(hi_ * BLOCK, n)])
+                mode_h = args.workload == "deflate-h"
+                hm = mm.compress_dev(sh, n, p_, mode_h=mode_h)          # warm-up: workspaces, buffers
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    hm = None
+                    hm = mm.compress_dev(sh, n, p_, mode_h=mode_h)
+                tm = (time.perf_counter() - t0) / 3
+                same = bool(hm.nbytes == c and torch.equal(hm.data[:c], last.data[:c]) and torch.equal(hm.block_bits, last.block_bits))
+                extras["multi_one_process"] = {"value": round(n / tm / 1e9, 3), "unit": "GB/s", "devices": [local, local], "transport": mm.transport,
+                                               "equal_to_single_context": same,
+                                               "what": "mi_lz_encode_multi_dev: two contexts on this one GPU, halves encoded side by side, gathered "
+                                                       "by peer copy; call returns synchronised"}
+                del hm
+                mm.close()
+            except Exception as e:
+                extras["multi_one_process"] = {"value": None, "error": repr(e)[:300]}
         if single:
             # PCIe-inclusive (never `value`).  The deflate workloads go through the HOST-buffer entry points the drop-in
             # compress() calls (pageable memory in and out, transfers chunked beside the encoder: host_api.hip); the others
@@ -710,6 +758,7 @@ def main():
                        "parallelism": f"blocks sharded over {world} GPU(s), {args.scaling} scaling"},
             "ratio": round(n_job / max(c_job, 1), 4), "ratio_vs_ref": ratio_vs_ref, "roundtrip": rt_ok, "decode_gbps": decode_gbps, "gather": gather_report,
             "roofline": roof, "cpu_baseline": cpu,
+            "fallback_blocks": path["fallback_blocks"], "wide_parts": path["wide_parts"], "order_violations": path["order_violations"],
         }
         line.update(extras)
         print(json.dumps(line), flush=True)

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("MI_CODEC_LIB") or os.path.join(LIB_DIR, "libmi_codec.
 MI_OK = 0
 STATUS = {0: "MI_OK", 1: "MI_ERR_ARG", 2: "MI_ERR_HIP", 3: "MI_ERR_NOMEM", 4: "MI_ERR_CAPACITY",
           5: "MI_ERR_EMPTY_INPUT", 6: "MI_ERR_SINGLE_SYMBOL", 7: "MI_ERR_CODE_TOO_LONG", 8: "MI_ERR_CORRUPT",
-          9: "MI_ERR_NO_DEVICE", 10: "MI_ERR_UNSTABLE"}
+          9: "MI_ERR_NO_DEVICE", 10: "MI_ERR_UNSTABLE", 11: "MI_ERR_TRANSPORT"}
 
 
 class MiError(RuntimeError):
@@ -59,6 +59,9 @@ EXPORTS = [
     "mi_deflate_h_bound_bytes", "mi_deflate_h_encode_dev", "mi_deflate_h_decode_dev", "mi_deflate_h_encode", "mi_deflate_h_decode",
     "mi_fse_block_bound", "mi_fse_encode_dev", "mi_fse_decode_dev", "mi_fse_encode", "mi_fse_decode", "mi_fse_normalise_dev",
     "mi_set_profiling", "mi_get_kernel_times",
+    "mi_multi_create", "mi_multi_destroy", "mi_multi_ndev", "mi_multi_ctx", "mi_multi_transport", "mi_multi_last_transport_error",
+    "mi_multi_shard", "mi_lz_encode_multi_dev", "mi_lz_encode_multi", "mi_deflate_h_encode_multi", "mi_multi_selftest_transport",
+    "mi_lz_path_stats",
 ]
 
 _lib = None
@@ -134,6 +137,25 @@ def lib():
             L.mi_fse_decode_dev.argtypes = [vp, C.POINTER(FseParams), vp, u64, vp, vp, u64, vp]
             L.mi_fse_decode.argtypes = [vp, C.POINTER(FseParams), vp, u64, vp, vp, u64]
             L.mi_fse_normalise_dev.argtypes = [vp, vp, C.c_uint32, vp, vp]
+        if hasattr(L, "mi_multi_create"):
+            L.mi_multi_create.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]
+            L.mi_multi_destroy.argtypes = [vp]
+            L.mi_multi_destroy.restype = None
+            L.mi_multi_ndev.argtypes = [vp]
+            L.mi_multi_ctx.argtypes = [vp, C.c_int]
+            L.mi_multi_ctx.restype = vp
+            L.mi_multi_transport.argtypes = [vp]
+            L.mi_multi_transport.restype = C.c_char_p
+            L.mi_multi_last_transport_error.argtypes = [vp]
+            L.mi_multi_last_transport_error.restype = C.c_char_p
+            L.mi_multi_shard.argtypes = [u64, C.c_int, C.c_int, C.POINTER(u64), C.POINTER(u64)]
+            L.mi_multi_shard.restype = None
+            L.mi_lz_encode_multi_dev.argtypes = [vp, C.POINTER(LzParams), C.c_int, C.POINTER(vp), u64, vp, u64, vp]
+            L.mi_lz_encode_multi.argtypes = [vp, C.POINTER(LzParams), vp, u64, vp, u64, vp]
+            L.mi_deflate_h_encode_multi.argtypes = [vp, C.POINTER(LzParams), vp, u64, vp, u64, vp]
+            L.mi_multi_selftest_transport.argtypes = [vp, u64]
+        if hasattr(L, "mi_lz_path_stats"):
+            L.mi_lz_path_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
         _lib = L
     return _lib
 

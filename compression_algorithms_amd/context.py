@@ -40,6 +40,12 @@ class Context:
         """sorts found out of (key, time) order by the kernels of this context so far (include/mi_codec.h); 0 on gfx950"""
         return int(self.L.mi_order_violations(self.h))
 
+    def path_stats(self):
+        """{fallback_blocks, wide_parts} the LZ encoders of this context met since it was created (mi_lz_path_stats)"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _lib.check(self.L.mi_lz_path_stats(self.h, C.byref(a), C.byref(b)), "mi_lz_path_stats")
+        return dict(fallback_blocks=int(a.value), wide_parts=int(b.value))
+
     def set_profiling(self, on=True):
         _lib.check(self.L.mi_set_profiling(self.h, 1 if on else 0), "mi_set_profiling")
 

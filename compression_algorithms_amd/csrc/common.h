@@ -26,9 +26,10 @@ struct mi_ctx {
     hipStream_t stream = nullptr;       // the context's own stream (host-buffer entry points; created on first use: mi_host_stream)
     hipStream_t side = nullptr;         // second stream: overlaps the replay/parse of batch i with the find of batch i+1
     hipStream_t fb = nullptr;           // low priority: the (normally empty) fallback chain must not hold LDS-hungry launches in front of real work
-    hipStream_t fb2 = nullptr;          // a second one, created only while an encode call finds the input living in the fallback (lz_emit.hip): the
-                                        // chains of consecutive batches then run side by side.  NOT kept: one more stream in the process — even
-                                        // idle, whatever the creation order or GPU_MAX_HW_QUEUES — cost the text pipeline 7 % (20.4 -> 19.1 GB/s)
+    hipStream_t fb2 = nullptr;          // a second one, alive only while the input lives in the fallback (created / released at the start of an
+                                        // encode call by the hint of the calls before it, lz_emit.hip): the chains of consecutive batches then run
+                                        // side by side.  Not permanent: one more stream in the process — even idle, whatever the creation order or
+                                        // GPU_MAX_HW_QUEUES — cost the text pipeline 7 % (20.4 -> 19.1 GB/s)
     hipStream_t parse = nullptr;        // third stage: parse / emit / concatenate
 #define MI_SETS 3
     hipEvent_t  ev_find[MI_SETS] = {}, ev_done[MI_SETS] = {}, ev_part[MI_SETS] = {}, ev_fb[MI_SETS] = {}, ev_replay[MI_SETS] = {};
@@ -38,6 +39,8 @@ struct mi_ctx {
     int         num_cu = 256;
     int         lds_rank_ok = 0;       // LDS returning atomics serve the lanes of one instruction in lane order (self-check at creation)
     int         test_break_rank = 0;   // MI_LZ_TEST_BREAK_RANK=1: the scatter mis-ranks on purpose (tests of the order check)
+    int         test_force_fb = 0;     // MI_LZ_TEST_FORCE_FALLBACK=1 (lib_test only): every block goes to the fallback pipeline
+    uint64_t   *d_stats = nullptr;     // device counters behind mi_lz_path_stats: [0] fallback blocks, [1] wide parts
     uint32_t   *h_order = nullptr;     // pinned, device-visible: set by a kernel that found a sort out of order (lz_common.h)
     uint32_t   *d_order = nullptr;     // the same word as the device addresses it
     uint32_t    order_violations = 0;  // violations noticed so far (mi_order_poll)

@@ -56,6 +56,7 @@ const char *mi_status_str(mi_status s)
     case MI_ERR_CODE_TOO_LONG: return "Huffman code longer than 32 bits";
     case MI_ERR_CORRUPT: return "corrupt stream";
     case MI_ERR_NO_DEVICE: return "no HIP device: this library has no CPU fallback";
+    case MI_ERR_TRANSPORT: return "multi-device gather: RCCL missing or an RCCL call failed";
     case MI_ERR_UNSTABLE: return "a sort came out unstable (LDS atomics not lane-ordered): encode again, the context now ranks with ballots";
     }
     return "unknown";
@@ -111,6 +112,8 @@ mi_status mi_ctx_create(mi_ctx **out, int device)
     c->h_order[0] = 0; c->h_order[1] = 0;          // [0] order flag, [1] blocks the last batch sent to the fallback (a grid-size hint)
     c->lds_rank_ok = lds_rank_selfcheck(c);
     c->test_break_rank = getenv("MI_LZ_TEST_BREAK_RANK") != nullptr;
+    c->test_force_fb = getenv("MI_LZ_TEST_FORCE_FALLBACK") != nullptr;       // (only a -DMI_TEST_HOOKS build looks at the flag)
+    if (hipMalloc((void **)&c->d_stats, 64) != hipSuccess || hipMemset(c->d_stats, 0, 64) != hipSuccess) { mi_ctx_destroy(c); return MI_ERR_NOMEM; }
     *out = c;
     return MI_OK;
 }
@@ -125,6 +128,7 @@ void mi_ctx_destroy(mi_ctx *c)
     free(c->pending); free(c->event_pool);
     if (c->ws) hipFree(c->ws);
     if (c->d_err) hipFree(c->d_err);
+    if (c->d_stats) hipFree(c->d_stats);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->h_order) hipHostFree(c->h_order);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -159,6 +163,18 @@ uint32_t mi_order_violations(mi_ctx *c)
     if (!c) return 0;
     mi_order_poll(c);
     return c->order_violations;
+}
+
+mi_status mi_lz_path_stats(mi_ctx *c, uint64_t *fallback_blocks, uint64_t *wide_parts)
+{
+    if (!c || !c->d_stats) return MI_ERR_ARG;
+    uint64_t h[2] = {0, 0};
+    MI_HIP(c, hipSetDevice(c->device));
+    MI_HIP(c, hipDeviceSynchronize());
+    MI_HIP(c, hipMemcpy(h, c->d_stats, 16, hipMemcpyDeviceToHost));
+    if (fallback_blocks) *fallback_blocks = h[0];
+    if (wide_parts) *wide_parts = h[1];
+    return MI_OK;
 }
 
 mi_status mi_set_profiling(mi_ctx *c, int on)

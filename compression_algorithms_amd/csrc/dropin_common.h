@@ -19,6 +19,29 @@ static mi_ctx *dropin_ctx(void)
     return g_ctx;
 }
 
+/* MI_CODEC_DEVICES=0,1,2,...: the block pipelines (deflate's compress()) spread their blocks over these GPUs from this one
+ * process — one context per listed device, contiguous block ranges, the streams gathered into the first device over RCCL / xGMI
+ * (include/mi_codec.h "Several GPUs of one node").  Unset: one GPU (MI_CODEC_DEVICE).  A device may be listed twice (two contexts
+ * on one GPU, peer copies instead of RCCL): the shape the path is tested in on a one-GPU box. */
+static mi_multi *g_multi;
+__attribute__((unused)) static mi_multi *dropin_multi(void)
+{
+    const char *e = getenv("MI_CODEC_DEVICES");
+    if (g_multi || !e || !*e) return g_multi;
+    int dev[64], nd = 0;
+    for (const char *q = e; *q && nd < 64; ) {
+        char *end;
+        const long v = strtol(q, &end, 10);
+        if (end == q || v < 0) { fprintf(stderr, "mi_codec: MI_CODEC_DEVICES=%s is not a list of device ordinals\n", e); exit(1); }
+        dev[nd++] = (int)v;
+        q = (*end == ',') ? end + 1 : end;
+        if (*end && *end != ',') { fprintf(stderr, "mi_codec: MI_CODEC_DEVICES=%s is not a list of device ordinals\n", e); exit(1); }
+    }
+    const mi_status st = mi_multi_create(&g_multi, dev, nd);
+    if (st != MI_OK) { fprintf(stderr, "mi_codec: MI_CODEC_DEVICES=%s: %s\n", e, mi_status_str(st)); exit(1); }
+    return g_multi;
+}
+
 /* Side tables of the drop-ins, kept OUT of band.  The reference's BitStream / BitWriter have no room for the per-block
  * (per-tile) offsets a parallel decoder needs, and probing for a trailer behind a caller's buffer reads past a buffer
  * the reference produced.  So compress registers {buffer pointer, stream length in bits} -> table here and

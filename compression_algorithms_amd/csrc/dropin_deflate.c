@@ -80,6 +80,58 @@ void write_length_distance(char *buffer, uint8_t length, uint16_t distance, uint
     buffer[(*at)++] = 1; buffer[(*at)++] = (char)(distance & 0xFF); buffer[(*at)++] = (char)(distance >> 8); buffer[(*at)++] = (char)length;
 }
 
+/* ---- deflate/huffman.h + deflate.h:19-21: host helpers of the entropy stage the reference sketches -------------------------- */
+void init_bitwriter(BitWriter *w, uint64_t buffer_size)                                     /* deflate/huffman.c:7-13: size in BYTES, zeroed */
+{
+    w->buffer = (uint32_t *)calloc(buffer_size ? buffer_size : 4, 1);
+    w->word_idx = 0; w->bit_idx = 0; w->buffer_size = buffer_size;
+}
+
+void write_bits(BitWriter *w, uint32_t bits, uint8_t length)                                  /* deflate/huffman.c:16-46 */
+{
+    /* MSB first: the next free bit of the current word is bit 31 - bit_idx.  `bits` beyond `length` are the caller's to
+     * keep zero (the reference ORs them in unmasked when the code fits the word exactly, masked otherwise: same result
+     * for well-formed input) */
+    if (!length) return;
+    const uint32_t room = 32u - (uint32_t)w->bit_idx;
+    const uint32_t v = length >= 32 ? bits : (bits & ((1u << length) - 1u));
+    if (length <= room) {
+        w->buffer[w->word_idx] |= v << (room - length);
+        w->bit_idx += length;
+        if (w->bit_idx == 32) { w->bit_idx = 0; ++w->word_idx; }
+    } else {
+        const uint32_t spill = length - room;
+        w->buffer[w->word_idx++] |= v >> spill;
+        w->buffer[w->word_idx] |= v << (32u - spill);
+        w->bit_idx = spill;
+    }
+}
+
+void append_huffman_tree_literal(uint32_t *frequencies, char literal) { ++frequencies[(uint8_t)literal]; }
+void append_huffman_tree_pair(uint32_t *frequencies, uint16_t offset)
+{
+    /* bin 256 + (leading zeros of the 16-bit offset): deflate/huffman.c:60-61; offset 0 is the caller's bug there (clz(0)) and
+     * lands in the last bin here */
+    const unsigned lz16 = offset ? (unsigned)__builtin_clz((unsigned)offset) - 16u : 16u;
+    ++frequencies[256 + (lz16 > 29u ? 29u : lz16)];
+}
+
+void gather_codes(MinHeapNode *root, uint16_t code, uint8_t length, uint16_t *codes, uint8_t *code_lengths)
+{
+    if (!root) return;
+    if (!root->left && !root->right) { codes[root->data] = code; code_lengths[root->data] = length; return; }   /* a leaf keeps the path */
+    gather_codes(root->left, (uint16_t)(code << 1), (uint8_t)(length + 1), codes, code_lengths);           /* left = 0 */
+    gather_codes(root->right, (uint16_t)((code << 1) | 1u), (uint8_t)(length + 1), codes, code_lengths);    /* right = 1 */
+}
+
+void init_huffman_node(HuffmanNode *node) { node->left = NULL; node->right = NULL; node->value = 0; node->frequency = 0; }
+void destroy_huffman_node(HuffmanNode *node)
+{
+    if (node->left) { destroy_huffman_node(node->left); free(node->left); node->left = NULL; }
+    if (node->right) { destroy_huffman_node(node->right); free(node->right); node->right = NULL; }
+}
+bool compare_huffman_node(const HuffmanNode *a, const HuffmanNode *b) { return a->frequency < b->frequency; }
+
 StateData compress(const char *input_filename)
 {
     const char *slash = strrchr(input_filename, '/');
@@ -87,7 +139,8 @@ StateData compress(const char *input_filename)
     StateData sd = { NULL, NULL, (char *)malloc(strlen(filename) + strlen(extension) + 1) };
     strcpy(sd.compressed_filename, filename); strcat(sd.compressed_filename, extension);
     uint64_t n; char *in = slurp(input_filename, &n);
-    mi_ctx *ctx = dropin_ctx();
+    mi_multi *mm = dropin_multi();                              /* MI_CODEC_DEVICES=0,1,...: the blocks spread over several GPUs */
+    mi_ctx *ctx = mm ? NULL : dropin_ctx();
     mi_lz_params p = mi_lz_params_deflate();
     /* MI_DEFLATE_MODE=H: finish what lz77.c:279 leaves as a TODO — the same tokens, Huffman coded per block
      * (include/mi_codec.h "mode H").  Default: the reference's raw token bytes. */
@@ -97,8 +150,12 @@ StateData compress(const char *input_filename)
     const uint64_t cap = (mode_h ? mi_deflate_h_bound_bytes(n, &p) : mi_lz_bound_bytes(n, &p)) + 64;
     uint8_t *out = (uint8_t *)malloc(cap); uint64_t *bits = (uint64_t *)malloc(8 * (nblocks + 1));
     struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
-    mi_status st = mode_h ? mi_deflate_h_encode(ctx, &p, (const uint8_t *)in, n, out, cap, bits)
-                          : mi_lz_encode(ctx, &p, (const uint8_t *)in, n, out, cap, bits);
+    /* the reference's block loop (deflate.c:47-63), all blocks at once; with MI_CODEC_DEVICES each device takes a contiguous
+     * range of them and the streams meet on the first device — the same bytes either way */
+    mi_status st = mm ? (mode_h ? mi_deflate_h_encode_multi(mm, &p, (const uint8_t *)in, n, out, cap, bits)
+                                : mi_lz_encode_multi(mm, &p, (const uint8_t *)in, n, out, cap, bits))
+                      : (mode_h ? mi_deflate_h_encode(ctx, &p, (const uint8_t *)in, n, out, cap, bits)
+                                : mi_lz_encode(ctx, &p, (const uint8_t *)in, n, out, cap, bits));
     clock_gettime(CLOCK_MONOTONIC, &t1);
     if (st != MI_OK) { fprintf(stderr, "compress: %s\n", mi_status_str(st)); exit(1); }
     /* Mode T keeps the reference's file byte for byte (the bare token concatenation of deflate.c:56) and puts what a

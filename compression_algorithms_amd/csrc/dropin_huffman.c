@@ -46,6 +46,62 @@ void write_bits(BitWriter *writer, uint32_t bits, uint8_t length)   /* huffman.c
     }
 }
 
+/* ---- huffman.h:62-73: the reference's priority queue (huffman.c:80-163), host side ---------------------------------------
+ * An implicit binary min-heap over Node pointers keyed by frequency.  Only the comparisons matter for parity: both sifts
+ * move an element only past a STRICTLY smaller / larger key, and sifting down looks at the left child first, so on a tie
+ * between the children the left one moves up.  The GPU's k_huff_build performs these same operations in this order. */
+PriorityQueue *init_priority_queue(uint64_t capacity)
+{
+    PriorityQueue *q = (PriorityQueue *)malloc(sizeof *q);
+    if (!q) { printf("ERROR: out of memory\n"); exit(1); }
+    q->nodes = (Node **)malloc((capacity ? capacity : 1) * sizeof(Node *));
+    q->size = 0;
+    q->capacity = capacity;
+    return q;
+}
+
+void swap_nodes(Node **a, Node **b) { Node *t = *a; *a = *b; *b = t; }
+
+void heapify_up(PriorityQueue *q, uint64_t idx)
+{
+    for (; idx > 0; idx = (idx - 1) / 2) {
+        Node **child = &q->nodes[idx], **parent = &q->nodes[(idx - 1) / 2];
+        if (!((*child)->frequency < (*parent)->frequency)) return;
+        swap_nodes(child, parent);
+    }
+}
+
+void heapify_down(PriorityQueue *q, uint64_t idx)
+{
+    for (;;) {
+        uint64_t pick = idx;
+        const uint64_t l = 2 * idx + 1, r = l + 1;
+        if (l < q->size && q->nodes[l]->frequency < q->nodes[pick]->frequency) pick = l;
+        if (r < q->size && q->nodes[r]->frequency < q->nodes[pick]->frequency) pick = r;
+        if (pick == idx) return;
+        swap_nodes(&q->nodes[idx], &q->nodes[pick]);
+        idx = pick;
+    }
+}
+
+void enqueue(PriorityQueue *q, Node *node)
+{
+    if (q->size == q->capacity) { printf("ERROR: Queue is full\n"); exit(1); }       /* huffman.c:138-141 */
+    q->nodes[q->size] = node;
+    heapify_up(q, q->size++);
+}
+
+Node *dequeue(PriorityQueue *q)
+{
+    if (q->size == 0) { printf("ERROR: Queue is empty\n"); exit(1); }               /* huffman.c:149-152 */
+    Node *top = q->nodes[0];
+    q->nodes[0] = q->nodes[--q->size];
+    heapify_down(q, 0);
+    return top;
+}
+
+bool is_empty(PriorityQueue *q) { return q->size == 0; }
+
 Node *init_node(uint8_t value, uint32_t frequency)                  /* huffman.c:165-177 */
 {
     Node *n = (Node *)malloc(sizeof *n);

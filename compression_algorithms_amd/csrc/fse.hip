@@ -10,23 +10,21 @@
 //   state flush          main.zig:65
 //   LSB-first bit append main.zig:28-39
 //
-// One wave per block.  The block is read twice from HBM/L2 (histogram pass, coalesced 16 B per
-// lane; encode pass, each lane streaming its own contiguous sub-stream with 16-byte loads, the next
-// one in flight), the tables (3N bytes: 768 B at table_log 8, 12 KiB at 12) live in dynamic LDS, so
-// ~20 waves per CU hide the table-lookup latency of the serial state chain.  The encode loop runs
-// ONCE: the chain is serial, so a dry run that only counts bits costs as much as the coding.  Every
-// lane writes its words at a fixed stride inside the block's record (the worst case, which is what
-// the record is sized for) and the wave then closes the gaps in place, left to right.
-//
-// Why the in-place compaction needs no fence: sub-stream l moves DOWN, from l * lstr to its prefix
-// offset woff[l], and woff[l] + cnt[l] = woff[l+1] <= (l+1) * lstr, so a store for sub-stream l never
-// lands on a word that a LATER load (of l itself or of any l' > l) still has to read; the only loads
-// a store can overlap are ones of the same or an earlier copy step, and the store carries their data
-// (v = payload[src]; payload[dst] = v), so it cannot issue before they have returned.
-//
-// Staging the sub-stream words through LDS instead was not done: the worst case
-// is 64 lanes x 257 words = 64 KiB per wave, i.e. two waves per CU instead of twenty — the state
-// chain needs the occupancy more than the ~36 KiB per block of L2 write traffic it would save.
+// One wave per block, lane l codes sub-stream l (a contiguous 1 KiB of a full block) serially: the state chain is the work.
+// Round 3 moved 9 x the algorithmic bytes for it (profiles/pmc_traffic_fse.json: 14.5 GB per 10^9 B at 4.1 TB/s — the kernel was
+// bound by its own waste): every lane loaded 16 B at a time from its own cache line, eight visits per line spread over ~2 000
+// cycles each while twenty waves per CU shared a 32 KiB L1 (every line fetched up to eight times), and stored its output one
+// dword at a time at a fixed stride — 64 partial 32-byte sectors per wave store, 8 x write amplification — after which the wave
+// copied the record down in place and k_fse_pack copied it again.  Round 4:
+//   input   a lane takes a whole 128-byte line into registers at once (eight 16-byte loads back to back: the line is fetched
+//           ONCE), the next line is in flight while these 128 symbols are coded;
+//   tables  per symbol ONE packed dword {nb_hi, threshold, delta} instead of three LDS reads, all 16 of a load issued together,
+//           off the serial chain (they do not depend on the state);
+//   output  words go to a lane-private 64-byte LDS window (interleaved: no bank conflicts) and leave as whole 64-byte pieces
+//           (two full sectors) to the lane's fixed-stride region of a SCRATCH record; nothing is compacted in place;
+//   pack    k_fse_pack places header and sub-streams at their final offsets: the payload moves once.
+// HBM traffic per 10^9 B: 2 n read (histogram pass + coding pass) + c written + c read + c written by the pack (c = 0.61 n),
+// against 14.5 + 1.2 GB before.  The record format is unchanged (include/mi_fse.h, oracle/orc_fse.c: byte-equal).
 #include "common.h"
 
 #define FSE_MAX_LOG   12
@@ -124,19 +122,28 @@ __device__ __forceinline__ void fse_build_tables(const uint32_t *s_cnt, uint32_t
     }
 }
 
-__global__ __launch_bounds__(64)
-void k_fse_encode(const uint8_t *__restrict__ in, uint64_t n_total, FseP P, uint8_t *__restrict__ rec_out,
-                  uint64_t rec_stride, uint64_t *__restrict__ rec_bits)
+// scratch record of one block (k_fse_encode -> k_fse_pack): the final record's fixed part (bitmap, counts, states, lengths:
+// FSE_SCR_FIXED bytes at most) followed by the 64 lanes' sub-streams at a fixed stride of `lstr` words (a multiple of 16: a
+// lane's 64-byte pieces are 64-byte aligned)
+#define FSE_SCR_FIXED 1024u                       // >= 32 + 512 + 2 * (64 + 1) + 4 * 64 = 930
+__host__ __device__ __forceinline__ uint32_t fse_lane_stride_words(uint32_t block, uint32_t S, uint32_t L)
 {
-    // LDS: 6 KiB static + 3N dynamic (N = table size), so table_log 8 runs ~20 waves per CU
-    __shared__ uint32_t s_work[4 * 256];                  // 4 sub-histograms, then fill/thresh/delta/nb_hi
-    __shared__ uint32_t s_cnt[256], s_cum[256];
+    uint32_t m = (block + S - 1) / S; m = (m + 3u) & ~3u;
+    return (((m * L + 31u) / 32u + 1u) + 15u) & ~15u;
+}
+
+__global__ __launch_bounds__(64)
+void k_fse_encode(const uint8_t *__restrict__ in, uint64_t n_total, FseP P, uint8_t *__restrict__ scr, uint64_t scr_stride,
+                  uint64_t *__restrict__ rec_bits, uint32_t *__restrict__ rec_fixed)
+{
+    // LDS: 6 KiB static + 3N dynamic (N = table size): table_log 8 could run 23 waves per CU
+    __shared__ uint32_t s_work[4 * 256];                  // 4 sub-histograms; then s_fill (table build); then the output windows
+    __shared__ uint32_t s_cnt[256], s_cum[256];           // s_cum becomes the packed per-symbol table
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     uint32_t (*s_hist)[256] = reinterpret_cast<uint32_t (*)[256]>(s_work);
     uint32_t *s_fill = s_work + 256;                      // (the histogram is dead once s_cnt exists)
-    uint32_t *s_thresh = s_work + 512;
-    int32_t  *s_delta = reinterpret_cast<int32_t *>(s_work + 768);
-    uint8_t  *s_nbhi = reinterpret_cast<uint8_t *>(s_work);          // first 256 bytes
+    uint32_t *s_tab = s_cum;                              // nb_hi | threshold << 4 | (delta + 4096) << 17
+    uint32_t *s_win = s_work;                             // [16][64]: word j of lane l's 64-byte window at j * 64 + l
     uint16_t *s_next = reinterpret_cast<uint16_t *>(s_dyn);          // [N]
     uint8_t  *s_symat = s_dyn + 2 * (1u << P.L);                     // [N]
 
@@ -172,16 +179,20 @@ void k_fse_encode(const uint8_t *__restrict__ in, uint64_t n_total, FseP P, uint
     fse_normalise_wave(s_hist[0], L, s_cnt);
     __builtin_amdgcn_wave_barrier();
     fse_build_tables(s_cnt, L, P.spread, s_cum, s_symat, s_next, s_fill);
-    for (uint32_t s = lane; s < 256; s += 64) {
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t s = lane; s < 256; s += 64) {           // (in place over s_cum: every lane reads and writes its own entries)
         const uint32_t c = s_cnt[s];
-        uint32_t nb = 0, th = 0; int32_t dl = 0;
-        if (c) { nb = L - (31u - (uint32_t)__builtin_clz(c)); th = c << nb; dl = (int32_t)s_cum[s] - (int32_t)c; }
-        s_nbhi[s] = (uint8_t)nb; s_thresh[s] = th; s_delta[s] = dl;
+        uint32_t e = 0;
+        if (c) {
+            const uint32_t nb = L - (31u - (uint32_t)__builtin_clz(c));
+            e = nb | ((c << nb) << 4) | ((uint32_t)((int32_t)s_cum[s] - (int32_t)c + 4096) << 17);
+        }
+        s_tab[s] = e;
     }
     __builtin_amdgcn_wave_barrier();
 
-    // ---- record header
-    uint8_t *rec = rec_out + b * rec_stride;
+    // ---- record header, into the scratch record
+    uint8_t *rec = scr + b * scr_stride;
     uint32_t nsym = 0;
     {
         // bitmap: lane l < 32 writes byte l
@@ -210,97 +221,113 @@ void k_fse_encode(const uint8_t *__restrict__ in, uint64_t n_total, FseP P, uint
     uint8_t *states = rec + hdr;
     const uint32_t states_bytes = 2u * (S + (S & 1u));
     uint8_t *lens = states + states_bytes;
-    uint32_t *payload = reinterpret_cast<uint32_t *>(lens + 4u * S);       // records are 4-byte aligned
     if ((S & 1u) && lane == 0) { states[2 * S] = 0; states[2 * S + 1] = 0; }
+    const uint32_t lstr = fse_lane_stride_words(P.block, S, L);
+    uint32_t *mine = reinterpret_cast<uint32_t *>(rec + FSE_SCR_FIXED) + (size_t)lane * lstr;     // 64-byte aligned (scr, stride, FSE_SCR_FIXED are)
+    __builtin_amdgcn_wave_barrier();                           // s_fill (in s_work) is dead: the output windows take its place
 
-    // ---- sub-stream of this lane: bytes [a, a+len), encoded last symbol first
+    // ---- sub-stream of this lane: bytes [a, a+len), encoded last symbol first (main.zig:58-62)
     const uint32_t m = fse_sub_len(n, S);
     const uint32_t a = lane * m;
     const uint32_t len = (lane < S && a < n) ? ((n - a < m) ? n - a : m) : 0u;
-    // ONE pass over the symbols: the state chain is serial, so a dry run to learn the sub-stream sizes costs as much as the
-    // coding itself.  Every lane writes its words at a fixed stride (the worst case, which is what the record is sized
-    // for) and the wave then closes the gaps in place, left to right — a coalesced copy of at most 64 KiB.
-    const uint32_t lstr = (m * L + 31u) / 32u + 1u;            // words per lane before compaction
     uint32_t x = N;
-    uint64_t acc = 0; uint32_t nacc = 0, widx = lane * lstr;
-    uint32_t bits = 0;
-    auto step = [&](uint32_t s) {
-        const uint32_t nb = s_nbhi[s] - (x < s_thresh[s] ? 1u : 0u);
+    uint64_t acc = 0; uint32_t nacc = 0, wcnt = 0;
+    // a finished word: into the lane's LDS window; every 16th one sends the window off as one aligned 64-byte piece
+    auto put = [&](uint32_t w) {
+        s_win[(wcnt & 15u) * 64u + lane] = w;
+        ++wcnt;
+        if ((wcnt & 15u) == 0) {
+            uint4 *dst = reinterpret_cast<uint4 *>(mine + (wcnt - 16u));
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                dst[q] = make_uint4(s_win[(4 * q) * 64u + lane], s_win[(4 * q + 1) * 64u + lane], s_win[(4 * q + 2) * 64u + lane], s_win[(4 * q + 3) * 64u + lane]);
+        }
+    };
+    auto step = [&](uint32_t e) {                              // e = s_tab[symbol]
+        const uint32_t nb = (e & 15u) - (x < ((e >> 4) & 0x1FFFu) ? 1u : 0u);
         acc |= (uint64_t)(x & ((1u << nb) - 1u)) << nacc;
         nacc += nb;
-        if (nacc >= 32) { payload[widx++] = (uint32_t)acc; acc >>= 32; nacc -= 32; }
-        bits += nb;
-        x = s_next[(int32_t)(x >> nb) + s_delta[s]];
+        x = s_next[(int32_t)(x >> nb) + (int32_t)(e >> 17) - 4096];
     };
-    if ((len & 15u) == 0 && ((((uintptr_t)(src + a)) & 15u) == 0)) {
-        // Every lane walks its own 1 KiB sub-stream, so its loads never coalesce and each costs a trip to HBM that the
-        // serial state chain cannot hide: 16 bytes per load, and the next 16 are in flight while these are coded.
+    auto drain = [&]() { if (nacc >= 32) { put((uint32_t)acc); acc >>= 32; nacc -= 32; } };     // (after two steps nacc <= 31 + 2 * 12)
+    if ((len & 127u) == 0 && ((((uintptr_t)(src + a)) & 15u) == 0)) {
         const uint4 *v16 = reinterpret_cast<const uint4 *>(src + a);
-        int32_t g = (int32_t)(len >> 4) - 1;
-        uint4 cur = make_uint4(0, 0, 0, 0);
-        if (g >= 0) cur = v16[g];
+        int32_t g = (int32_t)(len >> 7) - 1;                   // 128-byte lines, last one first
+        uint4 cur[8], nxt[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { cur[q] = make_uint4(0, 0, 0, 0); nxt[q] = make_uint4(0, 0, 0, 0); }
+        if (g >= 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cur[q] = v16[g * 8 + q];
+        }
         for (; g >= 0; --g) {
-            uint4 nxt = make_uint4(0, 0, 0, 0);
-            if (g > 0) nxt = v16[g - 1];
-            const uint32_t w4[4] = {cur.w, cur.z, cur.y, cur.x};       // backwards: last byte first
+            if (g > 0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                for (int k = 3; k >= 0; --k) step((w4[q] >> (8 * k)) & 0xFFu);
+                for (int q = 0; q < 8; ++q) nxt[q] = v16[(g - 1) * 8 + q];
             }
-            cur = nxt;
+#pragma unroll
+            for (int q = 7; q >= 0; --q) {
+                const uint32_t w4[4] = {cur[q].w, cur[q].z, cur[q].y, cur[q].x};       // backwards: last byte first
+                uint32_t e[16];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int k = 3; k >= 0; --k) e[4 * j + (3 - k)] = s_tab[(w4[j] >> (8 * k)) & 0xFFu];
+                }
+#pragma unroll
+                for (int j = 0; j < 16; j += 2) { step(e[j]); step(e[j + 1]); drain(); }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cur[q] = nxt[q];
         }
     } else {
-        // walk backwards in 4-byte groups (sub-streams start 4-byte aligned relative to the block)
+        // the ragged last block: walk backwards in 4-byte groups (sub-streams start 4-byte aligned relative to the block)
         for (uint32_t i = len; i > 0;) {
             const uint32_t take = ((i & 3u) ? (i & 3u) : 4u);
             const uint32_t base = i - take;
             uint32_t w = 0;
             if (take == 4 && ((((uintptr_t)(src + a + base)) & 3u) == 0)) w = *reinterpret_cast<const uint32_t *>(src + a + base);
             else for (uint32_t k = 0; k < take; ++k) w |= (uint32_t)src[a + base + k] << (8 * k);
-            for (int k = (int)take - 1; k >= 0; --k) step((w >> (8 * k)) & 0xFFu);
+            for (int k = (int)take - 1; k >= 0; --k) { step(s_tab[(w >> (8 * k)) & 0xFFu]); drain(); }
             i = base;
         }
     }
-    if (nacc) payload[widx] = (uint32_t)acc;
-    const uint32_t mybits = bits, final_t = x - N;
-    const uint32_t nwords = (bits + 31u) >> 5;
+    const uint32_t mybits = wcnt * 32u + nacc, final_t = x - N;
+    if (nacc) put((uint32_t)acc);                              // (pad bits zero: the accumulator only ever holds real bits)
+    const uint32_t nwords = wcnt;
+    for (uint32_t k = nwords & ~15u; k < nwords; ++k) mine[k] = s_win[(k & 15u) * 64u + lane];       // the last, partial window
     uint32_t inc = nwords;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += v; }
-    const uint32_t word_off = inc - nwords;
     const uint32_t total_words = __shfl(inc, 63);
     if (lane < S) {
         states[2 * lane] = (uint8_t)final_t; states[2 * lane + 1] = (uint8_t)(final_t >> 8);
         lens[4 * lane] = (uint8_t)mybits; lens[4 * lane + 1] = (uint8_t)(mybits >> 8);
         lens[4 * lane + 2] = (uint8_t)(mybits >> 16); lens[4 * lane + 3] = (uint8_t)(mybits >> 24);
     }
-    if (lane == 0) rec_bits[b] = 8ull * ((uint64_t)hdr + states_bytes + 4ull * S + 4ull * total_words);
-    // close the gaps: sub-stream l moves from l * lstr down to its prefix offset (never up, never past the next source)
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    for (uint32_t l = 1; l < S; ++l) {
-        const uint32_t cnt = __shfl(nwords, l), dsto = __shfl(word_off, l), srco = l * lstr;
-        if (dsto == srco) continue;
-        for (uint32_t k0 = 0; k0 < cnt; k0 += 64) {
-            const uint32_t k = k0 + lane;
-            uint32_t v = 0;
-            if (k < cnt) v = payload[srco + k];
-            if (k < cnt) payload[dsto + k] = v;
-        }
+    if (lane == 0) {
+        rec_fixed[b] = hdr + states_bytes + 4u * S;
+        rec_bits[b] = 8ull * ((uint64_t)hdr + states_bytes + 4ull * S + 4ull * total_words);
     }
 }
 
-// one wave per block: lane i decodes sub-stream i forwards, reading its bits backwards
+// one wave per block: lane i decodes sub-stream i forwards, reading its bits backwards.
+// Round 3's form fetched 62 GB per 10^9 decoded bytes (profiles/pmc_traffic_fse.json): two dependent dword loads per SYMBOL from
+// a lane-private address (64 cache lines per wave instruction, no reuse left in a thrashed L1) and 4-byte stores at a 1 KiB
+// stride.  Now a lane takes a whole 128-byte line of its sub-stream into an LDS window at once (the line is fetched once; the
+// bit reader is a 64-bit register refilled a dword at a time from the window), one packed table entry per state
+// {bits, base of the next state, symbol} replaces two LDS reads on the chain, and 64 decoded bytes leave as four back-to-back
+// 16-byte stores (two full sectors).
 __global__ __launch_bounds__(64)
 void k_fse_decode(const uint8_t *__restrict__ packed, uint64_t packed_bytes, const uint64_t *__restrict__ offsets, FseP P,
                   uint8_t *__restrict__ out, uint64_t n_total, uint32_t *__restrict__ err)
 {
     __shared__ uint32_t s_cnt[256], s_cum[256], s_fill[256];
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];   // next[N] u16, sub[N] u16, symat[N] u8
-    uint16_t *s_next = reinterpret_cast<uint16_t *>(s_dyn);
-    uint16_t *s_sub = s_next + (1u << P.L);
-    uint8_t  *s_symat = s_dyn + 4 * (1u << P.L);
+    __shared__ uint32_t s_in[32 * 64];                               // word j of lane l's 128-byte line at j * 64 + l
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];   // dec[N] u32, next[N] u16, symat[N] u8
+    uint32_t *s_dec = reinterpret_cast<uint32_t *>(s_dyn);            // nb | (y << nb) - N  << 4 | symbol << 20
+    uint16_t *s_next = reinterpret_cast<uint16_t *>(s_dyn + 4 * (1u << P.L));
+    uint8_t  *s_symat = s_dyn + 6 * (1u << P.L);
     const uint32_t lane = threadIdx.x;
     const uint64_t b = blockIdx.x;
     const uint64_t off = b * (uint64_t)P.block;
@@ -337,14 +364,17 @@ void k_fse_decode(const uint8_t *__restrict__ packed, uint64_t packed_bytes, con
     if (bad) { if (lane == 0) atomicOr(err, 1u); return; }
     __builtin_amdgcn_wave_barrier();
     fse_build_tables(s_cnt, L, P.spread, s_cum, s_symat, s_next, s_fill);
-    // sub-state of every position: y = cnt[s] + rank  <=>  next[cum[s] + rank] = N + u
+    // one entry per state u: sub-state y = cnt[s] + rank  <=>  next[cum[s] + rank] = N + u;  nb = L - floor(log2 y);
+    // the next state is (y << nb) - N + the nb bits read
     for (uint32_t idx = lane; idx < N; idx += 64) {
         // which symbol owns slot idx of `next`: the s with cum[s] <= idx < cum[s] + cnt[s]
         uint32_t lo = 0, hi = 255;
         while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (s_cum[mid] <= idx) lo = mid; else hi = mid - 1; }
         while (s_cnt[lo] == 0) --lo;
         const uint32_t u = (uint32_t)s_next[idx] - N;
-        s_sub[u] = (uint16_t)(s_cnt[lo] + (idx - s_cum[lo]));
+        const uint32_t y = s_cnt[lo] + (idx - s_cum[lo]);
+        const uint32_t nb = L - (31u - (uint32_t)__builtin_clz(y));
+        s_dec[u] = nb | (((y << nb) - N) << 4) | (lo << 20);
     }
     __builtin_amdgcn_wave_barrier();
     const uint32_t hdr = 32u + 2u * (nsym + (nsym & 1u));
@@ -370,35 +400,63 @@ void k_fse_decode(const uint8_t *__restrict__ packed, uint64_t packed_bytes, con
     for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(winc, o); if (lane >= (uint32_t)o) winc += v; }
     if (__shfl(winc, 63) > payload_words) bad = true;                          // the sub-streams must fit the record
     if (__ballot(bad) != 0ull) { if (lane == 0) atomicOr(err, 1u); return; }
-    const uint32_t *w = payload + (winc - nwords);
-    uint32_t pos = nbits;
+    const uint32_t *w = payload + (winc - nwords);                             // this lane's words [0, nwords): nothing else is ever read
+    // ---- the bit reader: stream words come through the lane's LDS line, whole 128-byte lines (absolute alignment) at a time
+    const uint32_t wbase = (uint32_t)((reinterpret_cast<uintptr_t>(w) >> 2) & 31u);      // w[k] sits in line (wbase + k) >> 5 of the lane
+    uint32_t cur_line = 0xFFFFFFFFu;
+    auto word_at = [&](uint32_t k) -> uint32_t {                               // k < nwords
+        const uint32_t q = wbase + k, ln = q >> 5;
+        if (ln != cur_line) {
+            cur_line = ln;
+            // words of this line that belong to the lane: q' in [ln * 32, ln * 32 + 32) with 0 <= q' - wbase < nwords
+#pragma unroll
+            for (uint32_t j = 0; j < 32; ++j) {
+                const uint32_t qq = ln * 32u + j;
+                uint32_t v = 0;
+                if (qq >= wbase && qq - wbase < nwords) v = w[qq - wbase];
+                s_in[j * 64u + lane] = v;
+            }
+        }
+        return s_in[(q & 31u) * 64u + lane];
+    };
+    uint64_t bw = 0; uint32_t have = 0; int32_t nxt = (int32_t)nwords - 1;      // bw: the `have` stream bits just below the read position
+    if (nwords) {
+        const uint32_t top = nbits - 32u * (nwords - 1u);                     // 1..32 bits in the last word
+        const uint32_t v = word_at(nwords - 1u);
+        bw = top >= 32 ? v : (v & ((1u << top) - 1u));
+        have = top; nxt = (int32_t)nwords - 2;
+    }
     uint8_t *dst = out + off + a;
-    uint32_t pack = 0;
-    for (uint32_t i = 0; i < len; ++i) {
-        if (tstate >= N) { bad = true; break; }
-        const uint32_t y = s_sub[tstate];
-        const uint32_t nb = L - (31u - (uint32_t)__builtin_clz(y));
-        if (pos < nb) { bad = true; break; }
-        pos -= nb;
-        uint32_t v = 0;
-        if (nb) {
-            const uint32_t wi = pos >> 5, sh = pos & 31u;
-            uint64_t two = w[wi];
-            if (sh + nb > 32) two |= (uint64_t)w[wi + 1] << 32;
-            v = (uint32_t)(two >> sh) & ((1u << nb) - 1u);
+    auto sym_step = [&]() -> uint32_t {                                        // returns the symbol; sets bad on a malformed stream
+        if (tstate >= N) { bad = true; return 0u; }
+        if (have < 12u && nxt >= 0) { bw = (bw << 32) | word_at((uint32_t)nxt); have += 32; --nxt; }
+        const uint32_t e = s_dec[tstate];
+        const uint32_t nb = e & 15u;
+        if (have < nb) { bad = true; return 0u; }
+        have -= nb;
+        const uint32_t v = (uint32_t)(bw >> have) & ((1u << nb) - 1u);
+        tstate = ((e >> 4) & 0xFFFFu) + v;
+        return e >> 20;
+    };
+    uint32_t i = 0;
+    if ((((uintptr_t)dst) & 15u) == 0) {
+        for (; i + 64u <= len && !bad; i += 64u) {
+            uint32_t o16[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                uint32_t pk = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pk |= sym_step() << (8 * k);
+                o16[q] = pk;
+            }
+            if (bad) break;
+            uint4 *d4 = reinterpret_cast<uint4 *>(dst + i);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) d4[q] = make_uint4(o16[4 * q], o16[4 * q + 1], o16[4 * q + 2], o16[4 * q + 3]);
         }
-        pack |= (uint32_t)s_symat[tstate] << (8 * (i & 3u));
-        if ((i & 3u) == 3u) {
-            if ((((uintptr_t)(dst + i - 3)) & 3u) == 0) *reinterpret_cast<uint32_t *>(dst + i - 3) = pack;
-            else { dst[i - 3] = (uint8_t)pack; dst[i - 2] = (uint8_t)(pack >> 8); dst[i - 1] = (uint8_t)(pack >> 16); dst[i] = (uint8_t)(pack >> 24); }
-            pack = 0;
-        }
-        tstate = (y << nb) + v - N;
     }
-    if (!bad && len) {
-        for (uint32_t k = len & ~3u; k < len; ++k) dst[k] = (uint8_t)(pack >> (8 * (k & 3u)));
-        if (tstate != 0 || pos != 0) bad = true;              // must land on the encoder's start state
-    }
+    for (; i < len && !bad; ++i) dst[i] = (uint8_t)sym_step();                 // ragged blocks, unaligned output
+    if (!bad && len && (tstate != 0 || have != 0 || nxt >= 0)) bad = true;     // must land on the encoder's start state with every bit used
     if (bad) atomicOr(err, 1u);
 }
 
@@ -440,14 +498,38 @@ void k_fse_scan(const uint64_t *__restrict__ bits, uint64_t nblocks, uint64_t *_
 }
 
 __global__ __launch_bounds__(256)
-void k_fse_pack(const uint8_t *__restrict__ recs, uint64_t rec_stride, const uint64_t *__restrict__ offsets,
-                uint64_t nblocks, uint32_t *__restrict__ out)
+void k_fse_pack(const uint8_t *__restrict__ scr, uint64_t scr_stride, const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ rec_fixed,
+                FseP P, uint32_t *__restrict__ out)
 {
-    // one workgroup per block record: straight dword copy (records and offsets are 4-byte aligned)
+    // one workgroup per block: the fixed part of the record is copied, then every sub-stream goes from its fixed-stride region of
+    // the scratch record to its place behind the ones before it — the payload's only move (4-byte aligned: records and offsets are)
+    __shared__ uint32_t s_woff[65];
     const uint64_t b = blockIdx.x;
-    const uint64_t o0 = offsets[b] >> 5, o1 = offsets[b + 1] >> 5;
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(recs + b * rec_stride);
-    for (uint64_t i = threadIdx.x; i < o1 - o0; i += 256) out[o0 + i] = src[i];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t fixed = rec_fixed[b], S = P.S;
+    const uint8_t *rec = scr + b * scr_stride;
+    uint32_t *dst = out + (offsets[b] >> 5);
+    const uint32_t *fsrc = reinterpret_cast<const uint32_t *>(rec);
+    for (uint32_t i = tid; i < fixed / 4u; i += 256) dst[i] = fsrc[i];
+    if (wave == 0) {
+        const uint8_t *lens = rec + fixed - 4u * S;
+        uint32_t nw = 0;
+        if (lane < S) nw = ((lens[4 * lane] | ((uint32_t)lens[4 * lane + 1] << 8) | ((uint32_t)lens[4 * lane + 2] << 16) | ((uint32_t)lens[4 * lane + 3] << 24)) + 31u) >> 5;
+        uint32_t inc = nw;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += v; }
+        s_woff[lane] = inc - nw;
+        if (lane == 63) s_woff[64] = inc;
+    }
+    __syncthreads();
+    const uint32_t lstr = fse_lane_stride_words(P.block, S, P.L);
+    const uint32_t *pay = reinterpret_cast<const uint32_t *>(rec + FSE_SCR_FIXED);
+    uint32_t *pdst = dst + fixed / 4u;
+    for (uint32_t l = wave; l < S; l += 4) {
+        const uint32_t w0 = s_woff[l], cnt = s_woff[l + 1] - w0;
+        const uint32_t *ps = pay + (size_t)l * lstr;
+        for (uint32_t k = lane; k < cnt; k += 64) pdst[w0 + k] = ps[k];
+    }
 }
 
 // =============================================================================================
@@ -483,19 +565,22 @@ extern "C" mi_status mi_fse_encode_dev(mi_ctx *ctx, const mi_fse_params *p, cons
     const uint64_t stride = mi_fse_block_bound(p);
     if (cap_bytes < nblocks * stride) return MI_ERR_CAPACITY;
     if (nblocks == 0) { MI_HIP(ctx, hipMemsetAsync(d_offsets, 0, 8, s)); return MI_OK; }
-    st = mi_ws_reserve(ctx, nblocks * stride + (nblocks + 2) * 8 + 4096);
+    // scratch records: fixed part + 64 lanes at a fixed stride (fse.hip header); 256-byte aligned stride
+    const uint64_t scr_stride = mi_align_up((size_t)FSE_SCR_FIXED + (size_t)FSE_MAX_S * fse_lane_stride_words(P.block, P.S, P.L) * 4u, 256);
+    st = mi_ws_reserve(ctx, nblocks * scr_stride + (nblocks + 2) * 12 + 8192);
     if (st) return st;
     mi_carver cv(ctx->ws);
-    uint8_t *recs = cv.take<uint8_t>(nblocks * stride);
+    uint8_t *recs = cv.take<uint8_t>(nblocks * scr_stride);
     uint64_t *bits = cv.take<uint64_t>(nblocks + 1);
+    uint32_t *fixed = cv.take<uint32_t>(nblocks + 1);
     {
         mi_prof_scope pr(ctx, "k_fse_encode", s, n);
-        hipLaunchKernelGGL(k_fse_encode, dim3((unsigned)nblocks), dim3(64), 3u << P.L, s, d_in, n, P, recs, stride, bits);
+        hipLaunchKernelGGL(k_fse_encode, dim3((unsigned)nblocks), dim3(64), 3u << P.L, s, d_in, n, P, recs, scr_stride, bits, fixed);
     }
     hipLaunchKernelGGL(k_fse_scan, dim3(1), dim3(1024), 0, s, bits, nblocks, d_offsets);
     {
         mi_prof_scope pr(ctx, "k_fse_pack", s, n);
-        hipLaunchKernelGGL(k_fse_pack, dim3((unsigned)nblocks), dim3(256), 0, s, recs, stride, d_offsets, nblocks,
+        hipLaunchKernelGGL(k_fse_pack, dim3((unsigned)nblocks), dim3(256), 0, s, recs, scr_stride, d_offsets, fixed, P,
                            reinterpret_cast<uint32_t *>(d_packed));
     }
     MI_HIP(ctx, hipGetLastError());
@@ -516,7 +601,7 @@ extern "C" mi_status mi_fse_decode_dev(mi_ctx *ctx, const mi_fse_params *p, cons
     if (!err) return MI_ERR_HIP;
     {
         mi_prof_scope pr(ctx, "k_fse_decode", s, n);
-        hipLaunchKernelGGL(k_fse_decode, dim3((unsigned)nblocks), dim3(64), 5u << P.L, s, d_packed, packed_bytes, d_offsets, P, d_out, n, err);
+        hipLaunchKernelGGL(k_fse_decode, dim3((unsigned)nblocks), dim3(64), 7u << P.L, s, d_packed, packed_bytes, d_offsets, P, d_out, n, err);
     }
     uint32_t h_err = 0;
     MI_HIP(ctx, hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, s));

@@ -21,10 +21,19 @@
 #endif
 #define LZ2_NWAVES    (LZ2_THREADS / 64)
 #ifndef LZ2_PARTBITS
-#define LZ2_PARTBITS  5                     // parts per block <= 2^LZ2_PARTBITS (one radix digit of stage 1)
+#define LZ2_PARTBITS  7                     // parts per block <= 2^LZ2_PARTBITS (one radix digit of stage 1)
 #endif
 #define LZ2_MAXPARTS  (1u << LZ2_PARTBITS)
 static_assert(LZ2_CAP % LZ2_THREADS == 0 && LZ2_CAP_S % LZ2_THREADS == 0 && LZ2_CAP_S <= LZ2_CAP, "entries per thread must be whole");
+// The greedy cuts of k_lz2_partition can never run out of part numbers.  A part ends at the LAST certified group that keeps it
+// within LZ2_CAP_S entries and (2^20-bucket tables) within 2^16 homes; so for two consecutive parts either their entries
+// exceed LZ2_CAP_S together or their homes exceed 2^16 together — otherwise the first would have been cut where the second
+// ends.  Disjoint pairs of the first kind: at most LZ_MAX_BLOCK / LZ2_CAP_S; of the second kind: at most T / 2^16 = 16 (none
+// for larger tables).  Round 3 had 32 part numbers for ~27 parts of text and a silent exit to the fallback pipeline (a tenth
+// of the speed) at the 33rd; an A/B build with parts of 2048 entries took that exit on every block.
+static_assert(2u * (LZ_MAX_BLOCK / LZ2_CAP_S + 1u + 16u) + 2u <= LZ2_MAXPARTS, "a block could need more parts than the partition can number");
+#define LZ2_GRID_PARTS 32u                  // k_lz2_find's grid covers this many parts per block (text: 26-27); parts listed beyond
+                                            // the grid (never seen on text) are taken by the looping k_lz2_find_wide
 #ifndef LZ2_BIG
 #define LZ2_BIG       8u                    // clusters of at least this many entries leave k_lz2_find (8 or 16: the register replay holds < 16)
 #endif

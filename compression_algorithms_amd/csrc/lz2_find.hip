@@ -664,7 +664,9 @@ __device__ __forceinline__ void lz2_find_part(const uint8_t *__restrict__ in, ui
 __global__ __launch_bounds__(LZ2_THREADS)
 void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scratch sc, uint64_t block0)
 {
-    const uint32_t nwork = *sc.work_count;
+    // the grid is a multiple of 8 (lz2_stage_find) and takes the first gridDim.x listed parts; what a batch lists beyond it
+    // (more than LZ2_GRID_PARTS parts per block on average: not seen on any corpus) is k_lz2_find_wide's
+    const uint32_t listed = *sc.work_count, nwork = listed < gridDim.x ? listed : gridDim.x;
     const uint32_t cpx = (nwork + 7u) >> 3, item_idx = (blockIdx.x & 7u) * cpx + (blockIdx.x >> 3);
     if ((blockIdx.x >> 3) >= cpx || item_idx >= nwork) return;
     lz2_find_part<LZ2_CAP_S>(in, n_total, P, sc, block0, sc.work[item_idx]);
@@ -672,11 +674,13 @@ void k_lz2_find(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scra
 
 // the parts above LZ2_CAP_S entries (rare: listed from the end of the work array backwards): a small grid that loops
 __global__ __launch_bounds__(LZ2_THREADS)
-void k_lz2_find_wide(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scratch sc, uint64_t block0)
+void k_lz2_find_wide(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz2Scratch sc, uint64_t block0, uint32_t covered)
 {
-    const uint32_t nwide = sc.work_count[1];
-    for (uint32_t k = blockIdx.x; k < nwide; k += gridDim.x) {
-        lz2_find_part<LZ2_CAP>(in, n_total, P, sc, block0, sc.work[sc.work_slots - 1u - k]);
+    // `covered` = what k_lz2_find's grid took from the front list; the rest of that list is done here too (a part of <= LZ2_CAP_S
+    // entries fits the wide instance)
+    const uint32_t nwide = sc.work_count[1], listed = sc.work_count[0], rest = listed > covered ? listed - covered : 0u;
+    for (uint32_t k = blockIdx.x; k < nwide + rest; k += gridDim.x) {
+        lz2_find_part<LZ2_CAP>(in, n_total, P, sc, block0, k < nwide ? sc.work[sc.work_slots - 1u - k] : sc.work[covered + (k - nwide)]);
         __syncthreads();
     }
 }
@@ -920,17 +924,20 @@ mi_status lz2_stage_partition(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, ui
 mi_status lz2_stage_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
                          const Lz2Scratch &sc, hipStream_t s)
 {
-    // the partition cuts at most LZ2_MAXPARTS parts per block (greedy, data dependent: ~26 for a full block) and lists them
-    const uint32_t parts = P.block / 64u + 1u < LZ2_MAXPARTS ? P.block / 64u + 1u : LZ2_MAXPARTS;
+    // the partition lists a block's parts (greedy, data dependent: 26-27 for a full block of text); the grid covers
+    // LZ2_GRID_PARTS per block, rounded up to the 8 XCD slices of the kernel's workgroup mapping (a grid that is not a multiple
+    // of 8 would leave items of the last row unassigned: ADVICE r3), the looping wide kernel takes whatever lies beyond
+    const uint32_t parts = P.block / 64u + 1u < LZ2_GRID_PARTS ? P.block / 64u + 1u : LZ2_GRID_PARTS;
+    const uint32_t grid = (parts * nb + 7u) & ~7u;
     {
         mi_prof_scope p(ctx, "k_lz2_find", s, (uint64_t)nb * P.block);
-        hipLaunchKernelGGL(k_lz2_find, dim3(parts * nb), dim3(LZ2_THREADS), 0, s, d_in, n, P, sc, block0);
+        hipLaunchKernelGGL(k_lz2_find, dim3(grid), dim3(LZ2_THREADS), 0, s, d_in, n, P, sc, block0);
     }
     {
         // parts of 2561..4096 entries (none in text): 256 looping workgroups, gone at once when the list is empty (timed apart: an
         // empty launch still waits for 76 KiB of LDS behind the kernel above)
         mi_prof_scope p(ctx, "k_lz2_find_wide", s, (uint64_t)nb * P.block);
-        hipLaunchKernelGGL(k_lz2_find_wide, dim3(256), dim3(LZ2_THREADS), 0, s, d_in, n, P, sc, block0);
+        hipLaunchKernelGGL(k_lz2_find_wide, dim3(256), dim3(LZ2_THREADS), 0, s, d_in, n, P, sc, block0, grid);
     }
     MI_HIP(ctx, hipGetLastError());
     return MI_OK;

@@ -25,7 +25,8 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     __shared__ __attribute__((aligned(16))) uint8_t s_in[LZ_MAX_BLOCK + LZ_TAIL + 16];
     __shared__ uint32_t s_grp[LZ2_NG];               // counts -> inclusive prefix; later the staging area
     __shared__ uint32_t s_safe[LZ2_NG / 32];
-    __shared__ uint32_t s_cnt[17][LZ2_MAXPARTS];               // 5-bit digits only (<= 32 parts): 2 KiB, not 16 — this kernel shares CUs with the replay kernels
+    // (the radix pass's counters — [17][LZ2_MAXPARTS], 8.5 KiB — live in s_gpart further down, which is dead by then: this kernel
+    //  shares CUs with the replay kernels and every KiB it leaves is a wave of theirs)
     __shared__ uint64_t s_scan64[18];
     __shared__ uint32_t s_scan32[18];
     __shared__ uint32_t s_thr[LZ2_MAXPARTS + 1];     // part k = home' in [s_thr[k], s_thr[k+1])
@@ -171,12 +172,17 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
                 if (n - cur <= LZ2_CAP) break;                                     // the rest is one wide part
                 gr = cut_below(cur + LZ2_CAP);
             }
-            if (gr < (int32_t)glo || k + 2 > LZ2_MAXPARTS) { bad = true; break; }     // one cluster larger than stage 2 can hold
+            // no certified cut within LZ2_CAP entries: one cluster larger than stage 2 can hold.  (k + 2 > LZ2_MAXPARTS cannot
+            // happen — the static_assert in lz2.h has the argument — and stays as a guard.)
+            if (gr < (int32_t)glo || k + 2 > LZ2_MAXPARTS) { bad = true; break; }
             cur = cum_incl((uint32_t)gr);
             glo = (uint32_t)gr + 1u;
             ++k;
             if (lane == 0) s_thr[k] = glo << gshift;
         }
+#ifdef MI_TEST_HOOKS                                       /* lib_test only (MI_LZ_TEST_FORCE_FALLBACK=1): every block takes the exit above, so a whole */
+        if (P.flags & LZP_FORCE_FB) bad = true;                /* batch of ordinary text runs through the fallback chain (tests/test_fallback_chain_gpu.py) */
+#endif
         if (lane == 0) {
             s_thr[k + 1] = T;                           // the last part takes everything up to the cut
             s_K = k + 1;
@@ -211,7 +217,10 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
         mt->fallback = fb ? 1u : 0u;
         if (fb) { const uint32_t k = atomicAdd(sc.fallback_count, 1u); sc.fallback_list[k] = lb; }
     }
-    if (s_flag != 0 || (P.deflate && no_safe)) return;
+    if (s_flag != 0 || (P.deflate && no_safe)) {
+        if (tid == 0 && P.stats) atomicAdd((unsigned long long *)&P.stats[0], 1ull);      // mi_lz_path_stats: blocks sent to the fallback
+        return;
+    }
     // this block's parts join the batch's work list: stage 2 runs one workgroup per LISTED part.  (A grid of
     // blocks x "most parts a block can have" interleaved a third of empty workgroups with the real ones; each still had to
     // be given stage 2's 67 KiB of LDS before it could leave: 14.65 -> 11.4 GB/s.)
@@ -223,6 +232,7 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
             for (uint32_t k = 0; k < K; ++k) s_wrank[k] = (uint8_t)(mt->part_count[k] <= LZ2_CAP_S ? ns++ : nw++);
             s_wbase = atomicAdd(sc.work_count, ns);
             s_wbase2 = nw ? atomicAdd(sc.work_count + 1, nw) : 0u;
+            if (nw && P.stats) atomicAdd((unsigned long long *)&P.stats[1], (unsigned long long)nw);       // mi_lz_path_stats: wide parts
         }
         __syncthreads();
         if (tid < (int)K) {
@@ -239,7 +249,9 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     //      time through LDS paid the pass's fixed costs eight times: 7.5 -> see DESIGN.md for the measurement.)
     uint16_t *plist = sc.plist + (size_t)lb * LZ_MAX_BLOCK;
     uint8_t  *part_in = reinterpret_cast<uint8_t *>(s_grp);             // [65536] part of every position; the group array is dead now
-    __shared__ uint8_t s_gpart[LZ2_NG];                                 // part of every rotated group (part boundaries are group boundaries)
+    __shared__ __attribute__((aligned(16))) uint8_t s_gpart[LZ2_NG];   // part of every rotated group (part boundaries are group boundaries)
+    static_assert(17u * LZ2_MAXPARTS * 4u <= LZ2_NG, "the radix counters reuse s_gpart");
+    uint32_t (*s_cnt)[LZ2_MAXPARTS] = reinterpret_cast<uint32_t (*)[LZ2_MAXPARTS]>(s_gpart);      // once part_in is tabulated
     {
         // sixteen consecutive groups per thread: one binary search for the first, then a walk along the thresholds
         constexpr uint32_t GPT = LZ2_NG / 1024;

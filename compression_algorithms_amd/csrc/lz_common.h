@@ -27,9 +27,11 @@ struct LzP {
     uint32_t wbits, lbits, tbits, deflate, block;
     uint32_t flags;        // LZP_ARANK: the context's self-check found LDS returning atomics lane-ordered (ctx.hip)
     uint32_t *order_flag;  // host-visible word of the context: a consumer that finds a sort out of order sets it (below)
+    uint64_t *stats;       // device counters of the context (mi_lz_path_stats): [0] blocks sent to the fallback pipeline, [1] wide parts
 };
 #define LZP_ARANK 1u
 #define LZP_BREAK 2u       // TEST BUILD ONLY (-DMI_TEST_HOOKS, MI_LZ_TEST_BREAK_RANK=1): the scatter swaps the ranks of neighbouring lanes with equal digits
+#define LZP_FORCE_FB 4u    // TEST BUILD ONLY (-DMI_TEST_HOOKS, MI_LZ_TEST_FORCE_FALLBACK=1): the partition hands EVERY block to the fallback pipeline
 
 // The stable radix scatter under LZP_ARANK ranks by the order in which ONE returning LDS add serves the lanes that hit one
 // address — lane order on gfx950, measured (scripts/micro/lds_atomic_order.hip) and probed once per context (ctx.hip), but
@@ -49,7 +51,8 @@ static inline LzP lz_params_of(mi_ctx *ctx, const mi_lz_params *p)
     mi_order_poll(ctx);                                             // a violation reported by an earlier call switches to ballots
     uint32_t fl = ctx->lds_rank_ok ? LZP_ARANK : 0u;
     if (fl && ctx->test_break_rank) fl |= LZP_BREAK;
-    return LzP{p->wbits, p->lbits, p->tbits, p->deflate, p->block, fl, ctx->d_order};
+    if (ctx->test_force_fb) fl |= LZP_FORCE_FB;
+    return LzP{p->wbits, p->lbits, p->tbits, p->deflate, p->block, fl, ctx->d_order, ctx->d_stats};
 }
 
 // per-block record written by k_lz_sort_home

@@ -632,21 +632,29 @@ static mi_status lz_encode_impl(mi_ctx *ctx, const mi_lz_params *p, const uint8_
 #else
     const int skip = 0;
 #endif
+    // The fallback chains of consecutive batches go to two streams WHEN the input lives in the fallback: their kernels are long
+    // serial chains on few workgroups and overlap well — pages 1.72 -> 2.16, runs 1.65 -> 2.77 GB/s on 10^8 B.  On text a second
+    // stream costs 7 % even idle (20.4 -> 19.1 GB/s, whatever GPU_MAX_HW_QUEUES says), so it exists only while the hint says so.
+    // The hint (ctx->h_order[1]) is the fallback count of the last batch the GPU has FINISHED — every batch of a call is queued
+    // before the first one runs, so in practice it is what an EARLIER call left: a first call on non-text input runs on one
+    // fallback stream and small grids, a text call right after such input still carries the second stream (bench.py reports the
+    // adversarial families warm AND cold).  Decided once per call; the stream is created here and released here — when a later
+    // call finds the hint low and the stream idle (hipStreamQuery: no host wait) — or with the context, never inside the loop
+    // (stream create/destroy per batch, skipped on early returns, may block in hipStreamDestroy).
+    const bool fb_busy = overlap && ctx->h_order && __atomic_load_n(ctx->h_order + 1, __ATOMIC_RELAXED) > 8u;     // (text: 0)
+    if (fb_busy && !ctx->fb2) {
+        int lo_ = 0, hi_ = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo_, &hi_);
+        if (hipStreamCreateWithPriority(&ctx->fb2, hipStreamNonBlocking, lo_) != hipSuccess) { (void)hipGetLastError(); ctx->fb2 = nullptr; }
+    } else if (!fb_busy && ctx->fb2) {
+        if (hipStreamQuery(ctx->fb2) == hipSuccess) { (void)hipStreamDestroy(ctx->fb2); ctx->fb2 = nullptr; }
+        else (void)hipGetLastError();                     // still draining an earlier call's chains: try again next time
+    }
     uint64_t batch = 0, prev_b0 = 0; uint32_t prev_nb = 0; int prev_k = -1;
     for (uint64_t b0 = 0; b0 < nblocks; b0 += nbmax, ++batch) {
         const uint32_t nb = (uint32_t)((nblocks - b0) < nbmax ? (nblocks - b0) : nbmax);
         const int k = (int)(batch % (uint64_t)nsets);
         if (overlap && batch >= (uint64_t)nsets) MI_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_done[k], 0));   // set k is free again
-        // The fallback chains of consecutive batches go to two streams WHEN the input lives in the fallback (the count the
-        // previous batch left, ctx->h_order[1]): their kernels are long serial chains on few workgroups and overlap well —
-        // pages 1.72 -> 2.16, runs 1.65 -> 2.77 GB/s on 10^8 B.  On text the second stream stays idle: with the (empty) chains
-        // of two batches in flight at once the step was 7 % slower (20.4 -> 19.1 GB/s, whatever GPU_MAX_HW_QUEUES says).
-        const bool fb_busy = overlap && ctx->h_order && __atomic_load_n(ctx->h_order + 1, __ATOMIC_RELAXED) > 8u;     // (text: 0)
-        if (fb_busy && !ctx->fb2) {
-            int lo_ = 0, hi_ = 0;
-            (void)hipDeviceGetStreamPriorityRange(&lo_, &hi_);
-            if (hipStreamCreateWithPriority(&ctx->fb2, hipStreamNonBlocking, lo_) != hipSuccess) ctx->fb2 = nullptr;
-        }
         st = lz_find_stage_a(ctx, P, d_in, n, b0, nb, sc[k], sc2[k], s,
                              overlap ? ((batch & 1u) && fb_busy && ctx->fb2 ? ctx->fb2 : ctx->fb) : s, ctx->ev_part[k], ctx->ev_fb[k]);
         if (st) return st;
@@ -672,7 +680,6 @@ static mi_status lz_encode_impl(mi_ctx *ctx, const mi_lz_params *p, const uint8_
         MI_HIP(ctx, hipEventRecord(ctx->ev_fork, sp));
         MI_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_fork, 0));
     }
-    if (ctx->fb2) { (void)hipStreamDestroy(ctx->fb2); ctx->fb2 = nullptr; }      // (released once its work is done: every chain on it was joined through ev_fb)
     MI_HIP(ctx, hipGetLastError());
     return MI_OK;
 }

@@ -177,8 +177,9 @@ void k_lz_sort_home(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, LzS
                     const uint32_t *__restrict__ blist, const uint32_t *__restrict__ bcount)
 {
     const uint32_t count = bcount ? *bcount : nb;          // only the listed blocks when there is a list
-    // how many blocks fell back, left where the host sees it (pinned word behind the order flag): the NEXT batch sizes its
-    // fallback grids by it — no synchronisation, a hint that is one batch old
+    // how many blocks fell back, left where the host sees it (pinned word behind the order flag): LATER launches size their
+    // fallback grids by it — no synchronisation; the batches of one call are all queued before the first runs, so the hint a
+    // call reads is what an earlier call left (lz_emit.hip)
     if (bcount && blockIdx.x == 0 && threadIdx.x == 0 && P.order_flag) P.order_flag[1] = count;
     for (uint32_t bi = blockIdx.x; bi < count; bi += gridDim.x) {
         lz_sort_home_block(in, n_total, P, sc, block0, blist ? blist[bi] : bi);
@@ -1018,8 +1019,9 @@ mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t
     static const bool prof_fb = getenv("MI_LZ_PROF_FALLBACK") != nullptr;      // inputs that live in the fallback (scripts/adv_profile.py)
     if (blist && !prof_fb) ctx->profiling = 0;
     MI_HIP(ctx, hipMemsetAsync(sc.giant_count, 0, 8, s));        // [0] clusters listed, [1] cursor of k_lz_emulate_dom
-    // fallback: few looping workgroups (see LZ_FB_GRID) — unless the previous batch had many blocks here (non-text input): the
-    // count k_lz_sort_home left in pinned memory sizes the grids (pages family: half the chip sat idle behind 128 workgroups)
+    // fallback: few looping workgroups (see LZ_FB_GRID) — unless the last finished batch (in practice: of an earlier call) had
+    // many blocks here (non-text input): the count k_lz_sort_home left in pinned memory sizes the grids (pages family: half the
+    // chip sat idle behind 128 workgroups)
     const uint32_t hint = (blist && ctx->h_order) ? __atomic_load_n(ctx->h_order + 1, __ATOMIC_RELAXED) : 0u;
     const uint32_t fb_want = hint > LZ_FB_GRID ? hint : LZ_FB_GRID;
     const uint32_t fgrid = (blist && nb > fb_want) ? fb_want : nb;

@@ -54,12 +54,23 @@ class LzStream:
     block_bits  int64 tensor [nblocks+1], exclusive prefix of per-block lengths in BITS
     """
 
-    def __init__(self, data, block_bits, n, p):
+    def __init__(self, data, block_bits, n, p, ctx=None, violations_before=0):
         self.data, self.block_bits, self.n, self.p = data, block_bits, n, p
+        self._ctx, self._v0 = ctx, violations_before
+
+    def check_order(self):
+        """mi_codec.h promises that a sort found out of (key, time) order is never silent: the asynchronous encoder cannot
+        say so when it returns, so the first read of its result does — MiError(MI_ERR_UNSTABLE); the context ranks
+        with ballots from then on, encode again."""
+        if self._ctx is not None and self._ctx.order_violations() != self._v0:
+            self._v0 = self._ctx.order_violations()
+            raise _lib.MiError(10, "the encoder that wrote this stream reported a sort out of order")
 
     @property
     def total_bits(self):
-        return int(self.block_bits[-1])
+        t = int(self.block_bits[-1])                       # (synchronises: the encoder has joined torch's stream)
+        self.check_order()
+        return t
 
     @property
     def nbytes(self):
@@ -86,10 +97,11 @@ def compress(data, p, ctx=None):
     cap = bound_bytes(n, p) + 64
     out = torch.empty(cap, dtype=torch.uint8, device=ctx.device)
     bits = torch.zeros(nblocks + 1, dtype=torch.int64, device=ctx.device)
+    v0 = ctx.order_violations()
     st = ctx.L.mi_lz_encode_dev(ctx.h, C.byref(p), C.c_void_p(d_in.data_ptr() if n else 0), n, C.c_void_p(out.data_ptr()), cap,
                                 C.c_void_p(bits.data_ptr()), ctx.stream_ptr())
     _lib.check(st, "mi_lz_encode_dev")
-    return LzStream(out, bits, n, p)
+    return LzStream(out, bits, n, p, ctx, v0)
 
 
 def decompress(stream, ctx=None):
@@ -114,10 +126,11 @@ def compress_h(data, p=None, ctx=None):
     cap = int(ctx.L.mi_deflate_h_bound_bytes(n, C.byref(p))) + 64
     out = torch.empty(cap, dtype=torch.uint8, device=ctx.device)
     bits = torch.zeros(nblocks + 1, dtype=torch.int64, device=ctx.device)
+    v0 = ctx.order_violations()
     st = ctx.L.mi_deflate_h_encode_dev(ctx.h, C.byref(p), C.c_void_p(d_in.data_ptr() if n else 0), n, C.c_void_p(out.data_ptr()),
                                        cap, C.c_void_p(bits.data_ptr()), ctx.stream_ptr())
     _lib.check(st, "mi_deflate_h_encode_dev")
-    return LzStream(out, bits, n, p)
+    return LzStream(out, bits, n, p, ctx, v0)
 
 
 def decompress_h(stream, ctx=None):

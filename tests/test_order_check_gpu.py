@@ -55,6 +55,11 @@ def test_broken_ranking_is_noticed_and_the_context_recovers(shape):
         torch.cuda.synchronize()
         assert ctx.order_violations() >= 1, "the mis-ranked scatter went unnoticed"
         try:
+            first.nbytes                                      # the Python device path: the first read of the result says so (ADVICE r3)
+            raise SystemExit("LzStream did not report the violation")
+        except _lib.MiError as e:
+            assert e.status == 10
+        try:
             ctx.sync()
             raise SystemExit("mi_sync did not report the violation")
         except _lib.MiError as e:
