@@ -32,7 +32,7 @@ struct mi_ctx {
                                         // GPU_MAX_HW_QUEUES — cost the text pipeline 7 % (20.4 -> 19.1 GB/s)
     hipStream_t parse = nullptr;        // third stage: parse / emit / concatenate
 #define MI_SETS 3
-    hipEvent_t  ev_find[MI_SETS] = {}, ev_done[MI_SETS] = {}, ev_part[MI_SETS] = {}, ev_fb[MI_SETS] = {}, ev_replay[MI_SETS] = {};
+    hipEvent_t  ev_find[MI_SETS] = {}, ev_done[MI_SETS] = {}, ev_part[MI_SETS] = {}, ev_fb[MI_SETS] = {}, ev_replay[MI_SETS] = {}, ev_wide[MI_SETS] = {};
     hipEvent_t  ev_fork = nullptr;
     int         last_hip = 0;
     int         profiling = 0;

@@ -84,7 +84,11 @@ mi_status mi_ctx_create(mi_ctx **out, int device)
     {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // lo = least urgent
-        bool ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
+        // stage B's stream: MI_SIDE_PRIO=lo creates it at the least urgent priority (A/B: partition + find are the chain the
+        // pipeline is bound by, and the replay kernels' small waves fragment the LDS their workgroups wait for)
+        const char *sp_ = getenv("MI_SIDE_PRIO");
+        bool ok = (sp_ && sp_[0] == 'l') ? hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, lo) == hipSuccess
+                                         : hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipStreamCreateWithPriority(&c->fb, hipStreamNonBlocking, lo) == hipSuccess;
         // stage C at raised priority: k_lz_parse_emit wants a whole CU's LDS and only gets one when all three workgroups of
         // k_lz2_find on it have left — first in line it spans 4.5 ms per launch instead of 6.4 and the step is 0.6 % shorter
@@ -96,6 +100,7 @@ mi_status mi_ctx_create(mi_ctx **out, int device)
     }
     for (int i = 0; i < MI_SETS; ++i) {
         hipEventCreateWithFlags(&c->ev_replay[i], hipEventDisableTiming);
+        hipEventCreateWithFlags(&c->ev_wide[i], hipEventDisableTiming);
         hipEventCreateWithFlags(&c->ev_part[i], hipEventDisableTiming);
         hipEventCreateWithFlags(&c->ev_fb[i], hipEventDisableTiming);
         hipEventCreateWithFlags(&c->ev_find[i], hipEventDisableTiming);
@@ -138,6 +143,7 @@ void mi_ctx_destroy(mi_ctx *c)
     if (c->parse) hipStreamDestroy(c->parse);
     for (int i = 0; i < MI_SETS; ++i) {
         if (c->ev_replay[i]) hipEventDestroy(c->ev_replay[i]);
+        if (c->ev_wide[i]) hipEventDestroy(c->ev_wide[i]);
         if (c->ev_find[i]) hipEventDestroy(c->ev_find[i]);
         if (c->ev_done[i]) hipEventDestroy(c->ev_done[i]);
         if (c->ev_part[i]) hipEventDestroy(c->ev_part[i]);

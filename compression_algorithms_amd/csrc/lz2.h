@@ -80,7 +80,8 @@ struct Lz2BigDesc {
 };
 
 struct Lz2Scratch {
-    uint16_t     *plist;        // [nb][65536] positions, grouped by part, time order inside a part
+    uint8_t      *partmap;      // [nb][65536] part of every position (0xFF past the block's end): written by the partition, scanned by stage 2
+    uint16_t     *plist;        // [nb][65536] positions, grouped by part, time order inside a part: written by stage 2 for the parse
     uint16_t     *cand;         // [nb][65536] find() result aligned with plist (own position = pending: see bigcand)
     Lz2BlockMeta *meta;         // [nb]
     uint32_t     *fallback_count, *fallback_list;    // blocks the first pipeline has to do

@@ -169,7 +169,7 @@ __device__ __forceinline__ void lz2_find_part(const uint8_t *__restrict__ in, ui
     const uint32_t nblk = mt->n;
     const uint8_t *src = in + off;
     const uint32_t T = 1u << P.tbits, Tmask = T - 1u, W = 1u << P.wbits;
-    const uint16_t *plist = sc.plist + (size_t)lb * LZ_MAX_BLOCK + pstart;
+    uint16_t *plist = sc.plist + (size_t)lb * LZ_MAX_BLOCK + pstart;       // written here (the parse reads position / candidate lists)
     (void)n_total;
     // keys of the home sort are relative to the part's first home; a part of a 2^20-bucket table spans < 2^16 homes, so two
     // 8-bit passes are enough (three otherwise).  For two passes the digits are COUNTED where they are in hand anyway: the first
@@ -185,16 +185,59 @@ __device__ __forceinline__ void lz2_find_part(const uint8_t *__restrict__ in, ui
     for (uint32_t i = tid; i < 256u * RST; i += LZ2_THREADS) { cntA[i] = 0; cntB[i] = 0; }
 
     bool viol = false;
-    // ---- gather: positions (coalesced) and their words (4 unaligned bytes each from the block; bytes
-    //      past the block end read as zero, the parity definition of the reference's over-read)
+    // ---- this part's positions, in time order: picked out of the block's part map (one byte per position, written by the
+    //      partition).  Thread t looks at positions [128 t, 128 t + 128) — eight 16-byte loads — counts the bytes that equal this
+    //      part's number (an exact SWAR zero-byte test per dword), a prefix sum over the threads gives its place, and it writes
+    //      its positions there in ascending order: a stable compaction without a single atomic.  (Round 3 read a list the
+    //      partition had sorted: item -> list -> words was a chain of three dependent global round trips, 26 % of this kernel.)
     {
-        // all of a thread's positions first, then all of their words, then the hashing: the two dependent global loads of
-        // every entry are in flight together instead of one entry at a time
+        constexpr uint32_t BPT = LZ_MAX_BLOCK / LZ2_THREADS;                // bytes of the map per thread
+        static_assert(BPT % 16u == 0, "whole 16-byte loads");
+        const uint4 *pm = reinterpret_cast<const uint4 *>(sc.partmap + (size_t)lb * LZ_MAX_BLOCK + (size_t)tid * BPT);
+        static_assert(BPT == 128u, "the match bitmap below is four dwords per thread");
+        const uint32_t pat = part * 0x01010101u;
+        auto nib = [&](uint32_t w) -> uint32_t {                            // bit k set: byte k of w equals `part`
+            const uint32_t x = w ^ pat;
+            const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;      // bit 7 of every zero byte of x, exactly
+            return (((z >> 7) * 0x00204081u) >> 21) & 15u;                  // bits 0, 8, 16, 24 -> 0..3 (the partial products never overlap)
+        };
+        // the loads first, all eight; what stays alive across the prefix sum is one match bit per position: four registers
+        uint32_t bm[4] = {0u, 0u, 0u, 0u};
+        {
+            uint4 pv[BPT / 16u];
+#pragma unroll
+            for (uint32_t q = 0; q < BPT / 16u; ++q) pv[q] = pm[q];
+#pragma unroll
+            for (uint32_t q = 0; q < BPT / 16u; ++q)
+                bm[q >> 1] |= (nib(pv[q].x) | (nib(pv[q].y) << 4) | (nib(pv[q].z) << 8) | (nib(pv[q].w) << 12)) << (16u * (q & 1u));
+        }
+        const uint32_t mine = (uint32_t)(__popc(bm[0]) + __popc(bm[1]) + __popc(bm[2]) + __popc(bm[3]));
+        __shared__ uint32_t s_scanp[LZ2_NWAVES + 2];
+        uint32_t total_m;
+        uint32_t at = block_exclusive_scan<uint32_t>(mine, OpAddU32(), 0u, s_scanp, &total_m);
+        (void)total_m;                                                      // == m: the partition counted the same bytes
+        const uint32_t p0 = (uint32_t)tid * BPT;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            uint32_t z = bm[k];
+            while (z) {
+                const uint32_t bpos = (uint32_t)__builtin_ctz(z);
+                z &= z - 1u;
+                if (at < CAP) s_pos[at] = (uint16_t)(p0 + 32u * k + bpos);
+                ++at;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- gather: the words (4 unaligned bytes each from the block; bytes past the block end read as zero, the parity
+    //      definition of the reference's over-read)
+    {
+        // all of a thread's words first, then the hashing: the loads are in flight together instead of one entry at a time
         constexpr uint32_t GCH = CAP / LZ2_THREADS;
         uint32_t gp[GCH], glo[GCH], ghi[GCH];
         const bool aligned = (((uintptr_t)src) & 3u) == 0;
 #pragma unroll
-        for (uint32_t c = 0; c < GCH; ++c) { const uint32_t j = tid + c * LZ2_THREADS; gp[c] = j < m ? (uint32_t)plist[j] : 0u; }
+        for (uint32_t c = 0; c < GCH; ++c) { const uint32_t j = tid + c * LZ2_THREADS; gp[c] = j < m ? (uint32_t)s_pos[j] : 0u; if (j < m) plist[j] = (uint16_t)gp[c]; }
 #pragma unroll
         for (uint32_t c = 0; c < GCH; ++c) {
             const uint32_t j = tid + c * LZ2_THREADS, p = gp[c];
@@ -222,7 +265,6 @@ __device__ __forceinline__ void lz2_find_part(const uint8_t *__restrict__ in, ui
                     const uint32_t sh = ((uint32_t)((uintptr_t)(src + p) & 3u)) * 8u;
                     if (sh) w = (glo[c] >> sh) | (ghi[c] << (32u - sh));
                 }
-                s_pos[j] = (uint16_t)p;
                 // every step of the reference hash is invertible (odd multipliers, rotations, xor-shifts), so the mixed
                 // value identifies the word: keep it instead of the word — the home is a mask away, equality is equality
                 const uint32_t mx = lz_mix32(w);
@@ -235,9 +277,7 @@ __device__ __forceinline__ void lz2_find_part(const uint8_t *__restrict__ in, ui
     if (tid == 0) { s_zslot = ~0u; s_zgid = ~0u; s_nbigl = 0; }
     __syncthreads();
     auto homep = [&](uint32_t j) -> uint32_t { return ((s_word[j] & Tmask) - base) & Tmask; };
-    // order check 1 of 3 (lz_common.h lz_order_violation): a part's list must be in time order — the partition's stable pass.
-    // (Through LDS: taking the neighbour's position from the lane below and the list cost the gather twice as much.)
-    for (uint32_t j = tid + 1; j < m; j += LZ2_THREADS) viol |= s_pos[j - 1] >= s_pos[j];
+    // (a part's positions are in time order by construction — a compaction, no sort: the order checks start with the home sort)
     LZ2_TICK(0);
 
     // ---- sort time indices by home', stable
@@ -862,11 +902,12 @@ size_t lz2_scratch_bytes(uint32_t nb)
 {
     size_t descs = 0;                                    // what lz2_carve takes for the class descriptor arrays, exactly
     for (uint32_t c = 0; c < LZ2_NCLASS; ++c) descs += lz2_class_cap(c);
-    return (size_t)nb * (LZ_MAX_BLOCK * 2 * 2 + LZ2_BIG_STRIDE * 2 * 4 + sizeof(Lz2BlockMeta) + 4 + 8 * LZ2_MAXPARTS + descs * sizeof(Lz2BigDesc)) + 16 * 256 + 4096 + 64 * 256;
+    return (size_t)nb * (LZ_MAX_BLOCK * (2 * 2 + 1) + LZ2_BIG_STRIDE * 2 * 4 + sizeof(Lz2BlockMeta) + 4 + 8 * LZ2_MAXPARTS + descs * sizeof(Lz2BigDesc)) + 16 * 256 + 4096 + 64 * 256;
 }
 
 void lz2_carve(mi_carver &cv, uint32_t nb, Lz2Scratch *sc)
 {
+    sc->partmap = cv.take<uint8_t>((size_t)nb * LZ_MAX_BLOCK);
     sc->plist = cv.take<uint16_t>((size_t)nb * LZ_MAX_BLOCK);
     sc->cand = cv.take<uint16_t>((size_t)nb * LZ_MAX_BLOCK);
     sc->meta = cv.take<Lz2BlockMeta>(nb);
@@ -921,24 +962,34 @@ mi_status lz2_stage_partition(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, ui
 }
 
 // stage A2: per-part find (LDS heavy: three workgroups per CU)
-mi_status lz2_stage_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
-                         const Lz2Scratch &sc, hipStream_t s)
+static uint32_t lz2_find_grid(const LzP &P, uint32_t nb)
 {
     // the partition lists a block's parts (greedy, data dependent: 26-27 for a full block of text); the grid covers
     // LZ2_GRID_PARTS per block, rounded up to the 8 XCD slices of the kernel's workgroup mapping (a grid that is not a multiple
     // of 8 would leave items of the last row unassigned: ADVICE r3), the looping wide kernel takes whatever lies beyond
     const uint32_t parts = P.block / 64u + 1u < LZ2_GRID_PARTS ? P.block / 64u + 1u : LZ2_GRID_PARTS;
-    const uint32_t grid = (parts * nb + 7u) & ~7u;
-    {
-        mi_prof_scope p(ctx, "k_lz2_find", s, (uint64_t)nb * P.block);
-        hipLaunchKernelGGL(k_lz2_find, dim3(grid), dim3(LZ2_THREADS), 0, s, d_in, n, P, sc, block0);
-    }
-    {
-        // parts of 2561..4096 entries (none in text): 256 looping workgroups, gone at once when the list is empty (timed apart: an
-        // empty launch still waits for 76 KiB of LDS behind the kernel above)
-        mi_prof_scope p(ctx, "k_lz2_find_wide", s, (uint64_t)nb * P.block);
-        hipLaunchKernelGGL(k_lz2_find_wide, dim3(256), dim3(LZ2_THREADS), 0, s, d_in, n, P, sc, block0, grid);
-    }
+    return (parts * nb + 7u) & ~7u;
+}
+
+mi_status lz2_stage_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
+                         const Lz2Scratch &sc, hipStream_t s)
+{
+    mi_prof_scope p(ctx, "k_lz2_find", s, (uint64_t)nb * P.block);
+    hipLaunchKernelGGL(k_lz2_find, dim3(lz2_find_grid(P, nb)), dim3(LZ2_THREADS), 0, s, d_in, n, P, sc, block0);
+    MI_HIP(ctx, hipGetLastError());
+    return MI_OK;
+}
+
+// parts of 2561..4096 entries (none in text) and whatever a batch lists beyond k_lz2_find's grid: 256 looping workgroups, gone at
+// once when there is nothing to do.  Its own launch and — in the pipelined encoder — NOT on the stream of partition and find: an
+// empty launch still has to be given 76 KiB of LDS per workgroup before it can leave, and it waited about a millisecond per batch
+// for that behind the parse kernel of the batch before, on the one chain the pipeline is bound by (kernel timeline, round 4:
+// partition 3.7 + find 4.45 + this 1.0 ms of a 9.3 ms batch period)
+mi_status lz2_stage_find_wide(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
+                              const Lz2Scratch &sc, hipStream_t s)
+{
+    mi_prof_scope p(ctx, "k_lz2_find_wide", s, (uint64_t)nb * P.block);
+    hipLaunchKernelGGL(k_lz2_find_wide, dim3(256), dim3(LZ2_THREADS), 0, s, d_in, n, P, sc, block0, lz2_find_grid(P, nb));
     MI_HIP(ctx, hipGetLastError());
     return MI_OK;
 }

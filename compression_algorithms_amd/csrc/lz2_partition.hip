@@ -25,8 +25,6 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     __shared__ __attribute__((aligned(16))) uint8_t s_in[LZ_MAX_BLOCK + LZ_TAIL + 16];
     __shared__ uint32_t s_grp[LZ2_NG];               // counts -> inclusive prefix; later the staging area
     __shared__ uint32_t s_safe[LZ2_NG / 32];
-    // (the radix pass's counters — [17][LZ2_MAXPARTS], 8.5 KiB — live in s_gpart further down, which is dead by then: this kernel
-    //  shares CUs with the replay kernels and every KiB it leaves is a wave of theirs)
     __shared__ uint64_t s_scan64[18];
     __shared__ uint32_t s_scan32[18];
     __shared__ uint32_t s_thr[LZ2_MAXPARTS + 1];     // part k = home' in [s_thr[k], s_thr[k+1])
@@ -247,11 +245,8 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     //      HBM: consecutive positions of one part land on consecutive addresses, and the exclusive scan over the parts is
     //      exactly the list layout (part k starts at the number of entries in parts < k).  (Staging 8192 positions at a
     //      time through LDS paid the pass's fixed costs eight times: 7.5 -> see DESIGN.md for the measurement.)
-    uint16_t *plist = sc.plist + (size_t)lb * LZ_MAX_BLOCK;
     uint8_t  *part_in = reinterpret_cast<uint8_t *>(s_grp);             // [65536] part of every position; the group array is dead now
     __shared__ __attribute__((aligned(16))) uint8_t s_gpart[LZ2_NG];   // part of every rotated group (part boundaries are group boundaries)
-    static_assert(17u * LZ2_MAXPARTS * 4u <= LZ2_NG, "the radix counters reuse s_gpart");
-    uint32_t (*s_cnt)[LZ2_MAXPARTS] = reinterpret_cast<uint32_t (*)[LZ2_MAXPARTS]>(s_gpart);      // once part_in is tabulated
     {
         // sixteen consecutive groups per thread: one binary search for the first, then a walk along the thresholds
         constexpr uint32_t GPT = LZ2_NG / 1024;
@@ -273,15 +268,21 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
         for (uint32_t i = 0; i < 64u; ++i) {
             const uint32_t p = (uint32_t)tid + 1024u * i;
             const uint32_t g = (gcache[i >> 1] >> (16u * (i & 1u))) & 0xFFFFu;
-            if (p < n) part_in[p] = s_gpart[(g - gstart_) & (LZ2_NG - 1u)];
+            part_in[p] = (p < n) ? s_gpart[(g - gstart_) & (LZ2_NG - 1u)] : (uint8_t)0xFF;      // 0xFF: no position (parts are numbered < 128)
         }
     }
     __syncthreads();
     PT_TICK(5);
-    radix_pass_1024<LZ2_PARTBITS, uint32_t>(n, s_cnt,
-        [&](uint32_t i) { return i | ((uint32_t)part_in[i] << 16); },
-        [&](uint32_t e) { return e >> 16; },
-        [&](uint32_t j, uint32_t e) { plist[j] = (uint16_t)e; }, P.flags & (LZP_ARANK | LZP_BREAK));
+    // The part of every position goes out as it stands, 64 KiB of bytes, coalesced.  Round 3 sorted the positions into
+    // per-part lists here (one stable radix pass over the block: 87 k of this kernel's 205 k cycles — 27 distinct digits, so the
+    // lanes of every counting and ranking atomic pile up on a few LDS addresses — and 128 KiB of scattered 2-byte stores);
+    // now every workgroup of stage 2 picks its own positions out of this map with byte compares and a prefix sum, in time
+    // order by construction (lz2_find.hip).
+    {
+        uint4 *dst = reinterpret_cast<uint4 *>(sc.partmap + (size_t)lb * LZ_MAX_BLOCK);
+        const uint4 *srcv = reinterpret_cast<const uint4 *>(part_in);
+        for (uint32_t i = tid; i < LZ_MAX_BLOCK / 16u; i += 1024u) dst[i] = srcv[i];
+    }
     PT_TICK(6);
     if (sc.dbg && tid == 0) atomicAdd((unsigned long long *)&sc.dbg[47], 1ull);
 }

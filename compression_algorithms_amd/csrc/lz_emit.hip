@@ -513,7 +513,8 @@ __device__ __forceinline__ uint32_t stream_bits(const uint8_t *s, uint64_t nbyte
 size_t   lz_scratch_bytes(uint32_t nb);
 void     lz_carve(mi_ctx *ctx, uint32_t nb, LzScratch *sc, Lz2Scratch *sc2, int set);
 mi_status lz_find_stage_a(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
-                          const LzScratch &sc, const Lz2Scratch &sc2, hipStream_t s, hipStream_t sf, hipEvent_t ev_part, hipEvent_t ev_fb);
+                          const LzScratch &sc, const Lz2Scratch &sc2, hipStream_t s, hipStream_t sf, hipEvent_t ev_part, hipEvent_t ev_fb,
+                          hipEvent_t ev_wide);
 mi_status lz_find_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &sc2, hipStream_t s);
 bool     lz_use_v2();
 mi_status lz_run_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
@@ -656,14 +657,17 @@ static mi_status lz_encode_impl(mi_ctx *ctx, const mi_lz_params *p, const uint8_
         const int k = (int)(batch % (uint64_t)nsets);
         if (overlap && batch >= (uint64_t)nsets) MI_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_done[k], 0));   // set k is free again
         st = lz_find_stage_a(ctx, P, d_in, n, b0, nb, sc[k], sc2[k], s,
-                             overlap ? ((batch & 1u) && fb_busy && ctx->fb2 ? ctx->fb2 : ctx->fb) : s, ctx->ev_part[k], ctx->ev_fb[k]);
+                             overlap ? ((batch & 1u) && fb_busy && ctx->fb2 ? ctx->fb2 : ctx->fb) : s, ctx->ev_part[k], ctx->ev_fb[k], ctx->ev_wide[k]);
         if (st) return st;
         if (hold_parse && prev_k >= 0) {
             MI_HIP(ctx, hipStreamWaitEvent(sp, ctx->ev_part[k], 0));
             st = stage_c(prev_k, prev_b0, prev_nb);
             if (st) return st;
         }
-        if (overlap) { MI_HIP(ctx, hipEventRecord(ctx->ev_find[k], s)); MI_HIP(ctx, hipStreamWaitEvent(sb, ctx->ev_find[k], 0)); }
+        if (overlap) {
+            MI_HIP(ctx, hipEventRecord(ctx->ev_find[k], s)); MI_HIP(ctx, hipStreamWaitEvent(sb, ctx->ev_find[k], 0));
+            if (lz_use_v2() && !getenv("MI_LZ_WIDE_INLINE")) MI_HIP(ctx, hipStreamWaitEvent(sb, ctx->ev_wide[k], 0));    // the wide parts' exports (lz_find.hip)
+        }
         if (!(skip & 1)) st = lz_find_stage_b(ctx, P, nb, sc2[k], sb);
         if (st) return st;
         if (overlap) {

@@ -937,6 +937,8 @@ mi_status lz2_stage_partition(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, ui
                               const Lz2Scratch &sc, hipStream_t s);
 mi_status lz2_stage_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
                          const Lz2Scratch &sc, hipStream_t s);
+mi_status lz2_stage_find_wide(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
+                              const Lz2Scratch &sc, hipStream_t s);
 mi_status lz2_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &sc, hipStream_t s);
 void   lz2_launch_scatter(const Lz2Scratch &sc, uint16_t *cand_by_pos, uint32_t nb, hipStream_t s);
 
@@ -969,7 +971,8 @@ void lz_carve(mi_ctx *ctx, uint32_t nb, LzScratch *sc, Lz2Scratch *sc2, int set)
 // the chain is normally empty, but its launches ask for 82..155 KiB of LDS per workgroup and would otherwise
 // sit in front of the real work waiting for that LDS.
 mi_status lz_find_stage_a(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
-                          const LzScratch &sc, const Lz2Scratch &sc2, hipStream_t s, hipStream_t sf, hipEvent_t ev_part, hipEvent_t ev_fb)
+                          const LzScratch &sc, const Lz2Scratch &sc2, hipStream_t s, hipStream_t sf, hipEvent_t ev_part, hipEvent_t ev_fb,
+                          hipEvent_t ev_wide)
 {
     if (!lz_use_v2()) return lz_find_batch(ctx, P, d_in, n, block0, nb, sc, s, nullptr, nullptr);
     mi_status st = lz2_stage_partition(ctx, P, d_in, n, block0, nb, sc2, s);
@@ -977,13 +980,23 @@ mi_status lz_find_stage_a(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64
     // MI_LZ_UNSAFE_NO_FALLBACK=1 (measurement only: wrong output for any block the partition hands back) leaves the
     // fallback chain out, to price its normally empty launches
     static const bool no_fb = getenv("MI_LZ_UNSAFE_NO_FALLBACK") != nullptr;
+    static const bool wide_inline = getenv("MI_LZ_WIDE_INLINE") != nullptr;      // A/B: the wide finder on the main stream as in round 3
+    if (sf != s) { MI_HIP(ctx, hipEventRecord(ev_part, s)); MI_HIP(ctx, hipStreamWaitEvent(sf, ev_part, 0)); }
+    const bool wide_aside = sf != s && ev_wide && !wide_inline;
+    if (wide_aside) {
+        // first thing on the side chain: stage B waits for it (exported clusters of wide parts), the fallback chain behind it does not matter
+        st = lz2_stage_find_wide(ctx, P, d_in, n, block0, nb, sc2, sf);
+        if (st) return st;
+        MI_HIP(ctx, hipEventRecord(ev_wide, sf));
+    }
     if (!no_fb) {
-        if (sf != s) { MI_HIP(ctx, hipEventRecord(ev_part, s)); MI_HIP(ctx, hipStreamWaitEvent(sf, ev_part, 0)); }
         st = lz_find_batch(ctx, P, d_in, n, block0, nb, sc, sf, sc2.fallback_list, sc2.fallback_count);
         if (st) return st;
     }
     if (sf != s) MI_HIP(ctx, hipEventRecord(ev_fb, sf));
-    return lz2_stage_find(ctx, P, d_in, n, block0, nb, sc2, s);
+    st = lz2_stage_find(ctx, P, d_in, n, block0, nb, sc2, s);
+    if (st || wide_aside) return st;
+    return lz2_stage_find_wide(ctx, P, d_in, n, block0, nb, sc2, s);
 }
 mi_status lz_find_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &sc2, hipStream_t s)
 {
@@ -992,7 +1005,7 @@ mi_status lz_find_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scrat
 mi_status lz_run_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
                       const LzScratch &sc, const Lz2Scratch &sc2, hipStream_t s)
 {
-    mi_status st = lz_find_stage_a(ctx, P, d_in, n, block0, nb, sc, sc2, s, s, nullptr, nullptr);
+    mi_status st = lz_find_stage_a(ctx, P, d_in, n, block0, nb, sc, sc2, s, s, nullptr, nullptr, nullptr);
     return st ? st : lz_find_stage_b(ctx, P, nb, sc2, s);
 }
 mi_status lz_check_params(const mi_lz_params *p)
