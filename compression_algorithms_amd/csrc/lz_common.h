@@ -79,8 +79,10 @@ struct LzScratch {
     uint64_t    *eA, *eB;          // [nb][65536]  entry records, ping-pong of the sort by cluster
     uint16_t    *cand;             // [nb][65536]  find() result per position
     LzBlockMeta *meta;             // [nb]
-    uint32_t    *giant_count;      // [1]
-    uint32_t    *giant_list;       // [nb * LZ_MAX_GIANTS_PER_BLOCK][2] = {block, start index}
+    uint32_t    *giant_count;      // [0] clusters listed from the front, [1] cursor of k_lz_emulate_dom, [2] clusters listed from the END
+                                   // (the ones a tile could not hold: the largest — handed out first), [3] cursor of k_lz_emulate_giant
+    uint32_t    *giant_list;       // [giant_cap][2] = {block, start index}
+    uint32_t     giant_cap;        // nb * LZ_MAX_GIANTS_PER_BLOCK
     uint32_t    *slot;             // [nb][SLOT_WORDS] block-local token stream
     uint64_t    *block_bits;       // [nb] bits produced per block (this batch)
 };
@@ -107,6 +109,14 @@ struct LzwScratch {
     uint64_t *block_bits;       // [nb + 1]
     uint32_t  S, slot_words;
 };
+
+// The g-th cluster of the fallback's work list, longest processing time first: the clusters that span tiles (listed from the
+// end of the array) come before the ones found inside a tile.  A cursor that hands out a 35 000-entry cluster last leaves one
+// workgroup replaying it alone: measured on the "pages" family, the longest workgroup of k_lz_emulate_dom ran 3.3 x the average.
+__device__ __forceinline__ uint32_t lz_giant_slot(const LzScratch &sc, uint32_t g, uint32_t n_back)
+{
+    return g < n_back ? sc.giant_cap - 1u - g : g - n_back;
+}
 
 // reference hash(): algorithms/lz77/lz77.c:13-41 == algorithms/deflate/lz77.c:14-42
 __device__ __forceinline__ uint32_t lz_mix32(uint32_t w)

@@ -340,7 +340,7 @@ __device__ __forceinline__ void lz_emulate_tile(LzP P, LzScratch sc, uint32_t lb
     if (b == ~0u || b - lasthead > LZ_GIANT_MIN || b - a > LZ_TILE_CAP) {
         // the cluster that starts at `lasthead` is too large for this tile: hand it to the giant kernel
         if (tid == 0) {
-            const uint32_t k = atomicAdd(sc.giant_count, 1u);
+            const uint32_t k = sc.giant_cap - 1u - atomicAdd(&sc.giant_count[2], 1u);      // from the end: handed out first (lz_giant_slot)
             sc.giant_list[2 * k] = lb; sc.giant_list[2 * k + 1] = lasthead;
         }
         b = lasthead;
@@ -419,8 +419,15 @@ void k_lz_emulate_giant(LzP P, LzScratch sc)
     static_assert(6 * LZ_GIANT_CAP <= 2 * LZ_MAX_BLOCK, "wave-replay tables must fit the buffer");
     __shared__ uint32_t s_end;
     const int tid = threadIdx.x;
-    const uint32_t count = *sc.giant_count;
-    for (uint32_t g = blockIdx.x; g < count; g += gridDim.x) {
+    const uint32_t n_back = sc.giant_count[2], count = sc.giant_count[0] + n_back;
+    // clusters come off a cursor, the tile-spanning ones first (lz_giant_slot); every workgroup reaches the exit: the cursor only grows
+    __shared__ uint32_t s_gnext;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_gnext = atomicAdd(&sc.giant_count[3], 1u);
+        __syncthreads();
+        if (s_gnext >= count) break;
+        const uint32_t g = lz_giant_slot(sc, s_gnext, n_back);
         const uint32_t lb = sc.giant_list[2 * g], a = sc.giant_list[2 * g + 1];
         if (a & DOM_DONE) continue;                      // k_lz_emulate_dom has replayed it
         const LzBlockMeta mt = sc.meta[lb];
@@ -564,7 +571,7 @@ void k_lz_emulate_dom(LzP P, LzScratch sc, uint64_t *dbg)
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t W = 1u << P.wbits;
     if (W > DOM_RING) return;
-    const uint32_t count = *sc.giant_count;
+    const uint32_t n_back = sc.giant_count[2], count = sc.giant_count[0] + n_back;
     const long long tk_wg = dbg ? clock64() : 0;
     // clusters are handed out by a cursor (they differ in size by a factor of 70: a static stride left the longest workgroup
     // 3.4 x the average); every workgroup reaches the exit: the cursor only grows
@@ -573,8 +580,8 @@ void k_lz_emulate_dom(LzP P, LzScratch sc, uint64_t *dbg)
         __syncthreads();
         if (tid == 0) s_next = atomicAdd(&sc.giant_count[1], 1u);
         __syncthreads();
-        const uint32_t g = s_next;
-        if (g >= count) break;
+        if (s_next >= count) break;
+        const uint32_t g = lz_giant_slot(sc, s_next, n_back);
         const uint32_t lb = sc.giant_list[2 * g], a = sc.giant_list[2 * g + 1];
         const LzBlockMeta mt = sc.meta[lb];
         const uint32_t n = mt.n;
@@ -959,6 +966,7 @@ void lz_carve(mi_ctx *ctx, uint32_t nb, LzScratch *sc, Lz2Scratch *sc2, int set)
     sc->meta = cv.take<LzBlockMeta>(nb);
     sc->giant_count = cv.take<uint32_t>(64);
     sc->giant_list = cv.take<uint32_t>((size_t)nb * LZ_MAX_GIANTS_PER_BLOCK * 2);
+    sc->giant_cap = nb * LZ_MAX_GIANTS_PER_BLOCK;
     sc->slot = cv.take<uint32_t>((size_t)nb * LZ_SLOT_WORDS);
     sc->block_bits = cv.take<uint64_t>(nb + 1);
     if (sc2) lz2_carve(cv, nb, sc2);
@@ -1031,7 +1039,7 @@ mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t
     const int saved_prof = ctx->profiling;
     static const bool prof_fb = getenv("MI_LZ_PROF_FALLBACK") != nullptr;      // inputs that live in the fallback (scripts/adv_profile.py)
     if (blist && !prof_fb) ctx->profiling = 0;
-    MI_HIP(ctx, hipMemsetAsync(sc.giant_count, 0, 8, s));        // [0] clusters listed, [1] cursor of k_lz_emulate_dom
+    MI_HIP(ctx, hipMemsetAsync(sc.giant_count, 0, 16, s));       // [0] / [2] clusters listed from the front / the end, [1] / [3] cursors (lz_common.h)
     // fallback: few looping workgroups (see LZ_FB_GRID) — unless the last finished batch (in practice: of an earlier call) had
     // many blocks here (non-text input): the count k_lz_sort_home left in pinned memory sizes the grids (pages family: half the
     // chip sat idle behind 128 workgroups)

@@ -30,12 +30,20 @@
 
 #define LZS_NG_BITS   15
 #define LZS_NG        (1u << LZS_NG_BITS)
-#define LZS_CAP       4096u
+#ifndef LZS_CAP
+#define LZS_CAP       2560u                       // events per part: 50 KiB of LDS, THREE workgroups of k_lzs_find per CU (4096: 75 KiB, two; same-box A/B 6.44 -> 6.81 / 4.06 -> 4.18 GB/s)
+#endif
 #define LZS_THREADS   512
 #define LZS_NWAVES    (LZS_THREADS / 64)
-#define LZS_PARTBITS  6
-#define LZS_MAXPARTS  (1u << LZS_PARTBITS)        // digit 63 is the bin of the event ids that are not events
-#define LZS_LANE_MAX  16u
+#define LZS_MAXPARTS  128u                        // room in the meta records; part numbers are bytes of the step's part map (0xFF: no event)
+#define LZS_KMAX      (LZS_CAP >= 4096u ? 64u : 96u)   // parts a step may cut per block (k_lzs_find's grid covers that many): 2 W / LZS_CAP is 32 / 51 on text
+static_assert(LZS_KMAX <= LZS_MAXPARTS && LZS_KMAX < 255u, "part numbers are bytes");
+#ifndef LZS_LANE_MAX
+#define LZS_LANE_MAX  16u                         // clusters of up to this many events are replayed inside k_lzs_find, one LANE each (16: registers only).
+                                                  // 64 (occupants in LDS, lzs_replay_lane64; no k_lzs_mid launches) was built and measured in round 4:
+                                                  // parity green, but the workgroup waits for its longest 64-event lane — k_lzs_find 10.8 -> 13.8 ms,
+                                                  // 6.81 -> 6.36 GB/s at 256 KiB blocks, 4.18 -> 3.48 at 1 MiB (make EXTRA=-DLZS_LANE_MAX=64u)
+#endif
 #define LZS_DEAD      0x80000000u
 #define LZS_NONE      0xFFFFFFFFu
 // entry flags in LDS
@@ -62,7 +70,8 @@ struct LzsScratch {
     uint32_t *key;        // [nb][S] mix32(word) by position
     uint32_t *slot;       // [nb][S] bucket an entry was inserted on | LZS_DEAD
     uint32_t *cand;       // [nb][S] find() by position (LZS_NONE = none)
-    uint32_t *plist;      // [nb][S] event ids of the current step, grouped by part, event order inside a part
+    uint32_t *plist;      // [nb][S] event ids of the current step, grouped by part, event order inside a part (written by k_lzs_find)
+    uint8_t  *pmap;       // [nb][2 W] the part of every event id of the current step (0xFF: not an event), written by k_lzs_part
     LzsMeta  *meta;       // [nb]
     uint64_t *work;       // [nb * LZS_MAXPARTS] parts of the current step: block | part << 16 | events << 24 | list start << 40
     uint32_t *counters;   // [0..63] parts listed in step k, [64] flagged blocks, [128 + 8 k ..] step k: exported events, clusters of class 0..3
@@ -107,7 +116,6 @@ void k_lzs_part(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
 {
     __shared__ uint32_t s_grp[LZS_NG];                // counts -> inclusive prefix; later the part of every event id (bytes)
     __shared__ uint32_t s_safe[LZS_NG / 32];
-    __shared__ uint32_t s_cnt[17][LZS_MAXPARTS];
     __shared__ uint64_t s_scan64[18];
     __shared__ uint32_t s_scan32[18];
     __shared__ uint32_t s_thr[LZS_MAXPARTS + 1];      // part k = coordinates in [s_thr[k], s_thr[k+1])
@@ -207,7 +215,7 @@ void k_lzs_part(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
                 const uint64_t mk = __ballot(c >= (int32_t)glo && is_safe((uint32_t)c));
                 if (mk) { gr = g - (int32_t)__builtin_ctzll(mk); break; }
             }
-            if (gr < (int32_t)glo || k + 3 > LZS_MAXPARTS) { bad = true; break; }     // one cluster above the capacity / too many parts
+            if (gr < (int32_t)glo || k + 3 > LZS_KMAX) { bad = true; break; }          // one cluster above the capacity / too many parts
             cur = s_grp[gr];
             glo = (uint32_t)gr + 1u;
             ++k;
@@ -239,11 +247,13 @@ void k_lzs_part(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     __syncthreads();
     if (tid < (int)K) sc.work[s_wbase + tid] = (uint64_t)lb | ((uint64_t)tid << 16) | ((uint64_t)mt->part_count[tid] << 24) | ((uint64_t)mt->part_start[tid] << 40);
 
-    // ---- event ids -> part lists, event order kept: the part of every id (a binary search over <= 63 thresholds), then ONE
-    //      stable radix pass by part number; ids that are not events of this step go to a last bin that is not stored
+    // ---- the part of every event id (a binary search over the thresholds), one byte each, goes out as it stands: 2 W bytes,
+    //      coalesced.  Every workgroup of stage 2 picks its own events out of this map (byte compares + a prefix sum: event
+    //      order by construction).  Round 3 sorted the ids into per-part lists here with one stable radix pass over 2 W ids —
+    //      half of this kernel, and it runs on ONE workgroup per block and step, on the chain every step waits for.
     uint8_t *part_in = reinterpret_cast<uint8_t *>(s_grp);          // [NE <= 131072] (the group array is dead: barrier above)
     for (uint32_t e = tid; e < NE; e += 1024) {
-        uint32_t pk = LZS_MAXPARTS - 1u;
+        uint32_t pk = 0xFFu;
         if (valid(e)) {
             const uint32_t c = coord(e);
             uint32_t lo = 0, hi = K - 1;                // last k with thr[k] <= c
@@ -253,11 +263,11 @@ void k_lzs_part(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
         part_in[e] = (uint8_t)pk;
     }
     __syncthreads();
-    uint32_t *plist = sc.plist + (size_t)lb * sc.S;
-    radix_pass_1024<LZS_PARTBITS, uint32_t>(NE, s_cnt,
-        [&](uint32_t i) { return i | ((uint32_t)part_in[i] << 24); },
-        [&](uint32_t e) { return e >> 24; },
-        [&](uint32_t j, uint32_t e) { if ((e >> 24) != LZS_MAXPARTS - 1u) plist[j] = e & 0xFFFFFFu; }, P.flags & LZP_ARANK);
+    {
+        uint4 *dst = reinterpret_cast<uint4 *>(sc.pmap + (size_t)lb * NE);
+        const uint4 *srcv = reinterpret_cast<const uint4 *>(part_in);
+        for (uint32_t i = tid; i < NE / 16u; i += 1024u) dst[i] = srcv[i];
+    }
 }
 
 // =============================================================================================
@@ -294,6 +304,46 @@ __device__ __forceinline__ void lzs_replay_lane(const uint32_t *e_key, const uin
             const uint32_t fb = b0 + (uint32_t)__builtin_ctz(~(mask >> b0));   // first fit, inside the cluster by the parking bound
             mask |= 1u << fb;
             tab = (tab & ~(15ull << (4u * fb))) | ((uint64_t)li << (4u * fb));
+            e_slot[i] = (uint16_t)(s + fb);
+        }
+    }
+}
+
+// a cluster of 17..64 events [s, s + m) on one lane: occupancy in a 64-bit register, the occupant of every slot (its index inside the
+// cluster, a byte) in the part's own LDS — `occ8` is indexed by slot like e_slot, and a cluster owns its slots [s, s + m).  Round 3
+// exported these clusters (8 bytes per event through HBM) to lane kernels of their own (k_lzs_mid: 16 / 32 KiB of LDS per wave, two
+// more launches on every step's chain) or, where those did not pay (few blocks), to the wave replay at ~75 CU-cycles per event; in
+// here they cost the workgroup its longest such lane: <= 64 events of a few LDS round trips each.
+__device__ __forceinline__ void lzs_replay_lane64(const uint32_t *e_key, const uint16_t *e_rf, uint16_t *e_slot, uint16_t *cand_i, uint8_t *occ8,
+                                                  uint32_t s, uint32_t m)
+{
+    uint64_t mask = 0;
+    bool any_new = false;
+    for (uint32_t li = 0; li < m; ++li) {               // the table the step starts from: old entries that are still there
+        const uint32_t rf = e_rf[s + li];
+        if ((rf & (RF_OLD | RF_DEAD)) == RF_OLD) { const uint32_t b = (rf & RF_SLOT) - s; mask |= 1ull << b; occ8[s + b] = (uint8_t)li; }
+        any_new |= !(rf & RF_OLD);
+    }
+    if (!any_new) return;                               // nobody asks
+    for (uint32_t li = 0; li < m; ++li) {
+        const uint32_t i = s + li, rf = e_rf[i], b0 = (rf & RF_SLOT) - s;
+        if (rf & RF_OLD) {                              // clear the recorded bucket, whoever sits there (lz77.c:70-76)
+            if ((mask >> b0) & 1ull) {
+                const uint32_t o = occ8[s + b0];
+                if (o != li && !(e_rf[s + o] & RF_OLD)) e_slot[s + o] |= ES_KILLED;
+                mask &= ~(1ull << b0);
+            }
+        } else {
+            const uint32_t key = e_key[i];
+            const uint32_t fb = b0 + (uint32_t)__builtin_ctzll(~(mask >> b0));   // first fit, inside the cluster by the parking bound
+            uint32_t res = 0xFFFFu;
+            for (uint32_t b = b0; b < fb; ++b) {                             // find(): lz77.c:94-108 — every slot of [b0, fb) is occupied
+                const uint32_t o = occ8[s + b];
+                if (e_key[s + o] == key) { res = s + o; break; }
+            }
+            cand_i[i] = (uint16_t)res;
+            mask |= 1ull << fb;
+            occ8[s + fb] = (uint8_t)li;
             e_slot[i] = (uint16_t)(s + fb);
         }
     }
@@ -337,7 +387,7 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     (void)n_total; (void)block0;
     long long tk = clock64();
 #define LZS_TICK(k) do { if (sc.dbg && tid == 0) { long long t2 = clock64(); atomicAdd((unsigned long long *)&sc.dbg[k], (unsigned long long)(t2 - tk)); tk = t2; } } while (0)
-    const uint32_t *plist = sc.plist + (size_t)lb * sc.S + pstart;
+    uint32_t *plist = sc.plist + (size_t)lb * sc.S + pstart;
     const uint32_t *key_new = sc.key + (size_t)lb * sc.S + t0;
     const uint32_t *key_old = sc.key + (size_t)lb * sc.S + (t0 - (step ? W : 0u));
     const uint32_t *slot_old = sc.slot + (size_t)lb * sc.S + (t0 - (step ? W : 0u));
@@ -355,14 +405,63 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     constexpr uint32_t RST = LZS_NWAVES + 1;
     const uint32_t seg = radix_seg<LZS_NWAVES>(m), seg_inv = (uint32_t)((0x100000000ull + seg - 1u) / seg);
     for (uint32_t i = tid; i < 256u * RST; i += LZS_THREADS) { cntA[i] = 0; cntB[i] = 0; }
-    // ---- gather: event ids (coalesced), then keys and slots of all of a thread's events together
+    // ---- this part's events, in event order: picked out of the step's part map (k_lzs_part: one byte per event id).  Thread t
+    //      looks at ids [BPT t, BPT t + BPT) — 16-byte loads — keeps one match bit per id, a prefix sum over the threads gives its
+    //      place, and it writes its ids there in ascending order (into s_key, which the keys only take over further down).
+    {
+        const uint32_t NE = 2u * W;
+        constexpr uint32_t BPTMAX = 256u;                                   // W <= 65536: at most 131072 / 512 bytes of the map per thread
+        const uint32_t BPT = NE / LZS_THREADS;                              // (a multiple of 16 for W >= 4096; smaller windows take the byte loop)
+        const uint8_t *pm = sc.pmap + (size_t)lb * NE + (size_t)tid * BPT;
+        const uint32_t pat = part * 0x01010101u;
+        auto nib = [&](uint32_t w) -> uint32_t {                            // bit k set: byte k of w equals `part`
+            const uint32_t x = w ^ pat;
+            const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+            return (((z >> 7) * 0x00204081u) >> 21) & 15u;
+        };
+        uint32_t bm[BPTMAX / 32u];
+#pragma unroll
+        for (uint32_t k = 0; k < BPTMAX / 32u; ++k) bm[k] = 0u;
+        if ((BPT & 15u) == 0u) {
+#pragma unroll
+            for (uint32_t q = 0; q < BPTMAX / 16u; ++q) {
+                if (q * 16u < BPT) {
+                    const uint4 v = reinterpret_cast<const uint4 *>(pm)[q];
+                    bm[q >> 1] |= (nib(v.x) | (nib(v.y) << 4) | (nib(v.z) << 8) | (nib(v.w) << 12)) << (16u * (q & 1u));
+                }
+            }
+        } else {
+            for (uint32_t i = 0; i < BPT; ++i) if (pm[i] == (uint8_t)part) bm[i >> 5] |= 1u << (i & 31u);
+        }
+        uint32_t mine = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < BPTMAX / 32u; ++k) mine += (uint32_t)__popc(bm[k]);
+        __shared__ uint32_t s_scanp[LZS_NWAVES + 2];
+        uint32_t total_m;
+        uint32_t at = block_exclusive_scan<uint32_t>(mine, OpAddU32(), 0u, s_scanp, &total_m);
+        (void)total_m;                                                      // == m: k_lzs_part counted the same bytes
+        const uint32_t e0 = (uint32_t)tid * BPT;
+#pragma unroll
+        for (uint32_t k = 0; k < BPTMAX / 32u; ++k) {
+            uint32_t z = bm[k];
+            while (z) {
+                const uint32_t bpos = (uint32_t)__builtin_ctz(z);
+                z &= z - 1u;
+                if (at < LZS_CAP) s_key[at] = e0 + 32u * k + bpos;
+                ++at;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- gather: keys and slots of all of a thread's events together; the ids also go to the part's list in HBM (coalesced): the
+    //      permutation further down needs every event's time again and LDS has no room to keep it until then
     {
         uint32_t ge[CH], gk[CH], gs[CH];
 #pragma unroll
         for (uint32_t c = 0; c < CH; ++c) {
             const uint32_t j = tid + c * LZS_THREADS;
-            ge[c] = j < m ? plist[j] : 0u;
-            if (j > 0 && j < m) viol |= plist[j - 1] >= ge[c];          // a part's list is in event order: k_lzs_part's stable pass
+            ge[c] = j < m ? s_key[j] : 0u;
+            if (j < m) plist[j] = ge[c];
         }
 #pragma unroll
         for (uint32_t c = 0; c < CH; ++c) {
@@ -522,7 +621,8 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
 #pragma unroll
         for (uint32_t c = 0; c < CH; ++c) {
             const uint32_t i = tid + c * LZS_THREADS;
-            rt[c] = i < m ? plist[s_j1[i]] >> 1 : 0u;
+            // (written by this workgroup in the gather: an agent-scope load goes past the L1, which may hold nothing newer but is not coherent)
+            rt[c] = i < m ? __hip_atomic_load(&plist[s_j1[i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 1 : 0u;
         }
 #pragma unroll
         for (uint32_t c = 0; c < CH; ++c) {
@@ -549,8 +649,10 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     uint16_t *e_slot = s_r;
     uint16_t *lane_list = s_g;                            // cluster numbers are dead: clusters of 2..16 events, largest class first
     uint32_t *s_big = &s_cnt[LZS_NWAVES][0];              // <= 4096 / 17 clusters above the lane size: 240 words of the last row
-    __shared__ uint32_t s_ccnt[4], s_cbase[4], s_ebase, s_dbase[LZS_NCLS];
-    if (tid < 4) s_ccnt[tid] = 0;
+    constexpr uint32_t NLC = 6u;                          // lane classes: 33..64, 17..32, 9..16, 5..8, 3..4, 2 events — the longest chains first
+    __shared__ uint32_t s_ccnt[NLC], s_cbase[NLC], s_ebase, s_dbase[LZS_NCLS];
+    uint8_t *occ8 = reinterpret_cast<uint8_t *>(s_j1);   // occupant of every slot, for the lanes that replay 17..64 events (s_j1 is dead after the permutation)
+    if (tid < NLC) s_ccnt[tid] = 0;
     __syncthreads();
     LZS_TICK(4);
 
@@ -561,18 +663,18 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
 #pragma unroll
     for (uint32_t c = 0; c < GPT; ++c) {
         const uint32_t g = tid + c * LZS_THREADS;
-        my_cls[c] = 4u; my_rank[c] = 0;
+        my_cls[c] = NLC; my_rank[c] = 0;
         if (g < ngroups) {
             const uint32_t cs = g ? (uint32_t)cur16[g - 1] : 0u, cm = (uint32_t)cur16[g] - cs;
             if (cm == 1u) { if (!(e_rf[cs] & RF_OLD)) { cand_i[cs] = 0xFFFFu; e_slot[cs] = (uint16_t)cs; } }     // nobody to find, its home is free
-            else if (cm <= LZS_LANE_MAX) { my_cls[c] = cm > 8u ? 0u : cm > 4u ? 1u : cm > 2u ? 2u : 3u; my_rank[c] = atomicAdd(&s_ccnt[my_cls[c]], 1u); }
+            else if (cm <= LZS_LANE_MAX) { my_cls[c] = cm > 32u ? 0u : cm > 16u ? 1u : cm > 8u ? 2u : cm > 4u ? 3u : cm > 2u ? 4u : 5u; my_rank[c] = atomicAdd(&s_ccnt[my_cls[c]], 1u); }
             else { const uint32_t q = atomicAdd(&s_nbig, 1u); s_big[q] = cs | (cm << 16); s_bigm[q] = (uint16_t)cm; }
         }
     }
     __syncthreads();
     if (tid == 0) {
         uint32_t run = 0;
-        for (int c = 0; c < 4; ++c) { s_cbase[c] = run; run += s_ccnt[c]; }
+        for (uint32_t c = 0; c < NLC; ++c) { s_cbase[c] = run; run += s_ccnt[c]; }
         // one reservation per part for what it exports (events, clusters per class): the returns are not needed before the
         // lane replay is over
         const uint32_t nbig = s_nbig;
@@ -584,13 +686,14 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     }
     __syncthreads();
 #pragma unroll
-    for (uint32_t c = 0; c < GPT; ++c) if (my_cls[c] < 4u) lane_list[s_cbase[my_cls[c]] + my_rank[c]] = (uint16_t)(tid + c * LZS_THREADS);
+    for (uint32_t c = 0; c < GPT; ++c) if (my_cls[c] < NLC) lane_list[s_cbase[my_cls[c]] + my_rank[c]] = (uint16_t)(tid + c * LZS_THREADS);
     __syncthreads();
-    const uint32_t nlane = s_cbase[3] + s_ccnt[3];
+    const uint32_t nlane = s_cbase[NLC - 1u] + s_ccnt[NLC - 1u];
     for (uint32_t q = tid; q < nlane; q += LZS_THREADS) {
         const uint32_t g = lane_list[q];
-        const uint32_t cs = g ? (uint32_t)cur16[g - 1] : 0u;
-        lzs_replay_lane(e_key, e_rf, e_slot, cand_i, cs, (uint32_t)cur16[g] - cs);
+        const uint32_t cs = g ? (uint32_t)cur16[g - 1] : 0u, cm = (uint32_t)cur16[g] - cs;
+        if (cm <= 16u) lzs_replay_lane(e_key, e_rf, e_slot, cand_i, cs, cm);
+        else lzs_replay_lane64(e_key, e_rf, e_slot, cand_i, occ8, cs, cm);
     }
     __syncthreads();
     LZS_TICK(5);
@@ -859,7 +962,8 @@ void lzs_view(const LzwScratch &ws, uint32_t nb, LzsScratch *sc)
 {
     // the sliced finder lives in the arrays of lzw.hip's workspace (which it never uses at the same time)
     sc->key = ws.gid; sc->slot = ws.rd; sc->cand = ws.cand; sc->plist = ws.t_pos; sc->S = ws.S;
-    sc->meta = reinterpret_cast<LzsMeta *>(ws.eA);                       // nb x 784 B of nb x S x 8 B
+    sc->meta = reinterpret_cast<LzsMeta *>(ws.eA);                       // nb records at the start of the nb x S x 8 B of eA ...
+    sc->pmap = reinterpret_cast<uint8_t *>(ws.eA) + mi_align_up((size_t)nb * sizeof(LzsMeta), 256);   // ... then nb part maps of 2 W <= 128 KiB (S >= 65 792: 8 S bytes per block)
     sc->work = reinterpret_cast<uint64_t *>(ws.eB);                      // nb x 64 items
     sc->counters = reinterpret_cast<uint32_t *>(sc->work + (size_t)nb * LZS_MAXPARTS);                 // four groups x LZS_CTR_WORDS ([64] of the first: flagged blocks)
     sc->flag_count = sc->counters + 64;
@@ -887,7 +991,7 @@ bool lzs_applicable(const LzP &P)
 mi_status lzs_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
                    const LzwScratch &ws, hipStream_t s, uint32_t *flagged, const uint32_t **flag_list)
 {
-    static_assert(sizeof(LzsMeta) <= 65536u * 8u, "the meta records live in one row of eA");
+    static_assert(sizeof(LzsMeta) + 2u * 65536u + 512u <= 65792u * 8u, "meta records and part maps live in eA: 8 S bytes per block, S >= 65 792");
     if (!lzs_applicable(P)) return MI_ERR_ARG;
     LzsScratch all;
     lzs_view(ws, nb, &all);
@@ -912,6 +1016,7 @@ mi_status lzs_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, u
         q = all;
         const size_t o = (size_t)lo[g] * all.S;
         q.key += o; q.slot += o; q.cand += o; q.plist += o; q.big_key += o; q.big_info += o;
+        q.pmap += (size_t)lo[g] * 2u * (1u << P.wbits);
         q.meta += lo[g]; q.work += (size_t)lo[g] * LZS_MAXPARTS; q.counters += (size_t)g * LZS_CTR_WORDS;
         for (uint32_t c = 0; c < LZS_NCLS; ++c) q.big_desc[c] += o / 2;
         q.flag_count = all.counters + 64;                 // one count and one list of flagged blocks for the whole batch
@@ -926,11 +1031,12 @@ mi_status lzs_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, u
             const LzsScratch &q = sg[g];
             // the lane-per-cluster kernels pay when a step has enough clusters to fill them (MI_LZS_MID=0/1 forces it: A/B)
             const char *em = getenv("MI_LZS_MID");
-            const uint32_t use_mid = em ? (uint32_t)(em[0] == '1') : (uint32_t)((uint64_t)nbg * W >= (6u << 20));
+            const uint32_t use_mid = LZS_LANE_MAX >= LZS_MID_MAX ? 0u      // (k_lzs_find replays clusters of up to LZS_LANE_MAX events itself)
+                                     : em ? (uint32_t)(em[0] == '1') : (uint32_t)((uint64_t)nbg * W >= (6u << 20));
             { mi_prof_scope p(ctx, "k_lzs_part", st[g], (uint64_t)nbg * W);
               hipLaunchKernelGGL(k_lzs_part, dim3(nbg), dim3(1024), 0, st[g], n, P, q, block0 + lo[g], k); }
             { mi_prof_scope p(ctx, "k_lzs_find", st[g], (uint64_t)nbg * W);
-              hipLaunchKernelGGL(k_lzs_find, dim3(nbg * LZS_MAXPARTS), dim3(LZS_THREADS), 0, st[g], n, P, q, block0 + lo[g], k, use_mid); }
+              hipLaunchKernelGGL(k_lzs_find, dim3(nbg * LZS_KMAX), dim3(LZS_THREADS), 0, st[g], n, P, q, block0 + lo[g], k, use_mid); }
             if (ax[g] != st[g]) { MI_HIP(ctx, hipEventRecord(ctx->ev_find[g], st[g])); MI_HIP(ctx, hipStreamWaitEvent(ax[g], ctx->ev_find[g], 0)); }
             { mi_prof_scope p(ctx, "k_lzs_big<4096>", ax[g], (uint64_t)nbg * W);
               hipLaunchKernelGGL(k_lzs_big<LZS_CAP>, dim3((unsigned)ctx->num_cu * 4u), dim3(64), 0, ax[g], P, q, k, 3u); }
