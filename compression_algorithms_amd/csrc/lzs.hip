@@ -1033,10 +1033,18 @@ mi_status lzs_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, u
             const char *em = getenv("MI_LZS_MID");
             const uint32_t use_mid = LZS_LANE_MAX >= LZS_MID_MAX ? 0u      // (k_lzs_find replays clusters of up to LZS_LANE_MAX events itself)
                                      : em ? (uint32_t)(em[0] == '1') : (uint32_t)((uint64_t)nbg * W >= (6u << 20));
+            // MI_LZS_PHASE=1: the groups walk their steps out of phase (group 1 starts its first partition when group 0 has finished
+            // its first find).  The kernel timeline of round 4 (95 blocks of 1 MiB) shows the two groups in lockstep — both
+            // partitions side by side, 2 x 47 workgroups on 256 CUs for 0.26 of a step's 1.23 ms, then both finds, then both
+            // replays — but half a step apart they are no faster (4.18 -> 4.06 GB/s at 1 MiB, 6.79 -> 6.7 at 256 KiB): a group's
+            // step is a chain of three kernel LATENCIES (partition 0.26, find 0.41, longest replay 0.53 ms) whoever runs beside it.
+            static const bool phase = getenv("MI_LZS_PHASE") && getenv("MI_LZS_PHASE")[0] == '1';
+            if (phase && G > 1 && k == 0 && g == 1) MI_HIP(ctx, hipStreamWaitEvent(st[1], ctx->ev_part[0], 0));
             { mi_prof_scope p(ctx, "k_lzs_part", st[g], (uint64_t)nbg * W);
               hipLaunchKernelGGL(k_lzs_part, dim3(nbg), dim3(1024), 0, st[g], n, P, q, block0 + lo[g], k); }
             { mi_prof_scope p(ctx, "k_lzs_find", st[g], (uint64_t)nbg * W);
               hipLaunchKernelGGL(k_lzs_find, dim3(nbg * LZS_KMAX), dim3(LZS_THREADS), 0, st[g], n, P, q, block0 + lo[g], k, use_mid); }
+            if (phase && G > 1 && k == 0 && g == 0) MI_HIP(ctx, hipEventRecord(ctx->ev_part[0], st[0]));
             if (ax[g] != st[g]) { MI_HIP(ctx, hipEventRecord(ctx->ev_find[g], st[g])); MI_HIP(ctx, hipStreamWaitEvent(ax[g], ctx->ev_find[g], 0)); }
             { mi_prof_scope p(ctx, "k_lzs_big<4096>", ax[g], (uint64_t)nbg * W);
               hipLaunchKernelGGL(k_lzs_big<LZS_CAP>, dim3((unsigned)ctx->num_cu * 4u), dim3(64), 0, ax[g], P, q, k, 3u); }
