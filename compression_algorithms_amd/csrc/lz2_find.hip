@@ -21,6 +21,7 @@
 // algorithms/lz77/lz77.c:13-108 and algorithms/deflate/lz77.c:14-174).
 #include "lz_common.h"
 #include "lz2.h"
+#include "lz_dom.h"
 #include "lz_replay.h"
 #include <stdlib.h>
 
@@ -743,6 +744,7 @@ void k_lz2_big(LzP P, Lz2Scratch sc, int large)
     for (uint32_t ci = blockIdx.x; ci < ncl; ci += gridDim.x) {
         const Lz2BigDesc *dp = large == 1 ? &sc.desc[6][ci] : large == 4 ? &sc.desc[3][ci] : (ci < nhi ? &sc.desc[4][ci] : &sc.desc[5][ci - nhi]);
         const uint32_t d_block = dp->block, d_start = dp->start, n = dp->count;
+        if (n & 0x80000000u) continue;                       // k_lz2_dom has replayed it (class 6 only: counts are <= LZ2_CAP otherwise)
         const uint32_t d_anom = dp->anom, d_limit = dp->limit;
         const uint16_t *bp = sc.bigpos + (size_t)d_block * LZ2_BIG_STRIDE + d_start;
         const uint16_t *br = sc.bigrs + (size_t)d_block * LZ2_BIG_STRIDE + d_start;
@@ -751,6 +753,53 @@ void k_lz2_big(LzP P, Lz2Scratch sc, int large)
         // (in the non-PLAIN version the first-occurrence shortcut is off: that one cluster per block keeps the literal replay)
         if (d_anom == ~0u && d_limit == ~0u) big_replay<LDS_ENTRIES, NW, true>(s_occ, s_slot, lane, W, n, d_anom, d_limit, bp, br, bi, bc);
         else big_replay<LDS_ENTRIES, NW, false>(s_occ, s_slot, lane, W, n, d_anom, d_limit, bp, br, bi, bc);
+    }
+}
+
+// =============================================================================================
+// Exported clusters above 1024 entries (class 6: what the wide finder hands over — a run of one byte value with foreign words inside
+// its bucket range) that ONE word dominates: the dominated replay of the fallback pipeline (lz_dom.h: occupancy bits, a ring of the
+// live entries' slots, a FIFO of the live foreign entries; runs of the dominant word placed up to 64 entries per wave step) instead
+// of the general wave replay with a four-dword bitmap per lane, which took 18 of the "runs" family's 34 ms per 10^8 bytes.  A
+// cluster it finishes is flagged in its descriptor; k_lz2_big<LZ2_CAP> skips those and replays the rest (not dominated, given up,
+// or covering bucket 0 / T).  Reference behaviour emulated: algorithms/lz77/lz77.c:55-108.
+// =============================================================================================
+#define LZ2_DOM_DONE 0x80000000u
+__global__ __launch_bounds__(256)
+void k_lz2_dom(LzP P, Lz2Scratch sc)
+{
+    constexpr uint32_t RING = LZ2_CAP;                       // a cluster has at most LZ2_CAP entries: never more alive than that
+    static_assert((RING & (RING - 1u)) == 0, "the ring is indexed with a mask");
+    __shared__ uint32_t s_occ[LZ2_CAP / 32 + 72 + 264];     // occupancy bits (+ 64 zero words); the closed-form branch keeps <= block / W + 1 anchors here
+    __shared__ uint16_t s_ring[RING];
+    __shared__ uint16_t s_fid[DOM_FCAP], s_fpos[DOM_FCAP], s_fslot[DOM_FCAP];
+    __shared__ uint32_t s_votes[3], s_result, s_next;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t W = 1u << P.wbits;
+    const uint32_t count = sc.big_count[6];
+    uint32_t *cursor = sc.big_count + 8;                     // (zeroed with the other counters by stage 1)
+    struct Src {                                             // the exported arrays of lz2.h; results aligned with the entries
+        const uint16_t *bp, *br, *bi; uint16_t *bc;
+        __device__ __forceinline__ uint64_t ent(uint32_t i) const { return ((uint64_t)bp[i] << 16) | ((uint64_t)br[i] << 32) | ((uint64_t)bi[i] << 48); }
+        __device__ __forceinline__ void put(uint32_t i, uint32_t, uint32_t res) const { bc[i] = (uint16_t)res; }
+    };
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_next = atomicAdd(cursor, 1u);
+        __syncthreads();
+        const uint32_t ci = s_next;
+        if (ci >= count) break;
+        Lz2BigDesc *dp = &sc.desc[6][ci];
+        const uint32_t m = dp->count;
+        if (dp->anom != ~0u || dp->limit != ~0u || m > LZ2_CAP) continue;       // the cluster that covers bucket 0 / T: the general replay
+        const size_t at = (size_t)dp->block * LZ2_BIG_STRIDE + dp->start;
+        Src src{sc.bigpos + at, sc.bigrs + at, sc.bigpid + at, sc.bigcand + at};
+        // the replay writes the entries that find something; everything else reads "none" (the general replay writes all of them)
+        for (uint32_t i = tid; i < m; i += 256) src.bc[i] = (uint16_t)LZ_NONE16;
+        if (tid == 0) { s_votes[0] = s_votes[1] = s_votes[2] = 0; s_result = 0; }
+        __syncthreads();
+        const bool done = dom_cluster(src, m, W, (W < RING ? W : RING) - 1u, s_occ, s_ring, s_fid, s_fpos, s_fslot, s_votes, s_result, nullptr);
+        if (done && tid == 0) dp->count = m | LZ2_DOM_DONE;
     }
 }
 
@@ -1027,6 +1076,11 @@ mi_status lz2_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &
       } else {
           hipLaunchKernelGGL((k_lz2_big<LZ2_BIG_SMALL, 1>), dim3(grid_of((uint64_t)nb * (lz2_class_cap(4) + lz2_class_cap(5)))), dim3(64), 0, s, P, sc, 0);
       } }
+    { mi_prof_scope p(ctx, "k_lz2_dom", s, (uint64_t)nb * P.block);
+      // clusters above 1024 entries that one word dominates (none in text: an empty launch of 13 KiB workgroups); what it leaves
+      // goes to the general replay below
+      const uint64_t worst = (uint64_t)nb * lz2_class_cap(6);
+      hipLaunchKernelGGL(k_lz2_dom, dim3((unsigned)(worst < (uint64_t)ncu * 4u ? worst : (uint64_t)ncu * 4u)), dim3(256), 0, s, P, sc); }
     { mi_prof_scope p(ctx, "k_lz2_big<4096>", s, (uint64_t)nb * P.block);
       hipLaunchKernelGGL((k_lz2_big<LZ2_CAP, 4>), dim3(grid_of((uint64_t)nb * lz2_class_cap(6) < 4096 ? (uint64_t)nb * lz2_class_cap(6) : 4096)), dim3(64), 0, s, P, sc, 1); }   // 24 KiB each, normally none: a small striding grid
     MI_HIP(ctx, hipGetLastError());

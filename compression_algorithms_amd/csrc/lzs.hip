@@ -148,7 +148,25 @@ void k_lzs_part(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     for (uint32_t i = tid; i < LZS_NG / 32; i += 1024) s_safe[i] = 0;
     if (tid == 0) s_flag = 0;
     __syncthreads();
-    for (uint32_t e = tid; e < NE; e += 1024) if (valid(e)) atomicAdd(&s_grp[grp(coord(e))], 1u);
+    // coordinates of a thread's events, EB at a time: the (dependent-free) global loads of a batch are issued together.  One
+    // load per iteration — as this loop was written until round 4 — is a chain of 128 HBM round trips on the ONE workgroup per
+    // block that every step of the block waits for: most of this kernel's 0.26 ms at 95 blocks (kernel timeline, round 4)
+    constexpr uint32_t EB = 16u;
+    auto coords_batch = [&](uint32_t e0, uint32_t (&cv)[EB], uint32_t &vmask) {
+        vmask = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < EB; ++u) {
+            const uint32_t e = e0 + u * 1024u;
+            cv[u] = 0;
+            if (e < NE && valid(e)) { cv[u] = coord(e); vmask |= 1u << u; }
+        }
+    };
+    for (uint32_t e0 = tid; e0 < NE; e0 += EB * 1024u) {
+        uint32_t cv[EB], vm;
+        coords_batch(e0, cv, vm);
+#pragma unroll
+        for (uint32_t u = 0; u < EB; ++u) if ((vm >> u) & 1u) atomicAdd(&s_grp[grp(cv[u])], 1u);
+    }
     __syncthreads();
 
     // ---- overflow certificate (lz2_partition.hip): out_g = max(in_g + c_g - Gw, c_g - 1, 0), a scan of x -> max(x + a, b) maps
@@ -252,15 +270,22 @@ void k_lzs_part(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     //      order by construction).  Round 3 sorted the ids into per-part lists here with one stable radix pass over 2 W ids —
     //      half of this kernel, and it runs on ONE workgroup per block and step, on the chain every step waits for.
     uint8_t *part_in = reinterpret_cast<uint8_t *>(s_grp);          // [NE <= 131072] (the group array is dead: barrier above)
-    for (uint32_t e = tid; e < NE; e += 1024) {
-        uint32_t pk = 0xFFu;
-        if (valid(e)) {
-            const uint32_t c = coord(e);
-            uint32_t lo = 0, hi = K - 1;                // last k with thr[k] <= c
-            while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (s_thr[mid] <= c) lo = mid; else hi = mid - 1; }
-            pk = lo;
+    for (uint32_t e0 = tid; e0 < NE; e0 += EB * 1024u) {
+        uint32_t cv[EB], vm;
+        coords_batch(e0, cv, vm);
+#pragma unroll
+        for (uint32_t u = 0; u < EB; ++u) {
+            const uint32_t e = e0 + u * 1024u;
+            if (e >= NE) continue;
+            uint32_t pk = 0xFFu;
+            if ((vm >> u) & 1u) {
+                const uint32_t c = cv[u];
+                uint32_t lo = 0, hi = K - 1;            // last k with thr[k] <= c
+                while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (s_thr[mid] <= c) lo = mid; else hi = mid - 1; }
+                pk = lo;
+            }
+            part_in[e] = (uint8_t)pk;
         }
-        part_in[e] = (uint8_t)pk;
     }
     __syncthreads();
     {
@@ -872,6 +897,15 @@ void k_lzs_big(LzP P, LzsScratch sc, uint32_t step, uint32_t cls)
         const uint32_t *key = sc.big_key + first, *info = sc.big_info + first;
         uint32_t *slot_new = sc.slot + (size_t)lb * sc.S + t0;
         uint32_t *cand = sc.cand + (size_t)lb * sc.S + t0;
+        // A launch lasts as long as its longest chain, and a chain shares its SIMD's issue slots with up to seven other waves
+        // (~75 wave-uniform instructions per event: 512 events took ~0.5 ms, the whole launch, where they need ~0.07 alone):
+        // the longer the cluster, the higher the wave's priority while it replays it (s_setprio takes an immediate)
+        if (CAPB <= 1024u) {
+            if (m >= 384u) __builtin_amdgcn_s_setprio(3);
+            else if (m >= 256u) __builtin_amdgcn_s_setprio(2);
+            else if (m >= 128u) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         // the first 64 records serve the set-up pass and the first round of the replay: one load round for most clusters
         uint32_t n_key = lane < m ? key[lane] : 0u, n_inf = lane < m ? info[lane] : 0u;
         for (uint32_t idx = lane; idx < BW; idx += 64u) s_bm[idx] = 0;
