@@ -751,7 +751,22 @@ void k_lz2_big(LzP P, Lz2Scratch sc, int large)
         const uint16_t *bi = sc.bigpid + (size_t)d_block * LZ2_BIG_STRIDE + d_start;
         uint16_t *bc = sc.bigcand + (size_t)d_block * LZ2_BIG_STRIDE + d_start;
         // (in the non-PLAIN version the first-occurrence shortcut is off: that one cluster per block keeps the literal replay)
-        if (d_anom == ~0u && d_limit == ~0u) big_replay<LDS_ENTRIES, NW, true>(s_occ, s_slot, lane, W, n, d_anom, d_limit, bp, br, bi, bc);
+        // the occupancy bitmap takes one register per lane and 2048 slots: a cluster is replayed with as few as it needs (every
+        // first-fit and every clear walks all of them; the wide class was replayed with four whatever its size)
+        const bool plain = d_anom == ~0u && d_limit == ~0u;
+        if constexpr (NW > 1) {
+            if (n <= 2048u) {
+                if (plain) big_replay<LDS_ENTRIES, 1, true>(s_occ, s_slot, lane, W, n, d_anom, d_limit, bp, br, bi, bc);
+                else big_replay<LDS_ENTRIES, 1, false>(s_occ, s_slot, lane, W, n, d_anom, d_limit, bp, br, bi, bc);
+                continue;
+            }
+            if (n <= 4096u) {
+                if (plain) big_replay<LDS_ENTRIES, 2, true>(s_occ, s_slot, lane, W, n, d_anom, d_limit, bp, br, bi, bc);
+                else big_replay<LDS_ENTRIES, 2, false>(s_occ, s_slot, lane, W, n, d_anom, d_limit, bp, br, bi, bc);
+                continue;
+            }
+        }
+        if (plain) big_replay<LDS_ENTRIES, NW, true>(s_occ, s_slot, lane, W, n, d_anom, d_limit, bp, br, bi, bc);
         else big_replay<LDS_ENTRIES, NW, false>(s_occ, s_slot, lane, W, n, d_anom, d_limit, bp, br, bi, bc);
     }
 }

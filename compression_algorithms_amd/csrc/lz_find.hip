@@ -501,8 +501,17 @@ void k_lz_emulate_giant(LzP P, LzScratch sc)
             if (tid < 64) {
                 const bool plain = anom == ~0u && limit == ~0u;
                 if (m <= LZ_GIANT_CAP) {
-                    if (plain) big_replay<LZ_GIANT_CAP, (LZ_GIANT_CAP + 2047) / 2048, true>(s_occ32, s_slot16, (uint32_t)tid, W, m, anom, limit, gp, grs, gid, gc);
-                    else big_replay<LZ_GIANT_CAP, (LZ_GIANT_CAP + 2047) / 2048, false>(s_occ32, s_slot16, (uint32_t)tid, W, m, anom, limit, gp, grs, gid, gc);
+                    // as few bitmap registers as the cluster needs (2048 slots each): every first-fit and every clear walks them all
+                    if (m <= 4096u) {
+                        if (plain) big_replay<LZ_GIANT_CAP, 2, true>(s_occ32, s_slot16, (uint32_t)tid, W, m, anom, limit, gp, grs, gid, gc);
+                        else big_replay<LZ_GIANT_CAP, 2, false>(s_occ32, s_slot16, (uint32_t)tid, W, m, anom, limit, gp, grs, gid, gc);
+                    } else if (m <= 8192u) {
+                        if (plain) big_replay<LZ_GIANT_CAP, 4, true>(s_occ32, s_slot16, (uint32_t)tid, W, m, anom, limit, gp, grs, gid, gc);
+                        else big_replay<LZ_GIANT_CAP, 4, false>(s_occ32, s_slot16, (uint32_t)tid, W, m, anom, limit, gp, grs, gid, gc);
+                    } else {
+                        if (plain) big_replay<LZ_GIANT_CAP, (LZ_GIANT_CAP + 2047) / 2048, true>(s_occ32, s_slot16, (uint32_t)tid, W, m, anom, limit, gp, grs, gid, gc);
+                        else big_replay<LZ_GIANT_CAP, (LZ_GIANT_CAP + 2047) / 2048, false>(s_occ32, s_slot16, (uint32_t)tid, W, m, anom, limit, gp, grs, gid, gc);
+                    }
                 } else {
                     // posA / posB are free after k_lz_sort_home; every cluster uses its own range [a, a + m)
                     uint16_t *gslot = sc.posA + (size_t)lb * LZ_MAX_BLOCK + a, *gopos = sc.posB + (size_t)lb * LZ_MAX_BLOCK + a;
