@@ -190,6 +190,20 @@ def test_overshooting_last_match_every_block(flavour, wbits):
     assert st.nbytes <= lz.bound_bytes(len(data), p)
 
 
+@pytest.mark.parametrize("nblocks", [9, 1001, 1003])
+@pytest.mark.parametrize("flavour,wbits", CONFIGS)
+def test_tiny_blocks_whose_count_is_not_a_multiple_of_eight(flavour, wbits, nblocks):
+    """k_lz2_find deals its workgroups round the 8 XCDs (item = (id & 7) * ceil(work / 8) + (id >> 3)), which needs
+    a grid of 8 * ceil(work / 8); blocks below 64 bytes have ONE part each, so the grid used to be the block count — with 1 001
+    blocks of 8 bytes six parts were never run and their candidate lists stayed stale (1 000 blocks, the case above, hid it)."""
+    rng = np.random.default_rng(nblocks)
+    unit = np.array([0x41, 0, 0, 0, 0x61, 0x62, 0x63, 0x41], np.uint8)
+    data = np.tile(unit, nblocks)
+    flip = rng.integers(0, len(data), len(data) // 16)
+    data[flip] = rng.integers(0, 256, len(flip), dtype=np.uint8)      # not every block the same: a stale list would be a wrong one
+    _check(data, flavour, wbits, block=8)
+
+
 @pytest.mark.parametrize("flavour,wbits", CONFIGS)
 def test_random_small_blocks_inside_bound(flavour, wbits):
     from compression_algorithms_amd import lz
