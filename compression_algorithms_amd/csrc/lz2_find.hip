@@ -1050,10 +1050,19 @@ mi_status lz2_stage_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_
 // for that behind the parse kernel of the batch before, on the one chain the pipeline is bound by (kernel timeline, round 4:
 // partition 3.7 + find 4.45 + this 1.0 ms of a 9.3 ms batch period)
 mi_status lz2_stage_find_wide(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
-                              const Lz2Scratch &sc, hipStream_t s)
+                              const Lz2Scratch &sc, hipStream_t s, bool aside)
 {
-    mi_prof_scope p(ctx, "k_lz2_find_wide", s, (uint64_t)nb * P.block);
-    hipLaunchKernelGGL(k_lz2_find_wide, dim3(256), dim3(LZ2_THREADS), 0, s, d_in, n, P, sc, block0, lz2_find_grid(P, nb));
+    // on the side stream this launch is normally empty and merely waits for its LDS behind the other stages (6 ms of "duration"
+    // per batch in rocprofv3): timing it would report that wait as the pipeline's dominant kernel (as for the fallback chain,
+    // lz_find_batch); MI_LZ_PROF_FALLBACK=1 times it (inputs with wide parts: scripts/adv_profile.py)
+    static const bool prof_fb = getenv("MI_LZ_PROF_FALLBACK") != nullptr;
+    const int saved_prof = ctx->profiling;
+    if (aside && !prof_fb) ctx->profiling = 0;
+    {
+        mi_prof_scope p(ctx, "k_lz2_find_wide", s, (uint64_t)nb * P.block);
+        hipLaunchKernelGGL(k_lz2_find_wide, dim3(256), dim3(LZ2_THREADS), 0, s, d_in, n, P, sc, block0, lz2_find_grid(P, nb));
+    }
+    ctx->profiling = saved_prof;
     MI_HIP(ctx, hipGetLastError());
     return MI_OK;
 }

@@ -620,7 +620,7 @@ mi_status lz2_stage_partition(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, ui
 mi_status lz2_stage_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
                          const Lz2Scratch &sc, hipStream_t s);
 mi_status lz2_stage_find_wide(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
-                              const Lz2Scratch &sc, hipStream_t s);
+                              const Lz2Scratch &sc, hipStream_t s, bool aside);
 mi_status lz2_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &sc, hipStream_t s);
 void   lz2_launch_scatter(const Lz2Scratch &sc, uint16_t *cand_by_pos, uint32_t nb, hipStream_t s);
 
@@ -668,7 +668,7 @@ mi_status lz_find_stage_a(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64
     const bool wide_aside = sf != s && ev_wide && !wide_inline;
     if (wide_aside) {
         // first thing on the side chain: stage B waits for it (exported clusters of wide parts), the fallback chain behind it does not matter
-        st = lz2_stage_find_wide(ctx, P, d_in, n, block0, nb, sc2, sf);
+        st = lz2_stage_find_wide(ctx, P, d_in, n, block0, nb, sc2, sf, true);
         if (st) return st;
         MI_HIP(ctx, hipEventRecord(ev_wide, sf));
     }
@@ -679,7 +679,7 @@ mi_status lz_find_stage_a(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64
     if (sf != s) MI_HIP(ctx, hipEventRecord(ev_fb, sf));
     st = lz2_stage_find(ctx, P, d_in, n, block0, nb, sc2, s);
     if (st || wide_aside) return st;
-    return lz2_stage_find_wide(ctx, P, d_in, n, block0, nb, sc2, s);
+    return lz2_stage_find_wide(ctx, P, d_in, n, block0, nb, sc2, s, false);
 }
 mi_status lz_find_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &sc2, hipStream_t s)
 {
