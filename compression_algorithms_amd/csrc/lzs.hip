@@ -126,6 +126,8 @@ void k_lzs_part(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     const uint64_t off = (block0 + lb) * (uint64_t)P.block;
     const uint32_t n = (uint32_t)((n_total - off) < P.block ? (n_total - off) : P.block);
     const uint32_t W = 1u << P.wbits, t0 = step * W;
+    long long tkp = clock64();
+#define LZP_TICK(k) do { if (sc.dbg && tid == 0) { long long t2 = clock64(); atomicAdd((unsigned long long *)&sc.dbg[16 + (k)], (unsigned long long)(t2 - tkp)); tkp = t2; } } while (0)
     LzsMeta *mt = sc.meta + lb;
     if (t0 >= n || mt->fallback) { if (tid == 0) mt->nparts = 0; return; }
     const uint32_t nnew = (n - t0) < W ? (n - t0) : W;
@@ -138,10 +140,6 @@ void k_lzs_part(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
         const uint32_t t = e >> 1;
         return (e & 1u) ? (step ? true : (t == W - 1u && nnew == W)) : (t < nnew);
     };
-    auto coord = [&](uint32_t e) -> uint32_t {
-        const uint32_t t = e >> 1;
-        return (e & 1u) ? (step ? (slot_old[t] & ~LZS_DEAD) : 0u) : (key[t] & Tmask);
-    };
     auto grp = [&](uint32_t c) -> uint32_t { const uint32_t g = c >> gshift; return g < LZS_NG ? g : LZS_NG - 1u; };   // slots past T: the last group
 
     for (uint32_t i = tid; i < LZS_NG; i += 1024) s_grp[i] = 0;
@@ -152,23 +150,46 @@ void k_lzs_part(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     // load per iteration — as this loop was written until round 4 — is a chain of 128 HBM round trips on the ONE workgroup per
     // block that every step of the block waits for: most of this kernel's 0.26 ms at 95 blocks (kernel timeline, round 4)
     constexpr uint32_t EB = 16u;
-    auto coords_batch = [&](uint32_t e0, uint32_t (&cv)[EB], uint32_t &vmask) {
-        vmask = 0;
+    auto load_batch = [&](uint32_t e0, uint32_t (&raw)[EB]) {
+        // every load of the batch is UNCONDITIONAL (the address is chosen with a select, out-of-range ids read a clamped
+        // element): a load under an `if` sits in a basic block of its own together with the wait for its value, and sixteen
+        // such blocks are sixteen round trips one after the other — what the first "batched" form of this code still did
 #pragma unroll
         for (uint32_t u = 0; u < EB; ++u) {
             const uint32_t e = e0 + u * 1024u;
-            cv[u] = 0;
-            if (e < NE && valid(e)) { cv[u] = coord(e); vmask |= 1u << u; }
+            uint32_t t = e >> 1;
+            const uint32_t tmax = (e & 1u) ? W - 1u : nnew - 1u;      // (a new position past the block's end, an id past 2 W: clamped, then ignored)
+            if (t > tmax) t = tmax;
+            const uint32_t *ptr = (e & 1u) ? slot_old + t : key + t;
+            raw[u] = *ptr;
         }
     };
-    for (uint32_t e0 = tid; e0 < NE; e0 += EB * 1024u) {
-        uint32_t cv[EB], vm;
-        coords_batch(e0, cv, vm);
+    auto coord_of = [&](uint32_t e, uint32_t raw, bool &ok) -> uint32_t {
+        ok = e < NE && valid(e);
+        return !ok ? 0u : (e & 1u) ? (step ? (raw & ~LZS_DEAD) : 0u) : (raw & Tmask);
+    };
+    // (the next batch's loads are in flight while this batch's events are worked on)
+    {
+        uint32_t raw[EB], nraw[EB];
+        load_batch((uint32_t)tid, raw);
+        for (uint32_t e0 = tid; e0 < NE; e0 += EB * 1024u) {
+            const bool more = e0 + EB * 1024u < NE;
+            if (more) load_batch(e0 + EB * 1024u, nraw);
 #pragma unroll
-        for (uint32_t u = 0; u < EB; ++u) if ((vm >> u) & 1u) atomicAdd(&s_grp[grp(cv[u])], 1u);
+            for (uint32_t u = 0; u < EB; ++u) {
+                bool ok;
+                const uint32_t c = coord_of(e0 + u * 1024u, raw[u], ok);
+                if (ok) atomicAdd(&s_grp[grp(c)], 1u);
+            }
+            if (more) {
+#pragma unroll
+                for (uint32_t u = 0; u < EB; ++u) raw[u] = nraw[u];
+            }
+        }
     }
     __syncthreads();
 
+    LZP_TICK(0);
     // ---- overflow certificate (lz2_partition.hip): out_g = max(in_g + c_g - Gw, c_g - 1, 0), a scan of x -> max(x + a, b) maps
     constexpr uint32_t GPT = LZS_NG / 1024;
     const uint32_t g0 = tid * GPT;
@@ -206,6 +227,7 @@ void k_lzs_part(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     const uint32_t nev = s_grp[LZS_NG - 1];
     auto is_safe = [&](uint32_t g) -> bool { return (s_safe[g >> 5] >> (g & 31u)) & 1u; };
 
+    LZP_TICK(1);
     // ---- greedy cuts: every part takes as many events as stage 2 holds, ending at the last certified group that fits
     if (tid < 64) {
         const uint32_t lane = (uint32_t)tid;
@@ -246,7 +268,8 @@ void k_lzs_part(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
         }
     }
     __syncthreads();
-    const uint32_t K = s_K;                             // <= 63
+    const uint32_t K = s_K;                             // <= LZS_KMAX - 1
+    LZP_TICK(2);
     if (tid < (int)K) {
         auto cnt_below = [&](uint32_t h) -> uint32_t { return h == 0 ? 0u : (h == 0xFFFFFFFFu ? nev : s_grp[(h >> gshift) - 1u]); };
         const uint32_t a = s_thr[tid], b = s_thr[tid + 1];
@@ -270,29 +293,52 @@ void k_lzs_part(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
     //      order by construction).  Round 3 sorted the ids into per-part lists here with one stable radix pass over 2 W ids —
     //      half of this kernel, and it runs on ONE workgroup per block and step, on the chain every step waits for.
     uint8_t *part_in = reinterpret_cast<uint8_t *>(s_grp);          // [NE <= 131072] (the group array is dead: barrier above)
-    for (uint32_t e0 = tid; e0 < NE; e0 += EB * 1024u) {
-        uint32_t cv[EB], vm;
-        coords_batch(e0, cv, vm);
+    // the part of every PAIR of groups (of its first coordinate): one binary search per pair, 16 pairs per thread
+    __shared__ uint8_t s_gp2[LZS_NG / 2u];
+    for (uint32_t g2 = tid; g2 < LZS_NG / 2u; g2 += 1024u) {
+        const uint32_t c = g2 << (gshift + 1u);
+        uint32_t lo = 0, hi = K - 1;                    // last k with thr[k] <= c
+        while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (s_thr[mid] <= c) lo = mid; else hi = mid - 1; }
+        s_gp2[g2] = (uint8_t)lo;
+    }
+    __syncthreads();
+    LZP_TICK(3);
+    {
+        uint32_t raw[EB], nraw[EB];
+        load_batch((uint32_t)tid, raw);
+        for (uint32_t e0 = tid; e0 < NE; e0 += EB * 1024u) {
+            const bool more = e0 + EB * 1024u < NE;
+            if (more) load_batch(e0 + EB * 1024u, nraw);
 #pragma unroll
-        for (uint32_t u = 0; u < EB; ++u) {
-            const uint32_t e = e0 + u * 1024u;
-            if (e >= NE) continue;
-            uint32_t pk = 0xFFu;
-            if ((vm >> u) & 1u) {
-                const uint32_t c = cv[u];
-                uint32_t lo = 0, hi = K - 1;            // last k with thr[k] <= c
-                while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (s_thr[mid] <= c) lo = mid; else hi = mid - 1; }
-                pk = lo;
+            for (uint32_t u = 0; u < EB; ++u) {
+                const uint32_t e = e0 + u * 1024u;
+                if (e >= NE) continue;
+                bool ok;
+                const uint32_t c = coord_of(e, raw[u], ok);
+                // the part of the coordinate's group PAIR from the table, plus one where a part boundary lies between the pair's two
+                // groups (boundaries are group boundaries: at most one inside a pair): two dependent LDS reads, no loop, where the
+                // binary search over ~53 thresholds took six
+                uint32_t g2 = c >> (gshift + 1u);
+                if (g2 >= LZS_NG / 2u) g2 = LZS_NG / 2u - 1u;
+                uint32_t pk = s_gp2[g2];
+                pk += (pk + 1u < K && s_thr[pk + 1u] <= c) ? 1u : 0u;
+                part_in[e] = ok ? (uint8_t)pk : (uint8_t)0xFFu;
             }
-            part_in[e] = (uint8_t)pk;
+            if (more) {
+#pragma unroll
+                for (uint32_t u = 0; u < EB; ++u) raw[u] = nraw[u];
+            }
         }
     }
     __syncthreads();
+    LZP_TICK(4);
     {
         uint4 *dst = reinterpret_cast<uint4 *>(sc.pmap + (size_t)lb * NE);
         const uint4 *srcv = reinterpret_cast<const uint4 *>(part_in);
         for (uint32_t i = tid; i < NE / 16u; i += 1024u) dst[i] = srcv[i];
     }
+    LZP_TICK(5);
+    if (sc.dbg && tid == 0) atomicAdd((unsigned long long *)&sc.dbg[23], 1ull);
 }
 
 // =============================================================================================
@@ -1040,7 +1086,7 @@ mi_status lzs_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, u
     uint32_t G = eg ? (uint32_t)atoi(eg) : 2u;
     if (G < 1u || G > 2u) G = 2u;
     if (G > nb || !multi) G = 1;
-    MI_HIP(ctx, hipMemsetAsync(all.counters, 0, (size_t)LZS_CTR_WORDS * 4 * 4 + 16 * 8, s));
+    MI_HIP(ctx, hipMemsetAsync(all.counters, 0, (size_t)LZS_CTR_WORDS * 4 * 4 + 32 * 8, s));      // counters of four groups + the 32 debug counters (the flag list lies behind them)
     MI_HIP(ctx, hipEventRecord(ctx->ev_fork, s));
     LzsScratch sg[2]; uint32_t lo[3];
     for (uint32_t g = 0; g <= G; ++g) lo[g] = (uint32_t)(((uint64_t)nb * g) / G);
@@ -1109,8 +1155,14 @@ mi_status lzs_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, u
         } else *flag_list = nullptr;
     }
     if (sc.dbg) {                                        // development aid: phase shares of k_lzs_find on stderr
-        uint64_t v[16];
+        uint64_t v[24];
         if (hipMemcpy(v, sc.dbg, sizeof v, hipMemcpyDeviceToHost) == hipSuccess && v[8]) {
+            if (v[23]) {
+                static const char *pn[6] = {"zero + count", "certificate + prefix", "cuts", "part sizes + list", "part of every event", "map out"};
+                double pt = 0; for (int k = 0; k < 6; ++k) pt += (double)v[16 + k];
+                fprintf(stderr, "k_lzs_part: %llu workgroups, %.0f cycles each\n", (unsigned long long)v[23], pt / v[23]);
+                for (int k = 0; k < 6; ++k) fprintf(stderr, "   %-22s %5.1f %%  %8.0f cycles\n", pn[k], 100.0 * v[16 + k] / pt, (double)v[16 + k] / v[23]);
+            }
             static const char *nm[8] = {"gather", "sort", "sweep", "place", "permute", "lane replay", "export", "out"};
             double tot = 0; for (int k = 0; k < 8; ++k) tot += (double)v[k];
             fprintf(stderr, "k_lzs_find: %llu parts, %.0f events, %.1f clusters, %.2f wave clusters with %.0f events per part; %.0f cycles per part; flagged %u\n",
