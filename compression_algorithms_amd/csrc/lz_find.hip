@@ -307,8 +307,10 @@ __device__ void replay_cluster(const TileView &v, uint32_t s, uint32_t e, uint32
     }
 }
 
-__device__ __forceinline__ void lz_emulate_tile(LzP P, LzScratch sc, uint32_t lb, uint32_t t)
+__device__ __forceinline__ void lz_emulate_tile(LzP P, LzScratch sc, uint32_t lb, uint32_t t, uint64_t *dbg)
 {
+    long long tkt = dbg ? clock64() : 0;
+#define TL_TICK(k) do { if (dbg && threadIdx.x == 0) { long long t2 = clock64(); atomicAdd((unsigned long long *)&dbg[40 + (k)], (unsigned long long)(t2 - tkt)); tkt = t2; } } while (0)
     __shared__ uint16_t s_pos[LZ_TILE_CAP], s_rs[LZ_TILE_CAP], s_pid[LZ_TILE_CAP], s_occ[LZ_TILE_CAP];
     __shared__ uint32_t s_bm[LZ_TILE_CAP / 32 + 2];
     __shared__ uint32_t s_bm1[LZ_TILE_CAP / 1024 + 2];
@@ -320,19 +322,44 @@ __device__ __forceinline__ void lz_emulate_tile(LzP P, LzScratch sc, uint32_t lb
     const uint32_t lo = t * LZ_TILE_NOM, hi = (lo + LZ_TILE_NOM < n) ? lo + LZ_TILE_NOM : n;
     if (lo >= n) return;
     const uint64_t *E = sc.eA + (size_t)lb * LZ_MAX_BLOCK;
-    auto gid_at = [&](uint32_t i) { return (uint32_t)E[i] & 0xFFFFu; };
-    auto is_head = [&](uint32_t i) { return i == 0 || gid_at(i) != gid_at(i - 1); };
 
     if (tid == 0) { s_a = ~0u; s_b = ~0u; s_lasthead = 0; }
     __syncthreads();
+    // Cluster heads of a stretch of up to 4 096 + LZ_GIANT_MIN sorted entries, eight per thread: the cluster numbers of entry i and
+    // of i - 1 come in as UNCONDITIONAL loads (indices clamped), all sixteen of a thread before the first compare.  (Written as
+    // "for (i ...) if (is_head(i)) ..." every iteration was a dependent HBM round trip — a load under a condition waits for its value
+    // in its own basic block — and a tile did ~40 of them in a row before its replay began: round 4, on the way to "pages".)
+    auto heads_of = [&](uint32_t first, uint32_t end, auto &&fn) {            // fn(i) for every head i in [first, end), end - first <= 8 * 512
+        uint32_t g[8], gp[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+            uint32_t i = first + tid + 512u * u;
+            if (i >= n) i = n - 1u;
+            g[u] = (uint32_t)E[i] & 0xFFFFu;
+            gp[u] = (uint32_t)E[i ? i - 1u : 0u] & 0xFFFFu;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+            const uint32_t i = first + tid + 512u * u;
+            if (i < end && (i == 0 || g[u] != gp[u])) fn(i);
+        }
+    };
     // a = first head in [lo, hi)
-    for (uint32_t i = lo + tid; i < hi; i += 512) if (is_head(i)) atomicMin(&s_a, i);
+    heads_of(lo, hi, [&](uint32_t i) { atomicMin(&s_a, i); });
     __syncthreads();
     const uint32_t a = s_a;
     if (a == ~0u) return;                       // a cluster that started earlier covers this whole range
     // b = first head at or after hi (or n); give up after LZ_GIANT_MIN entries: the last cluster is a giant
-    for (uint32_t i = hi + tid; i < n && i <= hi + LZ_GIANT_MIN; i += 512) if (is_head(i)) atomicMin(&s_b, i);
-    for (uint32_t i = a + tid; i < hi; i += 512) if (is_head(i)) atomicMax(&s_lasthead, i);
+    static_assert(LZ_TILE_NOM <= 8 * 512 && LZ_GIANT_MIN + 1 <= 8 * 512 + 1, "heads_of covers eight entries per thread");
+    {
+        const uint32_t end2 = (n < hi + LZ_GIANT_MIN + 1u) ? n : hi + LZ_GIANT_MIN + 1u;
+        heads_of(hi, end2 < hi + 8u * 512u ? end2 : hi + 8u * 512u, [&](uint32_t i) { atomicMin(&s_b, i); });
+        if (end2 > hi + 8u * 512u && tid == 0) {                              // (the one index beyond eight per thread)
+            const uint32_t i = hi + 8u * 512u;
+            if (((uint32_t)E[i] & 0xFFFFu) != ((uint32_t)E[i - 1u] & 0xFFFFu)) atomicMin(&s_b, i);
+        }
+    }
+    heads_of(a, hi, [&](uint32_t i) { atomicMax(&s_lasthead, i); });
     __syncthreads();
     uint32_t b = s_b;
     if (b == ~0u) b = (n <= hi + LZ_GIANT_MIN) ? n : ~0u;
@@ -347,18 +374,34 @@ __device__ __forceinline__ void lz_emulate_tile(LzP P, LzScratch sc, uint32_t lb
     }
     const uint32_t m = b - a;
     if (m == 0) return;
-    // ---- load the tile
-    for (uint32_t i = tid; i < m; i += 512) {
-        const uint64_t e = E[a + i];
-        const uint32_t gid = (uint32_t)e & 0xFFFFu;
-        const bool head = (i == 0) || (((uint32_t)E[a + i - 1] & 0xFFFFu) != gid);
-        s_pos[i] = (uint16_t)(e >> 16);
-        s_rs[i] = (uint16_t)((((uint32_t)(e >> 32) & 0xFFFFu) - a) | (head ? RS_HEAD : 0u));
-        s_pid[i] = (uint16_t)(e >> 48);
+    TL_TICK(0);
+    // ---- load the tile: sixteen entries per thread at most, eight at a time, loads first (unconditional, clamped)
+    for (uint32_t i0 = 0; i0 < m; i0 += 8u * 512u) {
+        uint64_t ev[8]; uint32_t pg[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+            uint32_t i = i0 + tid + 512u * u;
+            if (i >= m) i = m - 1u;
+            ev[u] = E[a + i];
+            pg[u] = (uint32_t)E[a + (i ? i - 1u : 0u)] & 0xFFFFu;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+            const uint32_t i = i0 + tid + 512u * u;
+            if (i < m) {
+                const uint64_t e = ev[u];
+                const uint32_t gid = (uint32_t)e & 0xFFFFu;
+                const bool head = (i == 0) || (pg[u] != gid);
+                s_pos[i] = (uint16_t)(e >> 16);
+                s_rs[i] = (uint16_t)((((uint32_t)(e >> 32) & 0xFFFFu) - a) | (head ? RS_HEAD : 0u));
+                s_pid[i] = (uint16_t)(e >> 48);
+            }
+        }
     }
     for (uint32_t i = tid; i < LZ_TILE_CAP / 32 + 2; i += 512) s_bm[i] = 0;
     if (tid < LZ_TILE_CAP / 1024 + 2) s_bm1[tid] = 0;
     __syncthreads();
+    TL_TICK(1);
     // pid is a POSITION (first occurrence of the word); compare through it directly
     TileView v{s_pos, s_rs, s_pid, s_occ, s_bm, s_bm1, m};
     const uint32_t W = 1u << P.wbits;
@@ -392,14 +435,17 @@ __device__ __forceinline__ void lz_emulate_tile(LzP P, LzScratch sc, uint32_t lb
         }
         replay_cluster(v, s, e, W, first ? mt.anom_idx : ~0u, first ? mt.limit_idx : ~0u, cand);
     }
+    __syncthreads();
+    TL_TICK(2);
+    if (dbg && threadIdx.x == 0) atomicAdd((unsigned long long *)&dbg[43], 1ull);
 }
 
 __global__ __launch_bounds__(512)
-void k_lz_emulate(LzP P, LzScratch sc, uint32_t nb, const uint32_t *__restrict__ blist, const uint32_t *__restrict__ bcount)
+void k_lz_emulate(LzP P, LzScratch sc, uint32_t nb, const uint32_t *__restrict__ blist, const uint32_t *__restrict__ bcount, uint64_t *dbg)
 {
     const uint32_t count = bcount ? *bcount : nb;
     for (uint32_t bi = blockIdx.y; bi < count; bi += gridDim.y) {
-        lz_emulate_tile(P, sc, blist ? blist[bi] : bi, blockIdx.x);
+        lz_emulate_tile(P, sc, blist ? blist[bi] : bi, blockIdx.x, dbg);
         __syncthreads();
     }
 }
@@ -732,7 +778,7 @@ mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t
     {
         mi_prof_scope p(ctx, "k_lz_emulate", s, (uint64_t)nb * P.block);
         const uint32_t tiles = (P.block + LZ_TILE_NOM - 1) / LZ_TILE_NOM;
-        hipLaunchKernelGGL(k_lz_emulate, dim3(tiles, fgrid), dim3(512), 0, s, P, sc, nb, blist, bcount);
+        hipLaunchKernelGGL(k_lz_emulate, dim3(tiles, fgrid), dim3(512), 0, s, P, sc, nb, blist, bcount, ctx->lz_dbg);
     }
     {
         // dominated giant clusters first (78 KiB of LDS: two workgroups per CU); what it leaves goes to the general kernel

@@ -692,8 +692,10 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
 #pragma unroll
         for (uint32_t c = 0; c < CH; ++c) {
             const uint32_t i = tid + c * LZS_THREADS;
-            // (written by this workgroup in the gather: an agent-scope load goes past the L1, which may hold nothing newer but is not coherent)
-            rt[c] = i < m ? __hip_atomic_load(&plist[s_j1[i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 1 : 0u;
+            // (written by this workgroup in the gather: an agent-scope load goes past the L1, which may hold nothing newer but is not
+            //  coherent.  UNCONDITIONAL, index clamped, value used further down: a load inside a conditional expression waits for its
+            //  value in its own basic block, and the thread's loads would be one round trip after the other)
+            rt[c] = __hip_atomic_load(&plist[s_j1[i < m ? i : m - 1u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #pragma unroll
         for (uint32_t c = 0; c < CH; ++c) {
@@ -714,7 +716,7 @@ void k_lzs_find(uint64_t n_total, LzP P, LzsScratch sc, uint64_t block0, uint32_
 #pragma unroll
         for (uint32_t c = 0; c < CH; ++c) {
             const uint32_t i = tid + c * LZS_THREADS;
-            if (i < m) { e_key[i] = rk[c]; e_rf[i] = (uint16_t)rr[c]; e_t[i] = (uint16_t)rt[c]; }
+            if (i < m) { e_key[i] = rk[c]; e_rf[i] = (uint16_t)rr[c]; e_t[i] = (uint16_t)(rt[c] >> 1); }
         }
     }
     uint16_t *e_slot = s_r;
