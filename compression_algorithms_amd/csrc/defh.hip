@@ -193,9 +193,13 @@ void k_defh_encode(const uint32_t *__restrict__ trec_all, uint32_t *__restrict__
     // ---- pack, DEFH_THREADS * DEFH_PER tokens per round; a thread owns DEFH_PER consecutive tokens
     uint64_t qbase = 0;
     uint32_t carry = 0;
+    // (the next round's records are in flight while this round is packed: a round is three barriers and one HBM round trip)
+    uint4 nrv = make_uint4(0, 0, 0, 0);
+    if ((uint32_t)tid * DEFH_PER < ntok) nrv = *reinterpret_cast<const uint4 *>(trec + (uint32_t)tid * DEFH_PER);
     for (uint32_t t0 = 0; t0 < ntok; t0 += DEFH_THREADS * DEFH_PER) {
         const uint32_t t = t0 + (uint32_t)tid * DEFH_PER;
-        const uint4 rv = *reinterpret_cast<const uint4 *>(trec + t);       // the token array is 65536 words: in bounds
+        const uint4 rv = nrv;                                              // the token array is 65536 words: in bounds
+        if (t + DEFH_THREADS * DEFH_PER < ntok) nrv = *reinterpret_cast<const uint4 *>(trec + t + DEFH_THREADS * DEFH_PER);
         const uint32_t r[4] = {rv.x, rv.y, rv.z, rv.w};
         uint32_t c_v[4], c_k[4], x_v[4], x_k[4], mine = 0;
 #pragma unroll

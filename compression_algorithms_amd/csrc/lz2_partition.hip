@@ -41,14 +41,7 @@ void k_lz2_partition(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     const uint32_t T = 1u << P.tbits, Tmask = T - 1u;
     const uint32_t gshift = P.tbits - LZ2_NG_BITS, Gw = 1u << gshift;
 
-    const bool vec_ok = (((uintptr_t)src) & 15u) == 0;
-    for (uint32_t i = tid * 16u; i < LZ_MAX_BLOCK + LZ_TAIL; i += 1024u * 16u) {
-        if (vec_ok && i + 16u <= n) *reinterpret_cast<uint4 *>(s_in + i) = *reinterpret_cast<const uint4 *>(src + i);
-        else {
-#pragma unroll
-            for (uint32_t k = 0; k < 16; ++k) s_in[i + k] = (i + k < n) ? src[i + k] : (uint8_t)0;
-        }
-    }
+    lz_block_to_lds(s_in, src, n, (uint32_t)tid);
     for (uint32_t i = tid; i < LZ2_NG; i += 1024) s_grp[i] = 0;
     for (uint32_t i = tid; i < LZ2_NG / 32; i += 1024) s_safe[i] = 0;
     if (tid == 0) { s_s0 = ~0u; s_flag = 0; }

@@ -141,6 +141,41 @@ __device__ __forceinline__ uint32_t lds_word(const uint8_t *s, uint32_t p)
     return (uint32_t)(v >> ((p & 3u) * 8u));
 }
 
+// A block's bytes -> LDS with the zero tail the reference reads past `size`, by a workgroup of 1024 threads:
+// s_dst holds LZ_MAX_BLOCK + LZ_TAIL bytes (+ slack), 16-byte aligned.  The 16-byte loads of a thread (four or five) are
+// issued together and UNCONDITIONALLY (offsets clamped to the last whole vector) before the first LDS store: written as
+// "if (in range) s_dst[i] = src[i]" per iteration every load waited for its value in its own basic block — five HBM round
+// trips one after the other at the head of three kernels (round 4).
+__device__ __forceinline__ void lz_block_to_lds(uint8_t *s_dst, const uint8_t *__restrict__ src, uint32_t n, uint32_t tid)
+{
+    constexpr uint32_t NIT = (LZ_MAX_BLOCK + LZ_TAIL + 1024u * 16u - 1u) / (1024u * 16u);
+    const bool vec_ok = ((((uintptr_t)src) & 15u) == 0) && n >= 16u;
+    if (vec_ok) {
+        const uint32_t last = (n - 16u) & ~15u;                   // offset of the last whole 16-byte piece
+        uint4 v[NIT];
+#pragma unroll
+        for (uint32_t k = 0; k < NIT; ++k) {
+            const uint32_t i = tid * 16u + k * 1024u * 16u;
+            v[k] = *reinterpret_cast<const uint4 *>(src + (i <= last ? i : last));
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < NIT; ++k) {
+            const uint32_t i = tid * 16u + k * 1024u * 16u;
+            if (i >= LZ_MAX_BLOCK + LZ_TAIL) continue;
+            if (i + 16u <= n) *reinterpret_cast<uint4 *>(s_dst + i) = v[k];
+            else {
+#pragma unroll
+                for (uint32_t b = 0; b < 16; ++b) s_dst[i + b] = (i + b < n) ? src[i + b] : (uint8_t)0;
+            }
+        }
+    } else {
+        for (uint32_t i = tid * 16u; i < LZ_MAX_BLOCK + LZ_TAIL; i += 1024u * 16u) {
+#pragma unroll
+            for (uint32_t b = 0; b < 16; ++b) s_dst[i + b] = (i + b < n) ? src[i + b] : (uint8_t)0;
+        }
+    }
+}
+
 // ---- block-wide scans over 1024 threads (16 waves) -------------------------------------------
 template <typename T, typename Op>
 __device__ __forceinline__ T wave_inclusive_scan(T v, Op op)

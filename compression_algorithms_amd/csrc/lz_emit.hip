@@ -41,15 +41,7 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
     const uint32_t W = 1u << P.wbits, max_len = (1u << P.lbits) - 1u;
 
     // ---- block -> LDS with the zero tail
-    const bool vec_ok = (((uintptr_t)src) & 15u) == 0;
-    for (uint32_t i = tid * 16u; i < LZ_MAX_BLOCK + LZ_TAIL; i += 1024u * 16u) {
-        if (vec_ok && i + 16u <= n) {
-            *reinterpret_cast<uint4 *>(s_r0 + i) = *reinterpret_cast<const uint4 *>(src + i);
-        } else {
-#pragma unroll
-            for (uint32_t k = 0; k < 16; ++k) s_r0[i + k] = (i + k < n) ? src[i + k] : (uint8_t)0;
-        }
-    }
+    lz_block_to_lds(s_r0, src, n, (uint32_t)tid);
     if (tid == 0) s_L[LZ_MAX_BLOCK - 1] = 0;     // position 0xFFFF: its "pending" marker equals "none" (lz2.h); none unless a list says otherwise
     __syncthreads();
 
@@ -307,11 +299,16 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
             const uint32_t p0 = (uint32_t)tid * 64u;
             if (lit) {
                 const bool v16 = (((uintptr_t)src) & 15u) == 0 && p0 + 64u <= n;
+                // (the chunk's four 16-byte loads first, then their uses: one round trip, not four)
+                uint4 v4[4] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+                if (v16) {
+#pragma unroll
+                    for (uint32_t k4 = 0; k4 < 4u; ++k4) v4[k4] = *reinterpret_cast<const uint4 *>(src + p0 + 16u * k4);
+                }
 #pragma unroll
                 for (uint32_t k4 = 0; k4 < 4u; ++k4) {
-                    uint32_t w[4] = {0, 0, 0, 0};
-                    if (v16) { const uint4 v = *reinterpret_cast<const uint4 *>(src + p0 + 16u * k4); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
-                    else { for (uint32_t j = 0; j < 16u; ++j) if (p0 + 16u * k4 + j < n) w[j >> 2] |= (uint32_t)src[p0 + 16u * k4 + j] << (8u * (j & 3u)); }
+                    uint32_t w[4] = {v4[k4].x, v4[k4].y, v4[k4].z, v4[k4].w};
+                    if (!v16) { for (uint32_t j = 0; j < 16u; ++j) if (p0 + 16u * k4 + j < n) w[j >> 2] |= (uint32_t)src[p0 + 16u * k4 + j] << (8u * (j & 3u)); }
 #pragma unroll
                     for (uint32_t j = 0; j < 16u; ++j)
                         if ((lit >> (16u * k4 + j)) & 1ull) s_L[p0 + 16u * k4 + j] = (uint8_t)(w[j >> 2] >> (8u * (j & 3u)));
@@ -363,11 +360,15 @@ void k_lz_parse_emit(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, Lz
         const uint32_t p0 = (uint32_t)tid * 64u;
         if (lit) {
             const bool v16 = (((uintptr_t)src) & 15u) == 0 && p0 + 64u <= n;
+            uint4 v4[4] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+            if (v16) {
+#pragma unroll
+                for (uint32_t k4 = 0; k4 < 4u; ++k4) v4[k4] = *reinterpret_cast<const uint4 *>(src + p0 + 16u * k4);
+            }
 #pragma unroll
             for (uint32_t k4 = 0; k4 < 4u; ++k4) {
-                uint32_t w[4] = {0, 0, 0, 0};
-                if (v16) { const uint4 v = *reinterpret_cast<const uint4 *>(src + p0 + 16u * k4); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
-                else { for (uint32_t j = 0; j < 16u; ++j) if (p0 + 16u * k4 + j < n) w[j >> 2] |= (uint32_t)src[p0 + 16u * k4 + j] << (8u * (j & 3u)); }
+                uint32_t w[4] = {v4[k4].x, v4[k4].y, v4[k4].z, v4[k4].w};
+                if (!v16) { for (uint32_t j = 0; j < 16u; ++j) if (p0 + 16u * k4 + j < n) w[j >> 2] |= (uint32_t)src[p0 + 16u * k4 + j] << (8u * (j & 3u)); }
 #pragma unroll
                 for (uint32_t j = 0; j < 16u; ++j)
                     if ((lit >> (16u * k4 + j)) & 1ull) s_L[p0 + 16u * k4 + j] = (uint8_t)(w[j >> 2] >> (8u * (j & 3u)));

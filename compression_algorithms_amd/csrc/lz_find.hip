@@ -43,15 +43,7 @@ __device__ __forceinline__ void lz_sort_home_block(const uint8_t *__restrict__ i
     const uint32_t T = 1u << P.tbits, Tmask = T - 1u;
 
     // ---- block -> LDS, zero tail (the reference reads past `size`; the parity definition is zeros)
-    const bool vec_ok = (((uintptr_t)src) & 15u) == 0;
-    for (uint32_t i = tid * 16u; i < LZ_MAX_BLOCK + LZ_TAIL; i += 1024u * 16u) {
-        if (vec_ok && i + 16u <= n) {
-            *reinterpret_cast<uint4 *>(s_in + i) = *reinterpret_cast<const uint4 *>(src + i);
-        } else {
-#pragma unroll
-            for (uint32_t k = 0; k < 16; ++k) s_in[i + k] = (i + k < n) ? src[i + k] : (uint8_t)0;
-        }
-    }
+    lz_block_to_lds(s_in, src, n, (uint32_t)tid);
     if (tid < 16) s_in[LZ_MAX_BLOCK + LZ_TAIL + tid] = 0;
     __syncthreads();
 
