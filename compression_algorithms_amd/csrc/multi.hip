@@ -304,7 +304,8 @@ static mi_status multi_encode(mi_multi *m, const mi_lz_params *p, int mode_h, co
                               uint8_t *d_out0, uint64_t cap_bytes, uint64_t *d_block_bits0)
 {
     if (!m || !p || !d_out0 || !d_block_bits0 || (n && !d_in && !h_in) || !p->block) return MI_ERR_ARG;
-    if (p->block > 65536u) return MI_ERR_ARG;             // blocks above 64 KiB synchronise per batch and have their own workspace logic: one device
+    // (blocks above 64 KiB — the lz77 flavour's sliced finder — synchronise their stream once per batch: harmless here, every device
+    //  has its own host thread)
     if (((uintptr_t)d_out0 & 3u) != 0) return MI_ERR_ARG;
     if (cap_bytes < lz_bound(p, mode_h, n)) return MI_ERR_CAPACITY;
     const uint64_t nblocks = (n + p->block - 1) / p->block;

@@ -328,7 +328,7 @@ const char *mi_multi_last_transport_error(const mi_multi *m);                   
  * (the rule of compression_algorithms_amd/sharded.py shard_blocks) */
 void        mi_multi_shard(uint64_t nblocks, int g, int ndev, uint64_t *lo, uint64_t *hi);
 /* Shards resident: d_in[g] points at device g's shard (its block range of the n input bytes, on device g; NULL for an
- * empty range).  mode_h = 0: mi_lz_encode_dev's stream (either flavour, blocks <= 64 KiB), 1: mi_deflate_h_encode_dev's.
+ * empty range).  mode_h = 0: mi_lz_encode_dev's stream (either flavour, any block size it takes), 1: mi_deflate_h_encode_dev's.
  * d_out0 (cap_bytes >= the single-device bound for n, 4-byte aligned) and d_block_bits0 (u64[nblocks + 1]) live on
  * devices[0].  Returns when the assembled stream is complete (it synchronises every device's stream). */
 mi_status   mi_lz_encode_multi_dev(mi_multi *m, const mi_lz_params *p, int mode_h, const uint8_t *const *d_in, uint64_t n,

@@ -59,7 +59,8 @@ def _shards(mm, d, p):
 
 
 CASES = [("deflate-T", 0, 37 * 65536 - 4321), ("deflate-H", 1, 37 * 65536 - 4321), ("lz77w14", 0, 37 * 65536 - 77),
-         ("lz77w16", 0, 11 * 65536 + 5), ("deflate-T-small-blocks", 0, 200_003), ("deflate-H-fewer-blocks-than-devices", 1, 70_000)]
+         ("lz77w16", 0, 11 * 65536 + 5), ("deflate-T-small-blocks", 0, 200_003), ("deflate-H-fewer-blocks-than-devices", 1, 70_000),
+         ("lz77w16-256KiB-blocks", 0, 7 * 262144 + 4097)]
 
 
 @pytest.mark.gpu
@@ -68,7 +69,7 @@ CASES = [("deflate-T", 0, 37 * 65536 - 4321), ("deflate-H", 1, 37 * 65536 - 4321
 def test_two_contexts_on_one_gpu_equal_the_single_context_stream(name, mode_h, n, ndev):
     p = {"deflate-T": lz.params("deflate"), "deflate-H": lz.params("deflate"), "lz77w14": lz.params("lz77", 14),
          "lz77w16": lz.params("lz77", 16), "deflate-T-small-blocks": lz.params("deflate", block=4099),
-         "deflate-H-fewer-blocks-than-devices": lz.params("deflate")}[name]
+         "deflate-H-fewer-blocks-than-devices": lz.params("deflate"), "lz77w16-256KiB-blocks": lz.params("lz77", 16, 262144)}[name]
     data = synth.enwik_like(n, seed=404)
     d = data.cuda()
     one = lz.compress_h(d, p) if mode_h else lz.compress(d, p)
