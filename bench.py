@@ -64,6 +64,10 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="target duration of each leg of the headline's CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip mode_T / shard_125MB / end_to_end (A/B runs)")
+    ap.add_argument("--multi-devices", default=None,
+                    help="e.g. 0,1,2,3: ONE process, the C boundary's mi_lz_encode_multi_dev over these devices (config 5 through "
+                         "csrc/multi.hip: contiguous block ranges, RCCL gather into the first device; a device may repeat). "
+                         "Prints its own JSON line; --gpus N (one process per GPU) is what the driver launches")
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 path on a box with fewer GPUs than ranks (ranks share devices)")
@@ -432,8 +436,52 @@ def measure(ctx, workload, x, steps, warmup, pool=None, cpu=True, cold=False):
     return rec
 
 
+def main_multi_devices(args):
+    """--multi-devices: config 5 from the C boundary in ONE process (include/mi_codec.h mi_multi_*).  Strong scaling by
+    construction: ONE buffer of --bytes, device g holds and encodes its contiguous block range, the streams are gathered into the
+    first device inside the timed region.  Not the driver's line (that is --gpus N)."""
+    from compression_algorithms_amd import synth, lz
+    from compression_algorithms_amd.multi import Multi
+    devs = [int(d) for d in args.multi_devices.split(",")]
+    assert args.workload in ("deflate-h", "deflate"), "--multi-devices: the deflate workloads"
+    mm = Multi(devs)
+    p = lz.params("deflate")
+    n = args.bytes
+    nblk = (n + BLOCK - 1) // BLOCK
+    whole = synth.enwik_like(n, seed=args.seed, device=torch.device("cuda", devs[0]))
+    shards = []
+    for g, d in enumerate(devs):
+        lo, hi = mm.shard(nblk, g)
+        shards.append(whole[lo * BLOCK: min(hi * BLOCK, n)].to(torch.device("cuda", d)).clone() if hi > lo else None)
+    mode_h = args.workload == "deflate-h"
+    for _ in range(max(args.warmup, 1)):
+        h = mm.compress_dev(shards, n, p, mode_h=mode_h)
+    for d in set(devs):
+        torch.cuda.synchronize(d)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        h = None
+        h = mm.compress_dev(shards, n, p, mode_h=mode_h)           # returns synchronised (the gather included)
+    dt = time.perf_counter() - t0
+    torch.cuda.set_device(devs[0])
+    back = lz.decompress_h(h) if mode_h else lz.decompress(h)
+    ok = bool(torch.equal(back, whole))
+    print(json.dumps({"metric": "encode GB/s on enwik9 at 1/2/4/8 MI355X; ratio vs ref; round-trip bit-exact", "value": round(n * args.steps / dt / 1e9, 3),
+                      "unit": "GB/s", "n_gpus": len(set(devs)), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                      "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+                      "config": {"workload": f"{DESC[args.workload]}; {n} enwik-shaped bytes, ONE process over devices {devs} "
+                                             f"(mi_lz_encode_multi_dev, transport {mm.transport}), gather to device {devs[0]} inside the timed region",
+                                 "input_sha256": synth.digest(whole), "compressed_bytes_job": int(h.nbytes), "ratio": round(n / max(h.nbytes, 1), 4)},
+                      "roundtrip": ok}), flush=True)
+    mm.close()
+    if not ok:
+        sys.exit(3)
+
+
 def main():
     args = parse_args()
+    if args.multi_devices:
+        return main_multi_devices(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
