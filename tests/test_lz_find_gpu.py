@@ -139,3 +139,53 @@ def test_block_scan_composes_earlier_maps_first():
             assert (int(got_a), int(got_b)) == (a_run, b_run), (trial, t)
             a2, b2 = int(ab[t, 0]), int(ab[t, 1])
             a_run, b_run = max(a_run + a2, NEG), max(max(b_run + a2, NEG), b2)
+
+
+@pytest.mark.parametrize("flavour,wbits", CONFIGS)
+@pytest.mark.parametrize("shape", ["runs_1k_4k", "runs_with_strays", "two_runs_one_home_range"])
+def test_wide_clusters_take_the_dominated_replay(flavour, wbits, shape):
+    """round 4: exported clusters of 1 025 .. 4 096 entries (what the wide finder hands over: a run of one byte value with foreign
+    words inside its bucket range) that one word dominates are replayed by k_lz2_dom (lz_dom.h) — flagged in their descriptor —
+    and what it leaves (not dominated, given up, covering bucket 0 / T) by the general wave replay with one or two bitmap
+    registers.  find() at every position against the oracle's literal table; the counters must show the path was taken."""
+    from compression_algorithms_amd import lz
+    from compression_algorithms_amd.context import Context
+    rng = np.random.default_rng(len(shape) * 13 + (wbits or 15))
+    n = 3 * 65536 + 777
+    data = synth.enwik_like(n, seed=123).numpy().copy()
+    at = 500
+    while at + 5000 < n:
+        ln = int(rng.integers(1100, 3900))
+        b = int(rng.integers(0, 256))
+        data[at:at + ln] = b
+        if shape == "runs_with_strays":                 # foreign words inside the run's bucket range AND inside the run itself
+            for q in rng.integers(at, at + ln, 12):
+                data[q] = (b + 1 + int(rng.integers(0, 200))) & 0xFF
+        if shape == "two_runs_one_home_range":          # the same byte again a little later: one word, two bursts, retirements between
+            data[at + ln + 700: at + ln + 700 + ln // 2] = b
+            at += ln // 2 + 700
+        at += ln + int(rng.integers(3000, 9000))
+    _check(data, flavour, wbits)
+    ctx = Context(0)
+    p = lz.params(flavour, wbits)
+    lz.compress(data, p, ctx).nbytes
+    st = ctx.path_stats()
+    # parts above 2 560 entries existed: the wide finder and its clusters ran (two bursts of one byte can exceed 4 096 entries
+    # together: such a block takes the fallback pipeline instead, whose dominated replay is the same code)
+    assert st["wide_parts"] + st["fallback_blocks"] > 0, st
+    if shape != "two_runs_one_home_range":
+        assert st["wide_parts"] > 0, st
+
+
+def test_path_counters_are_zero_on_text_and_count_the_fallback():
+    """mi_lz_path_stats: text takes neither the fallback pipeline nor wide parts; a block of one byte value is a
+    giant cluster and takes the fallback, and is counted"""
+    from compression_algorithms_amd import lz
+    from compression_algorithms_amd.context import Context
+    ctx = Context(0)
+    p = lz.params("deflate")
+    lz.compress_h(synth.enwik_like(40 * 65536, seed=5), p, ctx).nbytes
+    assert ctx.path_stats() == {"fallback_blocks": 0, "wide_parts": 0}
+    data = np.concatenate([np.zeros(3 * 65536, np.uint8), synth.enwik_like(65536, seed=6).numpy()])
+    lz.compress_h(data, p, ctx).nbytes
+    assert ctx.path_stats()["fallback_blocks"] == 3
