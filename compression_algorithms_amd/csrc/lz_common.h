@@ -22,6 +22,9 @@
 #define LZ_MAX_TILES   (LZ_MAX_BLOCK / LZ_TILE_NOM)
 #define LZ_WAVE_MIN    128u           // fallback pipeline: clusters from this size on are replayed by a wave, not a lane
 #define LZ_MAX_GIANTS_PER_BLOCK (LZ_MAX_BLOCK / LZ_WAVE_MIN + 32u)
+#ifndef LZ_TILE_WAVE_MIN
+#define LZ_TILE_WAVE_MIN 16u          // ... and mixed clusters from this size on by a wave of the tile's own workgroup (lz_find.hip)
+#endif
 
 struct LzP {
     uint32_t wbits, lbits, tbits, deflate, block;
@@ -163,14 +166,16 @@ __device__ __forceinline__ void lz_block_to_lds(uint8_t *s_dst, const uint8_t *_
             const uint32_t i = tid * 16u + k * 1024u * 16u;
             if (i >= LZ_MAX_BLOCK + LZ_TAIL) continue;
             if (i + 16u <= n) *reinterpret_cast<uint4 *>(s_dst + i) = v[k];
-            else {
-#pragma unroll
+            else if (i >= n) *reinterpret_cast<uint4 *>(s_dst + i) = make_uint4(0u, 0u, 0u, 0u);
+            else {                                              // the one ragged piece of a block (rolled: unrolled byte loads of five
+#pragma unroll 1                                                 // pieces cost k_lz_sort_home 244 bytes of scratch per lane)
                 for (uint32_t b = 0; b < 16; ++b) s_dst[i + b] = (i + b < n) ? src[i + b] : (uint8_t)0;
             }
         }
     } else {
+#pragma unroll 1
         for (uint32_t i = tid * 16u; i < LZ_MAX_BLOCK + LZ_TAIL; i += 1024u * 16u) {
-#pragma unroll
+#pragma unroll 1
             for (uint32_t b = 0; b < 16; ++b) s_dst[i + b] = (i + b < n) ? src[i + b] : (uint8_t)0;
         }
     }
@@ -251,9 +256,10 @@ struct OpAm { __device__ uint64_t operator()(uint64_t earlier, uint64_t later) c
 //   hook(j, e)  called for every element with the output index it was stored at (e.g. to count the NEXT pass's digits)
 struct RadixNoHook { __device__ __forceinline__ void operator()(uint32_t, uint32_t) const {} };
 template <int NWAVES> __device__ __forceinline__ uint32_t radix_seg(uint32_t n) { return ((n + (uint32_t)(NWAVES * 64) - 1u) / (uint32_t)(NWAVES * 64)) * 64u; }
-template <int NWAVES, int NBITS, typename E, typename CntRow, typename Load, typename Digit, typename Store, typename Hook = RadixNoHook>
+template <int D> struct RadixDepth { static constexpr int value = D; };
+template <int NWAVES, int NBITS, typename E, typename CntRow, typename Load, typename Digit, typename Store, typename Hook = RadixNoHook, typename Depth = RadixDepth<1>>
 __device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load, Digit digit, Store store, uint32_t arank = 0u /* LZP_ARANK | LZP_BREAK */, uint64_t *dbg = nullptr,
-                                           bool counted = false, Hook hook = Hook())
+                                           bool counted = false, Hook hook = Hook(), Depth = Depth())
 {
     long long tk_ = dbg ? clock64() : 0;
 #define RP_TICK(k) do { if (dbg && threadIdx.x == 0) { long long t2 = clock64(); atomicAdd((unsigned long long *)&dbg[k], (unsigned long long)(t2 - tk_)); tk_ = t2; } } while (0)
@@ -270,6 +276,20 @@ __device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load,
         __syncthreads();
         // four elements per lane and step: their (dependent) key lookups are in flight together — at 4 waves per SIMD a pass is
         // a chain of LDS round trips, not a stream of instructions
+        if constexpr (Depth::value > 1) {
+            // keys in HBM (the fallback's sorts): the loads of D steps UNCONDITIONALLY (indices clamped) before the first use — a
+            // load under a condition waits for its value in its own basic block, and at one workgroup per CU nothing else hides it
+            constexpr int D = Depth::value;
+            for (uint32_t i = a + lane; i < b; i += 64u * D) {
+                E ee[D]; uint32_t dg[D];
+#pragma unroll
+                for (int u = 0; u < D; ++u) ee[u] = load(i + 64u * u < b ? i + 64u * u : b - 1u);
+#pragma unroll
+                for (int u = 0; u < D; ++u) dg[u] = digit(ee[u]);
+#pragma unroll
+                for (int u = 0; u < D; ++u) if (i + 64u * u < b) atomicAdd(&cnt[dg[u] * ST + wave], 1u);
+            }
+        } else
         for (uint32_t i = a + lane; i < b; i += 256) {
             uint32_t dg[4];
 #pragma unroll
@@ -332,6 +352,40 @@ __device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load,
         RP_TICK(10);
         return;
     }
+    if constexpr (Depth::value > 1) {
+        // ballot ranking, D steps of 64 elements per round: all D loads, then all D key lookups, then the D rankings in step order
+        constexpr int D = Depth::value;
+        for (uint32_t i0 = a; i0 < b; i0 += 64u * D) {
+            E ee[D]; uint32_t dg[D];
+#pragma unroll
+            for (int u = 0; u < D; ++u) { const uint32_t i = i0 + 64u * u + lane; ee[u] = load(i < b ? i : b - 1u); }
+#pragma unroll
+            for (int u = 0; u < D; ++u) dg[u] = digit(ee[u]);
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                const bool valid = i0 + 64u * u + lane < b;
+                const uint32_t d = dg[u];
+                uint64_t mask = __ballot(valid);
+                if (mask == 0ull) continue;                          // (uniform)
+#pragma unroll
+                for (int k = 0; k < NBITS; ++k) {
+                    const bool bit = (d >> k) & 1u;
+                    const uint64_t bal = __ballot(valid && bit);
+                    mask &= bit ? bal : ~bal;
+                }
+                const uint64_t below = mask & ((1ull << lane) - 1ull);
+                const uint32_t rank = __popcll(below), num = __popcll(mask);
+                const int leader = __ffsll((unsigned long long)mask) - 1;
+                uint32_t old = 0;
+                if (valid && lane == leader) old = atomicAdd(&cnt[d * ST + wave], num);
+                old = __shfl(old, leader < 0 ? 0 : leader);
+                if (valid) { store(old + rank, ee[u]); hook(old + rank, (uint32_t)ee[u]); }
+            }
+        }
+        __syncthreads();
+        RP_TICK(10);
+        return;
+    }
     // the element and its digit of the NEXT step are fetched while this step ranks and stores (two dependent LDS reads
     // off the chain: measured, the scatter is a chain of LDS round trips, 58 % of a pass)
     E en{};
@@ -371,5 +425,5 @@ __device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load,
 template <int NBITS, typename E, typename CntRow, typename Load, typename Digit, typename Store>
 __device__ __forceinline__ void radix_pass_1024(uint32_t n, CntRow *s_cnt, Load load, Digit digit, Store store, uint32_t arank = 0u)
 {
-    radix_pass<16, NBITS, E>(n, s_cnt, load, digit, store, arank);
+    radix_pass<16, NBITS, E>(n, s_cnt, load, digit, store, arank, nullptr, false, RadixNoHook(), RadixDepth<4>());
 }

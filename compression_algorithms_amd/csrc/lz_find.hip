@@ -81,23 +81,48 @@ __device__ __forceinline__ void lz_sort_home_block(const uint8_t *__restrict__ i
             if (rot && ph >= rot) h -= (int32_t)T;
             return h;
         };
+        // the chunk's sorted positions, in order: fn(k, position).  A whole chunk of an unrotated order comes in as 16-byte
+        // pieces, the next one in flight while eight entries are worked on (element by element every entry of the three loops
+        // below was its own HBM round trip — the stores of loop (c) keep the compiler from moving a load over them —, 192 in a
+        // row per thread at one workgroup per CU: most of the 1.2 ms a block spent in this kernel, round 4)
+        auto h_of = [&](uint32_t k, uint32_t pos) -> int32_t {
+            int32_t h = (int32_t)home_of(pos);
+            if (rot && phys(k) >= rot) h -= (int32_t)T;
+            return h;
+        };
+        auto for_chunk = [&](auto &&fn) {
+            if (k0 >= k1) return;
+            if (rot == 0 && k1 - k0 == 64u) {
+                uint4 nv = *reinterpret_cast<const uint4 *>(A + k0);
+#pragma unroll 1
+                for (uint32_t k = k0; k < k1; k += 8u) {
+                    const uint4 v = nv;
+                    nv = *reinterpret_cast<const uint4 *>(A + ((k + 8u < k1) ? k + 8u : k));          // unconditional (clamped)
+                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (uint32_t u = 0; u < 8; ++u) fn(k + u, (w[u >> 1] >> ((u & 1u) * 16u)) & 0xFFFFu);
+                }
+            } else {
+                for (uint32_t k = k0; k < k1; ++k) fn(k, (uint32_t)A[phys(k)]);
+            }
+        };
         // (a) chunk maximum of g = home - k
         int32_t m = INT32_MIN;
-        for (uint32_t k = k0; k < k1; ++k) { uint32_t pos; int32_t g = hk_at(k, pos) - (int32_t)k; m = g > m ? g : m; }
+        for_chunk([&](uint32_t k, uint32_t pos) { const int32_t g = h_of(k, pos) - (int32_t)k; m = g > m ? g : m; });
         premax = block_exclusive_scan<int32_t>(m, OpMaxI32(), INT32_MIN, s_i32, &gmax_total);
         // (b) heads and home-run starts of the chunk
         uint32_t nheads = 0; int32_t lasthead = -1, lastrun = -1;
         {
             int32_t run = premax, prev_h = 0;
             if (k0 > 0 && k0 < n) { uint32_t pp; prev_h = hk_at(k0 - 1, pp); }
-            for (uint32_t k = k0; k < k1; ++k) {
-                uint32_t pos; const int32_t h = hk_at(k, pos), g = h - (int32_t)k;
+            for_chunk([&](uint32_t k, uint32_t pos) {
+                const int32_t h = h_of(k, pos), g = h - (int32_t)k;
                 const bool head = (k == 0) || (g >= run);
                 run = g > run ? g : run;
                 if (head) { ++nheads; lasthead = (int32_t)k; }
                 if (k == 0 || h != prev_h) lastrun = (int32_t)k;
                 prev_h = h;
-            }
+            });
         }
         uint32_t total_heads; int32_t last_group_start, dummy;
         gid_base = block_exclusive_scan<uint32_t>(nheads, OpAddU32(), 0u, s_u32, &total_heads);
@@ -123,8 +148,8 @@ __device__ __forceinline__ void lz_sort_home_block(const uint8_t *__restrict__ i
                 if (hs_carry >= 0) { cur_hs = (uint32_t)hs_carry; (void)hk_at(cur_hs, hs_pos); hs_word = lds_word(s_in, hs_pos); }
             }
             uint32_t seen = 0;
-            for (uint32_t k = k0; k < k1; ++k) {
-                uint32_t pos; const int32_t h = hk_at(k, pos), g = h - (int32_t)k;
+            for_chunk([&](uint32_t k, uint32_t pos) {
+                const int32_t h = h_of(k, pos), g = h - (int32_t)k;
                 const bool head = (k == 0) || (g >= run);
                 run = g > run ? g : run;
                 const uint32_t w = lds_word(s_in, pos);
@@ -143,7 +168,7 @@ __device__ __forceinline__ void lz_sort_home_block(const uint8_t *__restrict__ i
                 const uint32_t rloc = cur_gs + (uint32_t)(h - cur_base);
                 E[pos] = lz_pack(cur_gid, pos, rloc, pid);
                 cand[pos] = LZ_NONE16;
-            }
+            });
         }
         if (tid == 0) {
             LzBlockMeta mt;
@@ -302,11 +327,25 @@ __device__ void replay_cluster(const TileView &v, uint32_t s, uint32_t e, uint32
 __device__ __forceinline__ void lz_emulate_tile(LzP P, LzScratch sc, uint32_t lb, uint32_t t, uint64_t *dbg)
 {
     long long tkt = dbg ? clock64() : 0;
-#define TL_TICK(k) do { if (dbg && threadIdx.x == 0) { long long t2 = clock64(); atomicAdd((unsigned long long *)&dbg[40 + (k)], (unsigned long long)(t2 - tkt)); tkt = t2; } } while (0)
+#define TL_TICK(k) do { if (dbg && threadIdx.x == 0) { long long t2 = clock64(); atomicAdd((unsigned long long *)&dbg[40 + (k)], (unsigned long long)(t2 - tkt)); if ((k) >= 2) atomicMax((unsigned long long *)&dbg[43 + (k)], (unsigned long long)(t2 - tkt)); tkt = t2; } } while (0)
     __shared__ uint16_t s_pos[LZ_TILE_CAP], s_rs[LZ_TILE_CAP], s_pid[LZ_TILE_CAP], s_occ[LZ_TILE_CAP];
     __shared__ uint32_t s_bm[LZ_TILE_CAP / 32 + 2];
     __shared__ uint32_t s_bm1[LZ_TILE_CAP / 1024 + 2];
     __shared__ uint32_t s_a, s_b, s_lasthead;
+    // clusters of LZ_TILE_WAVE_MIN .. LZ_WAVE_MIN - 1 entries that are not one word: a list for the workgroup's eight waves, and a
+    // wave's replay tables (slot -> occupant, entry -> slot, relative home slots, results): 1.25 KiB per wave
+    __shared__ uint32_t s_wl[LZ_TILE_CAP / LZ_TILE_WAVE_MIN + 1], s_nwl;
+    __shared__ uint32_t s_wv[8 * LZ_WAVE_MIN * 5 / 2];                       // per wave: occupants (u32), slots, homes, results (u16)
+    uint32_t (*s_wocc)[LZ_WAVE_MIN] = reinterpret_cast<uint32_t (*)[LZ_WAVE_MIN]>(s_wv);
+    uint16_t (*s_wslot)[LZ_WAVE_MIN] = reinterpret_cast<uint16_t (*)[LZ_WAVE_MIN]>(s_wv + 8 * LZ_WAVE_MIN);
+    uint16_t (*s_wrs)[LZ_WAVE_MIN] = s_wslot + 8, (*s_wc)[LZ_WAVE_MIN] = s_wslot + 16;
+    // the tile's cluster heads, one bit per entry, and — before the waves need their tables — the heads of the clusters the lanes
+    // work on, densely: taken by entry index a lane found a head at one in ten of its entries and a wave waited eight times for
+    // its longest cluster (round 4: 216 k of a tile's 380 k cycles on "pages")
+    __shared__ uint32_t s_hb[LZ_TILE_CAP / 32 + 2];
+    uint16_t *s_item = reinterpret_cast<uint16_t *>(s_wv);
+    __shared__ uint32_t s_nitem;
+    static_assert(sizeof(s_wv) >= (LZ_TILE_CAP / 2) * sizeof(uint16_t), "a cluster on the lanes' list has two entries at least");
 
     const int tid = threadIdx.x;
     const LzBlockMeta mt = sc.meta[lb];
@@ -315,7 +354,7 @@ __device__ __forceinline__ void lz_emulate_tile(LzP P, LzScratch sc, uint32_t lb
     if (lo >= n) return;
     const uint64_t *E = sc.eA + (size_t)lb * LZ_MAX_BLOCK;
 
-    if (tid == 0) { s_a = ~0u; s_b = ~0u; s_lasthead = 0; }
+    if (tid == 0) { s_a = ~0u; s_b = ~0u; s_lasthead = 0; s_nwl = 0; s_nitem = 0; }
     __syncthreads();
     // Cluster heads of a stretch of up to 4 096 + LZ_GIANT_MIN sorted entries, eight per thread: the cluster numbers of entry i and
     // of i - 1 come in as UNCONDITIONAL loads (indices clamped), all sixteen of a thread before the first compare.  (Written as
@@ -337,7 +376,15 @@ __device__ __forceinline__ void lz_emulate_tile(LzP P, LzScratch sc, uint32_t lb
         }
     };
     // a = first head in [lo, hi)
-    heads_of(lo, hi, [&](uint32_t i) { atomicMin(&s_a, i); });
+    // (one LDS atomic per wave: a tile of a text block has ~4 000 heads, and as many atomics on ONE address are served one by one)
+    auto wave_min = [&](uint32_t v) { for (int o = 32; o; o >>= 1) { const uint32_t t = __shfl_xor(v, o); v = t < v ? t : v; } return v; };
+    auto wave_max = [&](uint32_t v) { for (int o = 32; o; o >>= 1) { const uint32_t t = __shfl_xor(v, o); v = t > v ? t : v; } return v; };
+    {
+        uint32_t mn = ~0u;
+        heads_of(lo, hi, [&](uint32_t i) { mn = i < mn ? i : mn; });
+        mn = wave_min(mn);
+        if ((tid & 63) == 0 && mn != ~0u) atomicMin(&s_a, mn);
+    }
     __syncthreads();
     const uint32_t a = s_a;
     if (a == ~0u) return;                       // a cluster that started earlier covers this whole range
@@ -345,13 +392,21 @@ __device__ __forceinline__ void lz_emulate_tile(LzP P, LzScratch sc, uint32_t lb
     static_assert(LZ_TILE_NOM <= 8 * 512 && LZ_GIANT_MIN + 1 <= 8 * 512 + 1, "heads_of covers eight entries per thread");
     {
         const uint32_t end2 = (n < hi + LZ_GIANT_MIN + 1u) ? n : hi + LZ_GIANT_MIN + 1u;
-        heads_of(hi, end2 < hi + 8u * 512u ? end2 : hi + 8u * 512u, [&](uint32_t i) { atomicMin(&s_b, i); });
+        uint32_t mn = ~0u;
+        heads_of(hi, end2 < hi + 8u * 512u ? end2 : hi + 8u * 512u, [&](uint32_t i) { mn = i < mn ? i : mn; });
+        mn = wave_min(mn);
+        if ((tid & 63) == 0 && mn != ~0u) atomicMin(&s_b, mn);
         if (end2 > hi + 8u * 512u && tid == 0) {                              // (the one index beyond eight per thread)
             const uint32_t i = hi + 8u * 512u;
             if (((uint32_t)E[i] & 0xFFFFu) != ((uint32_t)E[i - 1u] & 0xFFFFu)) atomicMin(&s_b, i);
         }
     }
-    heads_of(a, hi, [&](uint32_t i) { atomicMax(&s_lasthead, i); });
+    {
+        uint32_t mx = 0;
+        heads_of(a, hi, [&](uint32_t i) { mx = i > mx ? i : mx; });
+        mx = wave_max(mx);
+        if ((tid & 63) == 0) atomicMax(&s_lasthead, mx);
+    }
     __syncthreads();
     uint32_t b = s_b;
     if (b == ~0u) b = (n <= hi + LZ_GIANT_MIN) ? n : ~0u;
@@ -380,14 +435,17 @@ __device__ __forceinline__ void lz_emulate_tile(LzP P, LzScratch sc, uint32_t lb
 #pragma unroll
         for (uint32_t u = 0; u < 8; ++u) {
             const uint32_t i = i0 + tid + 512u * u;
+            bool head = false;
             if (i < m) {
                 const uint64_t e = ev[u];
                 const uint32_t gid = (uint32_t)e & 0xFFFFu;
-                const bool head = (i == 0) || (pg[u] != gid);
+                head = (i == 0) || (pg[u] != gid);
                 s_pos[i] = (uint16_t)(e >> 16);
                 s_rs[i] = (uint16_t)((((uint32_t)(e >> 32) & 0xFFFFu) - a) | (head ? RS_HEAD : 0u));
                 s_pid[i] = (uint16_t)(e >> 48);
             }
+            const uint64_t hm = __ballot(head);                       // the wave's 64 consecutive entries (i - lane is a multiple of 64)
+            if ((tid & 63) == 0 && i < ((m + 63u) & ~63u)) { s_hb[i >> 5] = (uint32_t)hm; s_hb[(i >> 5) + 1u] = (uint32_t)(hm >> 32); }
         }
     }
     for (uint32_t i = tid; i < LZ_TILE_CAP / 32 + 2; i += 512) s_bm[i] = 0;
@@ -398,16 +456,30 @@ __device__ __forceinline__ void lz_emulate_tile(LzP P, LzScratch sc, uint32_t lb
     TileView v{s_pos, s_rs, s_pid, s_occ, s_bm, s_bm1, m};
     const uint32_t W = 1u << P.wbits;
     uint16_t *cand = sc.cand + (size_t)lb * LZ_MAX_BLOCK;
+    // end of the cluster that starts at head s: the next head bit, or m
+    auto cluster_end = [&](uint32_t s) -> uint32_t {
+        uint32_t wi = (s + 1u) >> 5;
+        uint32_t w = s_hb[wi] & ~((1u << ((s + 1u) & 31u)) - 1u);
+        const uint32_t wend = (m + 31u) >> 5;
+        while (!w && ++wi < wend) w = s_hb[wi];
+        const uint32_t e = w ? (wi << 5) + (uint32_t)__builtin_ctz(w) : m;
+        return e < m ? e : m;
+    };
     for (uint32_t s = tid; s < m; s += 512) {
         if (!(s_rs[s] & RS_HEAD)) continue;
-        uint32_t e = s + 1;
-        while (e < m && !(s_rs[e] & RS_HEAD)) ++e;
+        const uint32_t e = cluster_end(s);
         if (e - s < 2) continue;                 // a lone entry finds nothing and blocks nobody
         if (e - s >= LZ_WAVE_MIN) {              // a wave replays it (k_lz_emulate_giant): a lane would walk its probe chains bucket by bucket
             const uint32_t k = atomicAdd(sc.giant_count, 1u);
             sc.giant_list[2 * k] = lb; sc.giant_list[2 * k + 1] = a + s;
             continue;
         }
+        s_item[atomicAdd(&s_nitem, 1u)] = (uint16_t)s;
+    }
+    __syncthreads();
+    const uint32_t nitem = s_nitem;
+    for (uint32_t q = tid; q < nitem; q += 512) {
+        const uint32_t s = s_item[q], e = cluster_end(s);
         const bool first = (a + s) == 0;
         // a cluster of ONE word (most of them): find() only ever looks at the home slot, whose occupant — the anchor — is the
         // first entry, then the first entry after anchor + W, which itself finds the slot empty: one pass over
@@ -425,11 +497,37 @@ __device__ __forceinline__ void lz_emulate_tile(LzP P, LzScratch sc, uint32_t lb
                 continue;
             }
         }
+        // A mixed cluster of LZ_TILE_WAVE_MIN .. LZ_WAVE_MIN - 1 entries waits for a WAVE of this workgroup (below): on a lane its
+        // probe walks are three dependent LDS reads per bucket (occupancy bit -> occupant -> its word id), ~4.5 k cycles per entry
+        // on the "pages" family (phase counters, round 4: the longest such lane was 458 k of a tile's 525 k cycles); the wave
+        // replay of lz_replay.h looks at 64 buckets per step with the occupancy in registers.
+        if (e - s >= LZ_TILE_WAVE_MIN) { s_wl[atomicAdd(&s_nwl, 1u)] = s | ((e - s) << 16); continue; }
         replay_cluster(v, s, e, W, first ? mt.anom_idx : ~0u, first ? mt.limit_idx : ~0u, cand);
     }
     __syncthreads();
     TL_TICK(2);
-    if (dbg && threadIdx.x == 0) atomicAdd((unsigned long long *)&dbg[43], 1ull);
+    {
+        // ---- the listed clusters, one wave each (eight waves per workgroup): big_replay on the tile's LDS arrays — the same
+        //      entry format k_lz_emulate_giant feeds it (position, home slot relative to the cluster, word id)
+        const uint32_t wv = (uint32_t)tid >> 6, ln = (uint32_t)tid & 63u, nwl = s_nwl;
+        uint32_t *w_occ = s_wocc[wv];
+        uint16_t *w_slot = s_wslot[wv], *w_rs = s_wrs[wv], *w_c = s_wc[wv];
+        for (uint32_t q = wv; q < nwl; q += 8u) {
+            const uint32_t cs = s_wl[q] & 0xFFFFu, cm = s_wl[q] >> 16;
+            for (uint32_t i = ln; i < cm; i += 64u) w_rs[i] = (uint16_t)((s_rs[cs + i] & RS_MASK) - cs);
+            __builtin_amdgcn_wave_barrier();
+            const bool first = (a + cs) == 0;
+            const uint32_t anom = first ? mt.anom_idx : ~0u, limit = first ? mt.limit_idx : ~0u;
+            if (anom == ~0u && limit == ~0u) big_replay<LZ_WAVE_MIN, 1, true>(w_occ, w_slot, ln, W, cm, anom, limit, s_pos + cs, w_rs, s_pid + cs, w_c);
+            else big_replay<LZ_WAVE_MIN, 1, false>(w_occ, w_slot, ln, W, cm, anom, limit, s_pos + cs, w_rs, s_pid + cs, w_c);
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t i = ln; i < cm; i += 64u) { const uint32_t c = w_c[i]; if (c != LZ_NONE16) cand[s_pos[cs + i]] = (uint16_t)c; }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    TL_TICK(3);
+    if (dbg && threadIdx.x == 0) { atomicAdd((unsigned long long *)&dbg[44], 1ull); atomicMax((unsigned long long *)&dbg[47], (unsigned long long)m); }
 }
 
 __global__ __launch_bounds__(512)

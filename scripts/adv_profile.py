@@ -30,6 +30,7 @@ if os.environ.get("MI_LZ_DEBUG"):
     print("dom: clusters seen %d (entries %d)  taken %d (entries %d)  setup cycles/cluster %.0f  replay cycles/entry %.1f  fast %d scan %d foreign %d bailed %d"
           % (v[48], v[49], v[50], v[51], v[52] / max(v[50], 1), v[53] / max(v[51], 1), v[54], v[55], v[56], v[57]))
     print('   entries placed k at a time', v[61], ' of them in the one-retirement-per-entry regime', v[62], ' serial retirements', v[63])
-    if v[43]:
-        print("tile kernel: %d tiles, cycles per tile: heads %.0f, load %.0f, replay %.0f" % (v[43], v[40] / v[43], v[41] / v[43], v[42] / v[43]))
+    if v[44]:
+        print("tile kernel: %d tiles, cycles per tile: heads %.0f, load %.0f, lane replay %.0f, wave replay %.0f" % (v[44], v[40] / v[44], v[41] / v[44], v[42] / v[44], v[43] / v[44]))
+        print("   slowest tile: lane replay %d cycles, wave replay %d cycles; largest tile %d entries" % (v[45], v[46], v[47]))
     print('   largest cluster', v[58], ' longest workgroup (ticks)', v[59], ' largest giant list', v[60])

@@ -37,6 +37,7 @@ groups = {"A": ("k_lz2_partition", "k_lz2_find"), "B": ("k_lz2_mid", "k_lz2_big"
           "lzs": ("k_lzs", "void k_lzs", "k_lzw")}
 iv = [(s, e) for s, e, n in win]
 print("any kernel busy", round(union(iv) / 1e6, 3), "ms of", round((win[-1][1] - t0) / 1e6, 3))
+groups["fallback"] = ("k_lz_sort", "k_lz_emulate")
 for g, pre in groups.items():
     iv = [(s, e) for s, e, n in win if any(n.startswith(p) for p in pre)]
     if iv:
