@@ -114,3 +114,27 @@ def test_first_pipeline_alone_on_several_batches(shape):
         print("ok")
     """, MI_LZ_V2="0", MI_LZ_BATCH="64")
     assert "ok" in out
+
+
+@pytest.mark.parametrize("family", ["pages", "runs"])
+def test_warm_calls_on_two_fallback_streams_equal_the_oracle(family):
+    """A context that has seen fallback-heavy input sizes the fallback grids by the earlier call's count and runs the chains of
+    consecutive batches on two streams (lz_emit.hip: the hint is what an EARLIER call left).  The first call of a context runs
+    without, the later ones with: every call's stream must be the oracle's, token for token, and all of them the same bytes."""
+    out = _child(f"""
+        data = synth.family({family!r}, 77, 160 * 65536 + 4099)
+        x = torch.from_numpy(data).cuda()
+        p = lz.params("deflate")
+        ctx = Context(0)
+        os.environ["MI_LZ_BATCH"] = "64"
+        outs = []
+        for call in range(3):
+            st = lz.compress(x, p, ctx)
+            assert oracle_equal(st, data, p), call
+            outs.append(st.data[: st.nbytes].cpu().numpy().copy())
+        assert all(np.array_equal(outs[0], o) for o in outs[1:])
+        ps = ctx.path_stats()
+        assert ps["fallback_blocks"] > 0, ps
+        print("path", ps)
+    """, MI_LZ_BATCH="64")
+    assert "path" in out
