@@ -114,7 +114,7 @@ mi_status mi_ctx_create(mi_ctx **out, int device)
     if (hipMalloc((void **)&c->d_err, MI_ERR_SLOTS * sizeof(uint32_t)) != hipSuccess) { mi_ctx_destroy(c); return MI_ERR_NOMEM; }
     if (hipHostMalloc((void **)&c->h_order, 64, hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void **)&c->d_order, c->h_order, 0) != hipSuccess) { mi_ctx_destroy(c); return MI_ERR_NOMEM; }
-    c->h_order[0] = 0; c->h_order[1] = 0;          // [0] order flag, [1] blocks the last batch sent to the fallback (a grid-size hint)
+    c->h_order[0] = 0; c->h_order[1] = 0; c->h_order[2] = 0;   // [0] order flag, [1] blocks the last batch sent to the fallback (a grid-size hint), [2] blocks of that batch
     c->lds_rank_ok = lds_rank_selfcheck(c);
     c->test_break_rank = getenv("MI_LZ_TEST_BREAK_RANK") != nullptr;
     c->test_force_fb = getenv("MI_LZ_TEST_FORCE_FALLBACK") != nullptr;       // (only a -DMI_TEST_HOOKS build looks at the flag)

@@ -643,12 +643,21 @@ static mi_status lz_encode_impl(mi_ctx *ctx, const mi_lz_params *p, const uint8_
     // adversarial families warm AND cold).  Decided once per call; the stream is created here and released here — when a later
     // call finds the hint low and the stream idle (hipStreamQuery: no host wait) — or with the context, never inside the loop
     // (stream create/destroy per batch, skipped on early returns, may block in hipStreamDestroy).
-    const bool fb_busy = overlap && ctx->h_order && __atomic_load_n(ctx->h_order + 1, __ATOMIC_RELAXED) > 8u;     // (text: 0)
-    if (fb_busy && !ctx->fb2) {
+    const uint32_t fb_hint = (overlap && ctx->h_order) ? __atomic_load_n(ctx->h_order + 1, __ATOMIC_RELAXED) : 0u;
+    const bool fb_busy = fb_hint > 8u;                                                                             // (text: 0)
+    // When MOST blocks of a batch fall back (zeros, binary pages) stage B has next to nothing to do: the chains of the odd batches
+    // then go to ITS stream and no fifth stream is made at all — every stream beyond the four of the pipeline costs all of them
+    // (the process has four hardware queues: pages 33.2 -> 29.5 ms, zeros 12.2 -> 8.4 ms per 10^8 B against fb2).  Where stage B has
+    // real work beside the fallback (the "runs" family: 17 % of the blocks fall back, the rest export wide clusters) a chain in front
+    // of it costs more than the fifth stream (22.5 -> 27.2 ms): there fb2 stays.  MI_LZ_FB2_SIDE=0 / 1 forces either (A/B).
+    static const char *fb2_env = getenv("MI_LZ_FB2_SIDE");
+    const uint32_t fb_of = (overlap && ctx->h_order) ? __atomic_load_n(ctx->h_order + 2, __ATOMIC_RELAXED) : 0u;    // blocks of the batch the hint is from
+    const bool fb2_side = fb_busy && (fb2_env ? fb2_env[0] == '1' : fb_hint * 2u >= fb_of);
+    if (fb_busy && !ctx->fb2 && !fb2_side) {
         int lo_ = 0, hi_ = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo_, &hi_);
         if (hipStreamCreateWithPriority(&ctx->fb2, hipStreamNonBlocking, lo_) != hipSuccess) { (void)hipGetLastError(); ctx->fb2 = nullptr; }
-    } else if (!fb_busy && ctx->fb2) {
+    } else if ((!fb_busy || fb2_side) && ctx->fb2) {
         if (hipStreamQuery(ctx->fb2) == hipSuccess) { (void)hipStreamDestroy(ctx->fb2); ctx->fb2 = nullptr; }
         else (void)hipGetLastError();                     // still draining an earlier call's chains: try again next time
     }
@@ -671,7 +680,7 @@ static mi_status lz_encode_impl(mi_ctx *ctx, const mi_lz_params *p, const uint8_
         const int k = (int)(batch % (uint64_t)nsets);
         if (overlap && batch >= (uint64_t)nsets) MI_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_done[k], 0));   // set k is free again
         st = lz_find_stage_a(ctx, P, d_in, n, b0, nb, sc[k], sc2[k], s,
-                             overlap ? ((batch & 1u) && fb_busy && ctx->fb2 ? ctx->fb2 : ctx->fb) : s, ctx->ev_part[k], ctx->ev_fb[k], ctx->ev_wide[k]);
+                             overlap ? ((batch & 1u) && fb_busy && (ctx->fb2 || fb2_side) ? (fb2_side ? sb : ctx->fb2) : ctx->fb) : s, ctx->ev_part[k], ctx->ev_fb[k], ctx->ev_wide[k]);
         if (st) return st;
         if (hold_parse && prev_k >= 0) {
             MI_HIP(ctx, hipStreamWaitEvent(sp, ctx->ev_part[k], 0));

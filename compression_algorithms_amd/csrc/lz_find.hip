@@ -197,7 +197,7 @@ void k_lz_sort_home(const uint8_t *__restrict__ in, uint64_t n_total, LzP P, LzS
     // how many blocks fell back, left where the host sees it (pinned word behind the order flag): LATER launches size their
     // fallback grids by it — no synchronisation; the batches of one call are all queued before the first runs, so the hint a
     // call reads is what an earlier call left (lz_emit.hip)
-    if (bcount && blockIdx.x == 0 && threadIdx.x == 0 && P.order_flag) P.order_flag[1] = count;
+    if (bcount && blockIdx.x == 0 && threadIdx.x == 0 && P.order_flag) { P.order_flag[1] = count; P.order_flag[2] = nb; }
     for (uint32_t bi = blockIdx.x; bi < count; bi += gridDim.x) {
         lz_sort_home_block(in, n_total, P, sc, block0, blist ? blist[bi] : bi);
         __syncthreads();
