@@ -256,9 +256,9 @@ struct OpAm { __device__ uint64_t operator()(uint64_t earlier, uint64_t later) c
 //   hook(j, e)  called for every element with the output index it was stored at (e.g. to count the NEXT pass's digits)
 struct RadixNoHook { __device__ __forceinline__ void operator()(uint32_t, uint32_t) const {} };
 template <int NWAVES> __device__ __forceinline__ uint32_t radix_seg(uint32_t n) { return ((n + (uint32_t)(NWAVES * 64) - 1u) / (uint32_t)(NWAVES * 64)) * 64u; }
-template <int D> struct RadixDepth { static constexpr int value = D; };
+template <int D, bool SKIP = false> struct RadixDepth { static constexpr int value = D; static constexpr bool skip_identity = SKIP; };
 template <int NWAVES, int NBITS, typename E, typename CntRow, typename Load, typename Digit, typename Store, typename Hook = RadixNoHook, typename Depth = RadixDepth<1>>
-__device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load, Digit digit, Store store, uint32_t arank = 0u /* LZP_ARANK | LZP_BREAK */, uint64_t *dbg = nullptr,
+__device__ __forceinline__ bool radix_pass(uint32_t n, CntRow *s_cnt, Load load, Digit digit, Store store, uint32_t arank = 0u /* LZP_ARANK | LZP_BREAK */, uint64_t *dbg = nullptr,
                                            bool counted = false, Hook hook = Hook(), Depth = Depth())
 {
     long long tk_ = dbg ? clock64() : 0;
@@ -287,7 +287,15 @@ __device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load,
 #pragma unroll
                 for (int u = 0; u < D; ++u) dg[u] = digit(ee[u]);
 #pragma unroll
-                for (int u = 0; u < D; ++u) if (i + 64u * u < b) atomicAdd(&cnt[dg[u] * ST + wave], 1u);
+                for (int u = 0; u < D; ++u) {
+                    // 64 elements with ONE digit (a run of one byte value: equal words, equal homes) are one add, not 64 on one address
+                    const bool v = i + 64u * u < b;
+                    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dg[u]);
+                    const uint64_t live = __ballot(v);
+                    if (__ballot(v && dg[u] != d0) == 0ull && (live & 1ull)) {               // (lane 0 is live: d0 is a live lane's digit)
+                        if (lane == 0) atomicAdd(&cnt[d0 * ST + wave], (uint32_t)__popcll(live));
+                    } else if (v) atomicAdd(&cnt[dg[u] * ST + wave], 1u);
+                }
             }
         } else
         for (uint32_t i = a + lane; i < b; i += 256) {
@@ -308,6 +316,11 @@ __device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load,
         for (int w = 0; w < NWAVES; ++w) pre[w] = cnt[tid * ST + w];
 #pragma unroll
         for (int w = 0; w < NWAVES; ++w) { const uint32_t t = pre[w]; pre[w] = tot; tot += t; }
+    }
+    if constexpr (Depth::skip_identity) {
+        // one digit holds every element (a block of one byte value on the fallback's sorts): the pass would copy its input — the
+        // caller keeps the input instead (returns true; nothing has been stored)
+        if (__syncthreads_or((tid < ND && tot == n) ? 1 : 0)) return true;
     }
     __shared__ uint32_t s_scan[18];
     uint32_t total;
@@ -350,7 +363,7 @@ __device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load,
         }
         __syncthreads();
         RP_TICK(10);
-        return;
+        return false;
     }
     if constexpr (Depth::value > 1) {
         // ballot ranking, D steps of 64 elements per round: all D loads, then all D key lookups, then the D rankings in step order
@@ -384,7 +397,7 @@ __device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load,
         }
         __syncthreads();
         RP_TICK(10);
-        return;
+        return false;
     }
     // the element and its digit of the NEXT step are fetched while this step ranks and stores (two dependent LDS reads
     // off the chain: measured, the scatter is a chain of LDS round trips, 58 % of a pass)
@@ -414,6 +427,7 @@ __device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load,
     }
     __syncthreads();
     RP_TICK(10);
+    return false;
 }
 
 // Measured in k_lz2_find (MI_LZ_DEBUG counters, 3.5k keys, 8 waves): count 2.8k, offsets 2.0k, scatter 6.6k cycles per 8-bit
@@ -425,5 +439,11 @@ __device__ __forceinline__ void radix_pass(uint32_t n, CntRow *s_cnt, Load load,
 template <int NBITS, typename E, typename CntRow, typename Load, typename Digit, typename Store>
 __device__ __forceinline__ void radix_pass_1024(uint32_t n, CntRow *s_cnt, Load load, Digit digit, Store store, uint32_t arank = 0u)
 {
-    radix_pass<16, NBITS, E>(n, s_cnt, load, digit, store, arank, nullptr, false, RadixNoHook(), RadixDepth<4>());
+    (void)radix_pass<16, NBITS, E>(n, s_cnt, load, digit, store, arank, nullptr, false, RadixNoHook(), RadixDepth<4>());
+}
+// ... the same, but a pass in which ONE digit holds every element stores nothing and returns true: the caller goes on from its input
+template <int NBITS, typename E, typename CntRow, typename Load, typename Digit, typename Store>
+__device__ __forceinline__ bool radix_pass_1024_or_skip(uint32_t n, CntRow *s_cnt, Load load, Digit digit, Store store)
+{
+    return radix_pass<16, NBITS, E>(n, s_cnt, load, digit, store, 0u, nullptr, false, RadixNoHook(), RadixDepth<4, true>());
 }

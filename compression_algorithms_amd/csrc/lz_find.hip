@@ -51,19 +51,19 @@ __device__ __forceinline__ void lz_sort_home_block(const uint8_t *__restrict__ i
     uint16_t *B = sc.posB + (size_t)lb * LZ_MAX_BLOCK;
     auto home_of = [&](uint32_t p) -> uint32_t { return lz_mix32(lds_word(s_in, p)) & Tmask; };
 
-    // ---- sort positions by home, stable in time: identity -> A -> B -> A
-    radix_pass_1024<8, uint32_t>(n, s_cnt,
-        [&](uint32_t i) { return i; },
-        [&](uint32_t e) { return home_of(e) & 255u; },
-        [&](uint32_t j, uint32_t e) { A[j] = (uint16_t)e; });
-    radix_pass_1024<8, uint32_t>(n, s_cnt,
-        [&](uint32_t i) { return (uint32_t)A[i]; },
-        [&](uint32_t e) { return (home_of(e) >> 8) & 255u; },
-        [&](uint32_t j, uint32_t e) { B[j] = (uint16_t)e; });
-    radix_pass_1024<8, uint32_t>(n, s_cnt,
-        [&](uint32_t i) { return (uint32_t)B[i]; },
-        [&](uint32_t e) { return (home_of(e) >> 16) & 255u; },
-        [&](uint32_t j, uint32_t e) { A[j] = (uint16_t)e; });
+    // ---- sort positions by home, stable in time.  A pass in which every position has the same digit (a block of one byte value:
+    //      all three) stores nothing and the next one reads what this one would have read: `cur` = the current order (nullptr: the
+    //      identity), a pass writes to the array `cur` is not
+    const uint16_t *cur = nullptr;
+    for (uint32_t pass = 0; pass < 3; ++pass) {
+        uint16_t *dst = (cur == A) ? B : A;
+        const uint32_t sh = 8u * pass;
+        const bool same = radix_pass_1024_or_skip<8, uint32_t>(n, s_cnt,
+            [&](uint32_t i) { return cur ? (uint32_t)cur[i] : i; },
+            [&](uint32_t e) { return (home_of(e) >> sh) & 255u; },
+            [&](uint32_t j, uint32_t e) { dst[j] = (uint16_t)e; });
+        if (!same) cur = dst;
+    }
 
     // ---- cluster sweep over the sorted order (logical index k; `rot` rotates the order when a
     //      deflate-style cluster wraps past bucket T-1 into bucket 0)
@@ -76,7 +76,7 @@ __device__ __forceinline__ void lz_sort_home_block(const uint8_t *__restrict__ i
         auto phys = [&](uint32_t k) { uint32_t p = k + rot; return p >= n ? p - n : p; };
         auto hk_at = [&](uint32_t k, uint32_t &pos) -> int32_t {
             const uint32_t ph = phys(k);
-            pos = A[ph];
+            pos = cur ? (uint32_t)cur[ph] : ph;
             int32_t h = (int32_t)home_of(pos);
             if (rot && ph >= rot) h -= (int32_t)T;
             return h;
@@ -92,18 +92,18 @@ __device__ __forceinline__ void lz_sort_home_block(const uint8_t *__restrict__ i
         };
         auto for_chunk = [&](auto &&fn) {
             if (k0 >= k1) return;
-            if (rot == 0 && k1 - k0 == 64u) {
-                uint4 nv = *reinterpret_cast<const uint4 *>(A + k0);
+            if (rot == 0 && k1 - k0 == 64u && cur) {
+                uint4 nv = *reinterpret_cast<const uint4 *>(cur + k0);
 #pragma unroll 1
                 for (uint32_t k = k0; k < k1; k += 8u) {
                     const uint4 v = nv;
-                    nv = *reinterpret_cast<const uint4 *>(A + ((k + 8u < k1) ? k + 8u : k));          // unconditional (clamped)
+                    nv = *reinterpret_cast<const uint4 *>(cur + ((k + 8u < k1) ? k + 8u : k));        // unconditional (clamped)
                     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                     for (uint32_t u = 0; u < 8; ++u) fn(k + u, (w[u >> 1] >> ((u & 1u) * 16u)) & 0xFFFFu);
                 }
             } else {
-                for (uint32_t k = k0; k < k1; ++k) fn(k, (uint32_t)A[phys(k)]);
+                for (uint32_t k = k0; k < k1; ++k) { const uint32_t ph = phys(k); fn(k, cur ? (uint32_t)cur[ph] : ph); }
             }
         };
         // (a) chunk maximum of g = home - k
@@ -216,6 +216,7 @@ void k_lz_sort_cluster(LzScratch sc, uint32_t nb, const uint32_t *__restrict__ b
     for (uint32_t bi = blockIdx.x; bi < count; bi += gridDim.x) {
     const uint32_t lb = blist ? blist[bi] : bi;
     const uint32_t n = sc.meta[lb].n;
+    if (sc.meta[lb].ngroups <= 1u) continue;              // ONE cluster (a block of one byte value): position order is (cluster, time) order already
     uint64_t *A = sc.eA + (size_t)lb * LZ_MAX_BLOCK;
     uint64_t *B = sc.eB + (size_t)lb * LZ_MAX_BLOCK;
     radix_pass_1024<8, uint64_t>(n, s_cnt,
