@@ -544,15 +544,23 @@ void k_lz_emulate(LzP P, LzScratch sc, uint32_t nb, const uint32_t *__restrict__
 // one workgroup per giant cluster (and per cluster of >= LZ_WAVE_MIN entries the tile kernel hands over).
 // One word only: closed form.  <= LZ_GIANT_CAP entries: wave replay (lz_replay.h).  Larger: one lane, slots/occupants in
 // global scratch, bitmap in LDS.
+// CAPE = LZ_GIANT_CAP: every cluster left on the list (128 KiB of LDS: one workgroup per CU).  CAPE = LZ_GIANT_SMALL: only the
+// clusters of at most that many entries — most of a list: the "runs" family lists ~2 000 clusters of 128 .. 7 500 entries per batch,
+// and at one workgroup per CU, one wave of it replaying, they took 11 of that family's 23 ms — on 24 KiB, six workgroups per CU,
+// launched first with a cursor of its own; a cluster it finishes is flagged like those of k_lz_emulate_dom and the full instance
+// behind it skips it.
+#define LZ_GIANT_SMALL 4096u
+template <uint32_t CAPE>
 __global__ __launch_bounds__(256)
 void k_lz_emulate_giant(LzP P, LzScratch sc)
 {
-    // one LDS buffer, two uses: wave replay of <= LZ_GIANT_CAP entries (slot -> word id | position << 16, entry -> slot) or of
-    // up to 65 536 entries (slot -> word id only; lz_replay.h huge_replay)
-    __shared__ __attribute__((aligned(16))) uint8_t s_raw[2 * LZ_MAX_BLOCK];
-    uint32_t *s_occ32 = reinterpret_cast<uint32_t *>(s_raw);                              // [LZ_GIANT_CAP]
-    uint16_t *s_slot16 = reinterpret_cast<uint16_t *>(s_raw + 4 * LZ_GIANT_CAP);          // [LZ_GIANT_CAP]
-    uint16_t *s_oid16 = reinterpret_cast<uint16_t *>(s_raw);                              // [65536]
+    constexpr bool SMALL = CAPE < LZ_GIANT_CAP;
+    // one LDS buffer, two uses: wave replay of <= CAPE entries (slot -> word id | position << 16, entry -> slot) or — full instance
+    // only — of up to 65 536 entries (slot -> word id only; lz_replay.h huge_replay)
+    __shared__ __attribute__((aligned(16))) uint8_t s_raw[SMALL ? 6 * CAPE : 2 * LZ_MAX_BLOCK];
+    uint32_t *s_occ32 = reinterpret_cast<uint32_t *>(s_raw);                              // [CAPE]
+    uint16_t *s_slot16 = reinterpret_cast<uint16_t *>(s_raw + 4 * CAPE);                  // [CAPE]
+    uint16_t *s_oid16 = reinterpret_cast<uint16_t *>(s_raw);                              // [65536] (full instance)
     static_assert(6 * LZ_GIANT_CAP <= 2 * LZ_MAX_BLOCK, "wave-replay tables must fit the buffer");
     __shared__ uint32_t s_end;
     const int tid = threadIdx.x;
@@ -561,12 +569,12 @@ void k_lz_emulate_giant(LzP P, LzScratch sc)
     __shared__ uint32_t s_gnext;
     for (;;) {
         __syncthreads();
-        if (tid == 0) s_gnext = atomicAdd(&sc.giant_count[3], 1u);
+        if (tid == 0) s_gnext = atomicAdd(&sc.giant_count[SMALL ? 4 : 3], 1u);
         __syncthreads();
         if (s_gnext >= count) break;
         const uint32_t g = lz_giant_slot(sc, s_gnext, n_back);
         const uint32_t lb = sc.giant_list[2 * g], a = sc.giant_list[2 * g + 1];
-        if (a & DOM_DONE) continue;                      // k_lz_emulate_dom has replayed it
+        if (a & DOM_DONE) continue;                      // k_lz_emulate_dom (or the small instance of this kernel) has replayed it
         const LzBlockMeta mt = sc.meta[lb];
         const uint32_t n = mt.n;
         const uint64_t *E = sc.eA + (size_t)lb * LZ_MAX_BLOCK;
@@ -574,9 +582,12 @@ void k_lz_emulate_giant(LzP P, LzScratch sc)
         __syncthreads();
         if (tid == 0) s_end = n;
         __syncthreads();
-        for (uint32_t i = a + 1 + tid; i < n; i += 256) if (((uint32_t)E[i] & 0xFFFFu) != gid) { atomicMin(&s_end, i); break; }
+        // (the small instance looks no further than one entry past its capacity: a longer cluster is not its business)
+        const uint32_t scan_end = SMALL ? (n < a + CAPE + 2u ? n : a + CAPE + 2u) : n;
+        for (uint32_t i = a + 1 + tid; i < scan_end; i += 256) if (((uint32_t)E[i] & 0xFFFFu) != gid) { atomicMin(&s_end, i); break; }
         __syncthreads();
         const uint32_t b = s_end, m = b - a;
+        if (SMALL && (m > CAPE || (s_end == n && scan_end < n))) continue;
         const uint32_t W = 1u << P.wbits;
         uint16_t *cand = sc.cand + (size_t)lb * LZ_MAX_BLOCK;
         const bool first = a == 0;
@@ -617,6 +628,7 @@ void k_lz_emulate_giant(LzP P, LzScratch sc)
                 const uint32_t an = s_anch[lo];
                 if (an != i) cand[(uint32_t)(E[a + i] >> 16) & 0xFFFFu] = (uint16_t)((uint32_t)(E[a + an] >> 16) & 0xFFFFu);
             }
+            if (SMALL && tid == 0) sc.giant_list[2 * g + 1] = a | DOM_DONE;
             __syncthreads();
             continue;
         }
@@ -637,7 +649,15 @@ void k_lz_emulate_giant(LzP P, LzScratch sc)
             __syncthreads();
             if (tid < 64) {
                 const bool plain = anom == ~0u && limit == ~0u;
-                if (m <= LZ_GIANT_CAP) {
+                if constexpr (SMALL) {
+                    if (m <= 2048u) {
+                        if (plain) big_replay<CAPE, 1, true>(s_occ32, s_slot16, (uint32_t)tid, W, m, anom, limit, gp, grs, gid, gc);
+                        else big_replay<CAPE, 1, false>(s_occ32, s_slot16, (uint32_t)tid, W, m, anom, limit, gp, grs, gid, gc);
+                    } else {
+                        if (plain) big_replay<CAPE, 2, true>(s_occ32, s_slot16, (uint32_t)tid, W, m, anom, limit, gp, grs, gid, gc);
+                        else big_replay<CAPE, 2, false>(s_occ32, s_slot16, (uint32_t)tid, W, m, anom, limit, gp, grs, gid, gc);
+                    }
+                } else if (m <= LZ_GIANT_CAP) {
                     // as few bitmap registers as the cluster needs (2048 slots each): every first-fit and every clear walks them all
                     if (m <= 4096u) {
                         if (plain) big_replay<LZ_GIANT_CAP, 2, true>(s_occ32, s_slot16, (uint32_t)tid, W, m, anom, limit, gp, grs, gid, gc);
@@ -659,6 +679,7 @@ void k_lz_emulate_giant(LzP P, LzScratch sc)
             }
             __syncthreads();
             for (uint32_t i = tid; i < m; i += 256) { const uint32_t c = gc[i]; if (c != LZ_NONE16) cand[gp[i]] = (uint16_t)c; }
+            if (SMALL && tid == 0) sc.giant_list[2 * g + 1] = a | DOM_DONE;
         }
         __syncthreads();
     }
@@ -851,7 +872,7 @@ mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t
     const int saved_prof = ctx->profiling;
     static const bool prof_fb = getenv("MI_LZ_PROF_FALLBACK") != nullptr;      // inputs that live in the fallback (scripts/adv_profile.py)
     if (blist && !prof_fb) ctx->profiling = 0;
-    MI_HIP(ctx, hipMemsetAsync(sc.giant_count, 0, 16, s));       // [0] / [2] clusters listed from the front / the end, [1] / [3] cursors (lz_common.h)
+    MI_HIP(ctx, hipMemsetAsync(sc.giant_count, 0, 32, s));       // [0] / [2] clusters listed from the front / the end, [1] / [3] / [4] cursors (lz_common.h)
     // fallback: few looping workgroups (see LZ_FB_GRID) — unless the last finished batch (in practice: of an earlier call) had
     // many blocks here (non-text input): the count k_lz_sort_home left in pinned memory sizes the grids (pages family: half the
     // chip sat idle behind 128 workgroups)
@@ -881,7 +902,11 @@ mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t
         mi_prof_scope p(ctx, "k_lz_emulate_giant", s, (uint64_t)nb * P.block);
         const uint32_t cap = blist ? (hint > LZ_FB_GRID ? 512u : LZ_FB_GRID) : 1024u;
         const uint32_t grid = nb < cap ? nb : cap;
-        hipLaunchKernelGGL(k_lz_emulate_giant, dim3(grid), dim3(256), 0, s, P, sc);
+        if (blist && hint > 8u) {                           // blocks do fall back (lz_emit.hip's fb_busy): the clusters of <= LZ_GIANT_SMALL entries six workgroups per CU
+            const uint32_t gs = nb * 2u < (uint32_t)ctx->num_cu * 6u ? nb * 2u : (uint32_t)ctx->num_cu * 6u;
+            hipLaunchKernelGGL(k_lz_emulate_giant<LZ_GIANT_SMALL>, dim3(gs), dim3(256), 0, s, P, sc);
+        }
+        hipLaunchKernelGGL(k_lz_emulate_giant<LZ_GIANT_CAP>, dim3(grid), dim3(256), 0, s, P, sc);
     }
     ctx->profiling = saved_prof;
     MI_HIP(ctx, hipGetLastError());
