@@ -5,12 +5,17 @@
 // as driven by lz77_compress (lz77.c:281-338 / deflate lz77.c:215-275).
 //
 //   k_lz_sort_home       block -> LDS; positions sorted by (home bucket, time) with three
-//                        stable 8-bit radix passes; probe clusters by a prefix-max ("parking")
-//                        sweep; per position {cluster, dense home index, word id}
+//                        stable 8-bit radix passes (a pass that would not move anything stores
+//                        nothing); probe clusters by a prefix-max ("parking") sweep; per position
+//                        {cluster, dense home index, word id}
 //   k_lz_sort_cluster    entries sorted by (cluster, time): two stable 8-bit radix passes
-//   k_lz_emulate         a tile of clusters in LDS; one lane replays one cluster in time
-//                        order: FIFO eviction, find, first-fit insert on an occupancy bitmap
-//   k_lz_emulate_giant   clusters too large for a tile (one workgroup each)
+//   k_lz_emulate         a tile of clusters in LDS; clusters of one word by a closed form, mixed
+//                        clusters of < 16 entries one per LANE off a dense list, of 16..127
+//                        entries one per WAVE of the workgroup (lz_replay.h), in time order: FIFO
+//                        eviction, find, first-fit insert on an occupancy bitmap
+//   k_lz_emulate_dom     giant clusters that one word dominates, off a cursor (lz_dom.h)
+//   k_lz_emulate_giant   what is left of the giant list: one workgroup per cluster, a 24 KiB
+//                        instance for <= 4096 entries in front of the 128 KiB one
 //
 // Output: cand[p] = what find(word at p) returns in the table state after positions 0..p-1
 // were inserted (0xFFFF = none).  The parse consumes it in lz_emit.hip.
