@@ -17,6 +17,7 @@
 //   k_defh_decode   one wave per block: record -> tokens -> bytes (LZ copy in LDS), no token stream in HBM
 #include "lz_common.h"
 #include "lz_decode.h"
+#include "heap_cells.h"
 #include <stdlib.h>
 
 #define DEFH_NSYM     286
@@ -37,52 +38,19 @@
 
 // The reference's array heap (algorithms/huffman/huffman.c:100-163: strict '<' on the frequency in both sifts, leaves
 // enqueued in symbol order, first pop = left).  A heap cell holds frequency << 10 | node id (frequencies are <= 65 536
-// tokens, ids < 572), so a comparison is ONE LDS read per node instead of two dependent ones (heap[i], then freq[heap[i]]):
-// the merge loop runs on one lane and is the critical path of k_defh_encode.  Ties are still decided by position alone:
-// only the frequency field is compared.
+// tokens, ids < 572), so a comparison is ONE LDS read per node instead of two dependent ones (heap[i], then freq[heap[i]]) and
+// a merged node's frequency comes out of the two cells it pops: no frequency array.  The merge loop runs on one lane and is the
+// critical path of the entropy stage; its sifts read ahead of their decisions (heap_cells.h).  Ties are still decided by
+// position alone: only the frequency field is compared.
 struct DefhHeap {
-    uint32_t freq[2 * DEFH_NSYM];
     int16_t  parent[2 * DEFH_NSYM];
-    uint32_t heap[DEFH_NSYM];            // frequency << 10 | node id
+    uint32_t heap[DEFH_NSYM + 2];        // frequency << 10 | node id
     int16_t  leaf_of[DEFH_NSYM];
-    int      nheap, nnodes, root;
+    int      nnodes, root;
 };
+typedef HeapCells<uint32_t, 10> DefhCells;
 #define DH_F(c) ((c) >> 10)
 #define DH_ID(c) ((int)((c) & 1023u))
-
-__device__ inline void dh_up(DefhHeap &h, int i)
-{
-    const uint32_t me = h.heap[i];
-    while (i > 0) {
-        const int par = (i - 1) >> 1;
-        const uint32_t pc = h.heap[par];
-        if (!(DH_F(me) < DH_F(pc))) break;
-        h.heap[i] = pc;
-        i = par;
-    }
-    h.heap[i] = me;
-}
-__device__ inline void dh_down(DefhHeap &h, int i)
-{
-    const uint32_t me = h.heap[i];
-    for (;;) {
-        const int l = 2 * i + 1, r = l + 1;
-        int best = i; uint32_t bc = me;
-        if (l < h.nheap) { const uint32_t lc = h.heap[l]; if (DH_F(lc) < DH_F(bc)) { best = l; bc = lc; } }
-        if (r < h.nheap) { const uint32_t rc = h.heap[r]; if (DH_F(rc) < DH_F(bc)) { best = r; bc = rc; } }
-        if (best == i) break;
-        h.heap[i] = bc;
-        i = best;
-    }
-    h.heap[i] = me;
-}
-__device__ inline int dh_pop(DefhHeap &h)
-{
-    const int id = DH_ID(h.heap[0]);
-    h.heap[0] = h.heap[--h.nheap];
-    dh_down(h, 0);
-    return id;
-}
 
 __device__ __forceinline__ uint32_t clz16(uint32_t d) { return (uint32_t)__builtin_clz(d & 0xFFFFu) - 16u; }   // d in 1..65535
 
@@ -120,44 +88,55 @@ static_assert(DEFH_CODE_AT + 288u <= LZ_SLOT_WORDS, "tally and codes live behind
 __global__ __launch_bounds__(64)
 void k_defh_lengths(uint32_t *__restrict__ slots)
 {
+    // 4.5 KiB of LDS (8 before): the tally's array becomes the codes' once the leaves are enqueued, the heap cells carry the
+    // frequencies — the wave holds its LDS for the whole serial merge, and LDS-seconds are what the pipeline's stages compete for
     __shared__ DefhHeap h;
-    __shared__ uint32_t s_hist[DEFH_NSYM + 2], s_code[DEFH_NSYM + 2];
+    __shared__ uint32_t s_hist[DEFH_NSYM + 2];
     __shared__ __attribute__((aligned(16))) uint8_t s_len[DEFH_NSYM + 2];
     __shared__ uint32_t s_count[34], s_next[34];
+    uint32_t *const s_code = s_hist;
     const int tid = threadIdx.x;
     uint32_t *out = slots + (size_t)blockIdx.x * LZ_SLOT_WORDS;
     // ---- tally (lz77.c:206,231,273): taken by k_lz_parse_emit while it wrote the token records, left at the end of the slot
     for (int i = tid; i < DEFH_NSYM + 2; i += 64) { s_hist[i] = out[LZ_DEFH_HIST_AT + i]; s_len[i] = 0; }
+    for (int i = tid; i < DEFH_NSYM; i += 64) h.leaf_of[i] = -1;
     __syncthreads();
     // ---- code lengths: the reference heap, leaves enqueued in symbol order (one lane; <= 285 merges)
     if (tid == 0) {
-        h.nheap = 0; h.nnodes = 0; h.root = -1;
-        for (int s = 0; s < DEFH_NSYM; ++s) {
-            h.leaf_of[s] = -1;
-            const uint32_t f = s_hist[s];
-            if (!f) continue;
-            const int id = h.nnodes++;
-            h.freq[id] = f; h.parent[id] = -1; h.leaf_of[s] = (int16_t)id;
-            h.heap[h.nheap++] = (f << 10) | (uint32_t)id;
-            dh_up(h, h.nheap - 1);
-        }
-        if (h.nnodes > 1) {
-            while (h.nheap > 1) {
-                const int l = dh_pop(h), r = dh_pop(h), id = h.nnodes++;
-                h.freq[id] = h.freq[l] + h.freq[r]; h.parent[id] = -1;
-                h.parent[l] = (int16_t)id; h.parent[r] = (int16_t)id;
-                h.heap[h.nheap++] = (h.freq[id] << 10) | (uint32_t)id;
-                dh_up(h, h.nheap - 1);
+        int nheap = 0, nnodes = 0, root = -1;
+        for (int s0 = 0; s0 < DEFH_NSYM; s0 += 8) {
+            uint32_t f8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f8[k] = s_hist[s0 + k < DEFH_NSYM ? s0 + k : 0];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int s = s0 + k;
+                const uint32_t f = f8[k];
+                if (s >= DEFH_NSYM || !f) continue;
+                const int id = nnodes++;
+                h.parent[id] = -1; h.leaf_of[s] = (int16_t)id;
+                DefhCells::push(h.heap, nheap, (f << 10) | (uint32_t)id);
             }
-            h.root = dh_pop(h);
         }
+        if (nnodes > 1) {
+            while (nheap > 1) {
+                const uint32_t lc = DefhCells::pop(h.heap, nheap), rc = DefhCells::pop(h.heap, nheap);
+                const int id = nnodes++;
+                h.parent[id] = -1;
+                h.parent[DH_ID(lc)] = (int16_t)id; h.parent[DH_ID(rc)] = (int16_t)id;
+                DefhCells::push(h.heap, nheap, ((DH_F(lc) + DH_F(rc)) << 10) | (uint32_t)id);
+            }
+            root = DH_ID(DefhCells::pop(h.heap, nheap));
+        }
+        h.nnodes = nnodes; h.root = root;
     }
     __syncthreads();
     for (int sy = tid; sy < DEFH_NSYM; sy += 64) {
-        if (!s_hist[sy]) continue;
+        const int leaf = h.leaf_of[sy];
+        if (leaf < 0) continue;
         uint32_t len = 0;
         if (h.nnodes == 1) len = 1;
-        else for (int node = h.leaf_of[sy]; node != h.root; node = h.parent[node]) ++len;
+        else for (int node = leaf; node != h.root; node = h.parent[node]) ++len;
         s_len[sy] = (uint8_t)len;
     }
     __syncthreads();

@@ -12,6 +12,7 @@
 // HUFF_TILE input bytes = one workgroup; per-tile histograms (1 KiB each, 3 % of n) turn the
 // bit-offset computation into a dot product with the code lengths instead of a third pass.
 #include "common.h"
+#include "heap_cells.h"
 #include <stddef.h>
 
 #define HUFF_TILE      32768u          // input bytes per workgroup
@@ -75,44 +76,13 @@ struct HeapLds {
     uint8_t  value[511], is_right[511];
     uint64_t heap[256];                 // frequency << 16 | node id: a comparison is ONE LDS read per node (the loop runs on one lane)
     int16_t  leaf_of[256];
-    int      nheap, nnodes, root;
+    uint32_t hist[256];                 // the counters, so that lane 0 does not fetch them from global memory one by one
+    int      nnodes, root;
 };
+typedef HeapCells<uint64_t, 16> HuffCells;   // sifts that read ahead of their decisions (heap_cells.h); strict '<' on the
+                                             // frequency alone, ties keep their places (huffman.c:111-119, 121-140)
 #define HH_F(c) ((uint32_t)((c) >> 16))
 #define HH_ID(c) ((int)((c) & 0xFFFFu))
-
-__device__ inline void heap_up(HeapLds &h, int i)
-{
-    const uint64_t me = h.heap[i];
-    while (i > 0) {
-        const int par = (i - 1) >> 1;
-        const uint64_t pc = h.heap[par];
-        if (!(HH_F(me) < HH_F(pc))) break;           // strict '<' on the frequency alone: ties keep their places (huffman.c:111-119)
-        h.heap[i] = pc;
-        i = par;
-    }
-    h.heap[i] = me;
-}
-__device__ inline void heap_down(HeapLds &h, int i)
-{
-    const uint64_t me = h.heap[i];
-    for (;;) {
-        const int l = 2 * i + 1, r = l + 1;
-        int best = i; uint64_t bc = me;
-        if (l < h.nheap) { const uint64_t lc = h.heap[l]; if (HH_F(lc) < HH_F(bc)) { best = l; bc = lc; } }
-        if (r < h.nheap) { const uint64_t rc = h.heap[r]; if (HH_F(rc) < HH_F(bc)) { best = r; bc = rc; } }
-        if (best == i) break;
-        h.heap[i] = bc;
-        i = best;
-    }
-    h.heap[i] = me;
-}
-__device__ inline int heap_pop(HeapLds &h)
-{
-    const int id = HH_ID(h.heap[0]);
-    h.heap[0] = h.heap[--h.nheap];
-    heap_down(h, 0);
-    return id;
-}
 
 __global__ __launch_bounds__(256)
 void k_huff_build(const uint32_t *__restrict__ hist, mi_huffman_tree *__restrict__ tree,
@@ -123,34 +93,42 @@ void k_huff_build(const uint32_t *__restrict__ hist, mi_huffman_tree *__restrict
     __shared__ uint32_t s_maxlen;
     const int tid = threadIdx.x;
     const uint32_t f = hist[tid];
-    if (tid == 0) {
-        h.nheap = 0; h.nnodes = 0; h.root = -1; s_maxlen = 0;
-    }
+    if (tid == 0) s_maxlen = 0;
     h.leaf_of[tid] = -1;
+    h.hist[tid] = f;
     __syncthreads();
     if (tid == 0) {
-        for (int s = 0; s < 256; ++s) {
-            uint32_t fs = hist[s];
-            if (!fs) continue;
-            int id = h.nnodes++;
-            h.freq[id] = fs; h.left[id] = -1; h.right[id] = -1; h.parent[id] = -1;
-            h.value[id] = (uint8_t)s; h.is_right[id] = 0; h.leaf_of[s] = (int16_t)id;
-            h.heap[h.nheap++] = ((uint64_t)fs << 16) | (uint64_t)id;
-            heap_up(h, h.nheap - 1);
+        int nheap = 0, nnodes = 0, root = -1;
+        for (int s0 = 0; s0 < 256; s0 += 8) {
+            uint32_t f8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f8[k] = h.hist[s0 + k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int s = s0 + k;
+                const uint32_t fs = f8[k];
+                if (!fs) continue;
+                const int id = nnodes++;
+                h.freq[id] = fs; h.left[id] = -1; h.right[id] = -1; h.parent[id] = -1;
+                h.value[id] = (uint8_t)s; h.is_right[id] = 0; h.leaf_of[s] = (int16_t)id;
+                HuffCells::push(h.heap, nheap, ((uint64_t)fs << 16) | (uint64_t)id);
+            }
         }
-        if (h.nheap > 0) {
-            while (h.nheap > 1) {
-                int l = heap_pop(h), r = heap_pop(h);
-                int id = h.nnodes++;
-                h.freq[id] = h.freq[l] + h.freq[r];            // u32, wraps like the reference
+        if (nheap > 0) {
+            while (nheap > 1) {
+                const uint64_t lc = HuffCells::pop(h.heap, nheap), rc = HuffCells::pop(h.heap, nheap);
+                const int l = HH_ID(lc), r = HH_ID(rc);
+                const int id = nnodes++;
+                const uint32_t fm = HH_F(lc) + HH_F(rc);           // u32, wraps like the reference
+                h.freq[id] = fm;
                 h.left[id] = (int16_t)l; h.right[id] = (int16_t)r; h.parent[id] = -1;
                 h.value[id] = 0; h.is_right[id] = 0;
                 h.parent[l] = (int16_t)id; h.parent[r] = (int16_t)id; h.is_right[r] = 1;
-                h.heap[h.nheap++] = ((uint64_t)h.freq[id] << 16) | (uint64_t)id;
-                heap_up(h, h.nheap - 1);
+                HuffCells::push(h.heap, nheap, ((uint64_t)fm << 16) | (uint64_t)id);
             }
-            h.root = heap_pop(h);
+            root = HH_ID(HuffCells::pop(h.heap, nheap));
         }
+        h.nnodes = nnodes; h.root = root;
     }
     __syncthreads();
     // path codes: every present symbol walks leaf -> root; the edge next to the leaf is the LSB

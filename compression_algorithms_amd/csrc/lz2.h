@@ -54,7 +54,10 @@ __host__ __device__ __forceinline__ uint32_t lz2_class_of(uint32_t cnt, uint32_t
 {
     // wave replay: 4 = 512..1024 entries and 5 = wave_min..511 share one launch that starts the long chains first
     // (three wave-replay classes by LDS need: 3 = 128..255 entries (1.5 KiB per wave), 5 = 256..511 (3 KiB), 4 = 512..1024 (6 KiB))
-    if (cnt >= wave_min) return cnt > LZ2_BIG_SMALL ? 6u : cnt >= 512u ? 4u : 5u;      // (class 3 — 128..255 on 1.5 KiB — was measured: slower)
+    // wave_min bits 16..: the row replay is on (lz2_find.hip k_lz2_rows): 128..255 entries are a class of their own (3: rows of 8 lanes)
+    const bool three = (wave_min >> 16) != 0u;
+    wave_min &= 0xFFFFu;
+    if (cnt >= wave_min) return cnt > LZ2_BIG_SMALL ? 6u : cnt >= 512u ? 4u : (three && cnt < 256u) ? 3u : 5u;   // (class 3 on the WAVE replay with 1.5 KiB was measured: slower)
     return cnt < 16 ? 7u : cnt < 32 ? 0u : cnt < 64 ? 1u : cnt < 128 ? 2u : cnt < 256 ? 3u : 4u;
 }
 // cand placeholder of an entry whose cluster was exported: the entry's OWN position (a candidate is always smaller

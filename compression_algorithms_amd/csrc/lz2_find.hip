@@ -819,6 +819,175 @@ void k_lz2_dom(LzP P, Lz2Scratch sc)
 }
 
 // =============================================================================================
+// Row replay (round 4): SEVERAL exported clusters per wave, one per row of RL = 8 / 16 / 32 lanes (clusters of up to 256 / 512 /
+// 1024 entries: eight, four or two per wave).
+// The wave replay above spends ~65 wave-uniform instructions per entry and a CU issues one scalar instruction per cycle for all
+// its waves: k_lz2_big alone takes 10 of the step's 51 serial milliseconds (10^9 B, one stream).  Here nothing is wave-uniform
+// except the step counter: a row owns one cluster — its occupancy bitmap is RL dwords of LDS, one per lane; first fit = every
+// lane masks its dword, a ballot, the row's bits of it, ds_bpermute of the winning dword; a step's retirements (FIFO,
+// lz77.c:70-76: up to RL at once, a prefix of the live entries because positions ascend) are one LDS `and` per retiring lane;
+// the occupant of a slot and the slot + position of an entry are one LDS dword each — so a vector instruction serves all the
+// rows.  All global memory traffic happens at BOUNDARIES between passes of RL steps, uses before issues (a wait inside the
+// steps, or for a load some other row has just issued, would stall every row): the results of the last RL entries go out, the
+// next RL entries of every row were loaded a pass ago, and a three-stage prefetch (cursor -> descriptor -> first entries) has
+// the next cluster ready when a row finishes; rows start clusters on boundaries only.  16.25 KiB of LDS per wave for any RL.
+// Clusters come off a cursor (descriptor order); the one cluster per block that covers bucket 0 / T (anom / limit) is left to
+// k_lz2_big, which skips the descriptors flagged here.  Reference behaviour emulated: algorithms/lz77/lz77.c:55-108.
+// =============================================================================================
+#define ROW_BPERM(src_lane, v) ((uint32_t)__builtin_amdgcn_ds_bpermute((int)((src_lane) << 2), (int)(v)))
+
+// first free slot at or above `from` of the row's bitmap (lane l of the row holds dword l in v), or ~0u
+template <int RL>
+__device__ __forceinline__ uint32_t row_first_zero(uint32_t v, uint32_t from, uint32_t l, uint32_t rb)
+{
+    constexpr uint32_t RMASK = RL == 32 ? 0xFFFFFFFFu : ((1u << (RL & 31)) - 1u);
+    const uint32_t rw = from >> 5, lowmask = (1u << (from & 31u)) - 1u;
+    if (l < rw) v = 0xFFFFFFFFu; else if (l == rw) v |= lowmask;
+    const uint64_t mk = __ballot(v != 0xFFFFFFFFu);
+    const uint32_t my = (uint32_t)(mk >> rb) & RMASK;                       // this row's lanes that still have a free slot
+    const uint32_t ln = my ? (uint32_t)__builtin_ctz(my) : 0u;
+    const uint32_t mv = ROW_BPERM(rb + ln, v);
+    const uint32_t fz = (mv != 0xFFFFFFFFu) ? (uint32_t)__builtin_ctz(~mv) : 0u;
+    return my ? ((ln << 5) + fz) : ~0u;
+}
+
+template <int RL>                                         // lanes per row: 8, 16 or 32 (clusters of up to 256, 512, 1024 entries)
+__global__ __launch_bounds__(64)
+void k_lz2_rows(LzP P, Lz2Scratch sc, int cls_a, int cls_b, int cursor_slot)
+{
+    static_assert(RL == 8 || RL == 16 || RL == 32, "rows of 8, 16 or 32 lanes");
+    constexpr int NR = 64 / RL, CAPE = 32 * RL;            // rows per wave; slots of a row's bitmap (one dword per lane): 16.25 KiB per wave
+    constexpr uint32_t RMASK = RL == 32 ? 0xFFFFFFFFu : ((1u << (RL & 31)) - 1u);
+    __shared__ uint32_t s_occ[NR][CAPE];                   // slot -> word id | position << 16 of its occupant
+    __shared__ uint32_t s_ent[NR][CAPE];                   // entry -> its slot | its position << 16 (for its eviction)
+    __shared__ uint32_t s_bm[NR][RL];
+    const uint32_t lane = threadIdx.x, g = lane / (uint32_t)RL, l = lane & (uint32_t)(RL - 1), rb = lane & ~(uint32_t)(RL - 1);
+    const uint32_t W = 1u << P.wbits;
+    // two descriptor lists behind one cursor, the class of the LONGER clusters first: a launch lasts as long as its last chain
+    const uint32_t count_a = sc.big_count[cls_a], count = count_a + sc.big_count[cls_b];
+    uint32_t *cursor = sc.big_count + cursor_slot;         // (zeroed with the other counters by stage 1)
+    Lz2BigDesc *const descs_a = sc.desc[cls_a], *const descs_b = sc.desc[cls_b];
+    auto desc_of = [&](uint32_t ticket) -> Lz2BigDesc * { return ticket < count_a ? descs_a + ticket : descs_b + (ticket - count_a); };
+    uint32_t *occ = s_occ[g], *ent = s_ent[g], *bmw = s_bm[g];
+
+    bool active = false, exhausted = false;
+    uint32_t n = 0, i0 = 0, ev = 0;
+    size_t at = 0;
+    uint32_t cur_a = 0, cur_b = 0, out_acc = LZ_NONE16;
+    // the next cluster of this row: 0 = nothing, 1 = cursor value in flight, 2 = descriptor in flight, 3 = first entries in flight / ready
+    uint32_t pf_stage = 0, pf_ci = 0, pf_count = 0;
+    size_t pf_at = 0;
+    // Registers that ONLY loads write (no arithmetic on them before the next boundary, no conditional assignment: either would put
+    // a wait for the load right behind its issue).  Every boundary reloads all of them, from a harmless address when a row has
+    // nothing to ask for: r_n* = entries i0 + RL .. of the running cluster, r_f* = first RL entries of the prefetched cluster,
+    // r_d* = its descriptor, tk = lane 0's ticket from the cursor.
+    uint32_t r_np = 0, r_ni = 0, r_nr = 0, r_fp = 0, r_fi = 0, r_fr = 0, tk = 0;
+    uint4 r_d4 = make_uint4(0, 0, 0, 0); uint32_t r_d1 = 0;
+    // a zero the compiler cannot see through: on a provably uniform address it turns the cursor's atomic into its wave-aggregated
+    // form and reads the result back on the spot
+    uint32_t vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+
+    for (;;) {
+        // ================= boundary: USES (everything read here was loaded at least one pass ago) =================
+        const bool flush = active && i0 + l < n;
+        uint16_t *const flush_to = sc.bigcand + at + i0 + l;
+        if (active) {
+            i0 += (uint32_t)RL;
+            if (i0 >= n) active = false;
+            else { cur_a = r_np | (r_ni << 16); cur_b = r_nr; }
+        }
+        bool take = false, want_cursor = false;
+        uint32_t done_ci = 0, done_n = 0;
+        if (!active && pf_stage == 3u) {
+            take = true;
+            n = pf_count; at = pf_at;
+            cur_a = r_fp | (r_fi << 16); cur_b = r_fr; i0 = 0; ev = 0; active = true; pf_stage = 0;
+            bmw[l] = 0;
+            done_ci = pf_ci; done_n = n;
+        }
+        if (pf_stage == 1u) {
+            pf_ci = ROW_BPERM(rb, tk);                                      // lane 0 of the row asked the cursor
+            if (pf_ci >= count) { exhausted = true; pf_stage = 0; } else pf_stage = 2;
+        } else if (pf_stage == 2u) {
+            // the cluster that covers bucket 0 / T (and anything that does not fit): not ours, another one
+            if (r_d4.w != ~0u || r_d1 != ~0u || r_d4.z > (uint32_t)CAPE || r_d4.z < 2u * RL) pf_stage = 0;
+            else { pf_count = r_d4.z; pf_at = (size_t)r_d4.x * LZ2_BIG_STRIDE + r_d4.y; pf_stage = 3; }
+        }
+        if (pf_stage == 0u && !exhausted) { want_cursor = true; pf_stage = 1; }
+        // ================= boundary: ISSUES (all unconditional loads; nothing below waits for them) =================
+        {
+            const uint32_t k = i0 + (uint32_t)RL + l;
+            const size_t na = (active && k < n) ? at + k : 0;
+            r_np = sc.bigpos[na]; r_ni = sc.bigpid[na]; r_nr = sc.bigrs[na];
+            const size_t fa = (pf_stage == 3u) ? pf_at + l : 0;              // (>= 2 RL entries: the first RL exist)
+            r_fp = sc.bigpos[fa]; r_fi = sc.bigpid[fa]; r_fr = sc.bigrs[fa];
+            const uint32_t *dp = reinterpret_cast<const uint32_t *>(pf_stage == 2u ? desc_of(pf_ci) : descs_a);
+            r_d4 = *reinterpret_cast<const uint4 *>(dp); r_d1 = dp[4];
+        }
+        if (flush) *flush_to = (uint16_t)out_acc;
+        if (take && l == 0) desc_of(done_ci)->count = done_n | LZ2_DOM_DONE;     // k_lz2_big skips it
+        if (want_cursor && l == 0) tk = atomicAdd(cursor + vzero, 1u);
+        if (__ballot(active || pf_stage != 0u) == 0ull) break;
+        if (__ballot(active) == 0ull) continue;
+        // ================= RL steps: LDS, cross-lane and vector work only =================
+        // Software-pipelined: an entry's broadcast, the live entries a step may retire and the bitmap dwords the first fit needs
+        // are asked for as early as their addresses are known, and every loaded value is used unconditionally (a load whose
+        // only use sits under an `if` is sunk into that block together with the wait for it).
+        uint32_t a = ROW_BPERM(rb, cur_a), r = ROW_BPERM(rb, cur_b);
+        uint32_t e = ent[(active && ev + l < i0) ? ev + l : 0u];
+        for (uint32_t t = 0; t < (uint32_t)RL; ++t) {
+            const uint32_t i = i0 + t;
+            const bool on = active && i < n;
+            const uint32_t p = a & 0xFFFFu, id = a >> 16;
+            for (;;) {                                                      // FIFO retirement (lz77.c:70-76): normally one pass
+                const bool ret = on && ev + l < i && (e >> 16) + W < p;
+                const uint64_t mk = __ballot(ret);
+                if (ret) atomicAnd(&bmw[(e & 0xFFFFu) >> 5], ~(1u << (e & 31u)));       // clears the bucket
+                const uint32_t cnt = (uint32_t)__popc((uint32_t)(mk >> rb) & RMASK);
+                ev += cnt;
+                if (__ballot(cnt == (uint32_t)RL) == 0ull) break;           // a row whose every lane retired one may have more
+                e = ent[(on && ev + l < i) ? ev + l : 0u];
+            }
+            // (behind the clears, in the LDS queue's order) the home's dword and occupant, this lane's bitmap dwords
+            const uint32_t wr = bmw[r >> 5], h = occ[r], v = bmw[l];
+            const uint32_t tn = (t + 1u) & (uint32_t)(RL - 1);
+            const uint32_t na = ROW_BPERM(rb + tn, cur_a), nr = ROW_BPERM(rb + tn, cur_b);
+            const bool bit = (wr >> (r & 31u)) & 1u, same = (h & 0xFFFFu) == id;
+            const bool seek = on && id != p;                                // (the first occurrence of a word in the block finds nothing, ever)
+            // nothing evicted yet: the word's first occurrence = the word id; else the occupant of the home, if it is a copy
+            uint32_t res = (seek && ev == 0u) ? id : (seek && bit && same) ? (h >> 16) : (uint32_t)LZ_NONE16;
+            bool walk = seek && ev != 0u && bit && !same;
+            if (__ballot(walk) != 0ull) {
+                // the home holds another word: on to the first copy of this word or the first empty bucket, RL occupants per step
+                uint32_t e_end = row_first_zero<RL>(v, r + 1u, l, rb);   // (a walk changes no bit)
+                if (e_end > (uint32_t)CAPE) e_end = (uint32_t)CAPE;
+                uint32_t b0 = r + 1u;
+                while (__ballot(walk && b0 < e_end) != 0ull) {
+                    const uint32_t bb = b0 + l;
+                    const bool in = walk && bb < e_end;
+                    const uint32_t o = occ[in ? bb : 0u];
+                    const uint64_t mk = __ballot(in && (o & 0xFFFFu) == id);
+                    const uint32_t my = (uint32_t)(mk >> rb) & RMASK;
+                    const uint32_t src = ROW_BPERM(rb + (my ? (uint32_t)__builtin_ctz(my) : 0u), o);
+                    if (walk && my) { res = src >> 16; walk = false; }
+                    b0 += (uint32_t)RL;
+                }
+            }
+            // insert: first fit from the home on (inside the cluster by the parking bound)
+            const uint32_t b = row_first_zero<RL>(v, r, l, rb);
+            const bool put = on && b < (uint32_t)CAPE;
+            if (put && l == 0) atomicOr(&bmw[b >> 5], 1u << (b & 31u));
+            if (put) { occ[b] = id | (p << 16); ent[i] = b | (p << 16); }
+            if (on && l == t) out_acc = res;
+            e = ent[(active && i + 1u < n && ev + l < i + 1u) ? ev + l : 0u];     // (behind this step's own record)
+            a = na; r = nr;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// =============================================================================================
 // lane-per-cluster replay of exported clusters of one size class [16,32) / [32,64) / [64,128):
 // 64 clusters per wave, every lane owns a private LDS region (slot -> word id, slot -> position,
 // entry -> slot, occupancy bits).  All lanes of a wave step through clusters of similar size.
@@ -950,6 +1119,7 @@ template __global__ void k_lz2_big<LZ2_BIG_SMALL, 1>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_big<512, 1>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_big<256, 1>(LzP, Lz2Scratch, int);
 template __global__ void k_lz2_big<LZ2_CAP, 4>(LzP, Lz2Scratch, int);
+template __global__ void k_lz2_rows<16>(LzP, Lz2Scratch, int, int, int);
 
 
 // =============================================================================================
@@ -987,7 +1157,8 @@ void lz2_carve(mi_carver &cv, uint32_t nb, Lz2Scratch *sc)
     sc->work = cv.take<uint64_t>((size_t)nb * LZ2_MAXPARTS);
     sc->work_slots = nb * LZ2_MAXPARTS;
     sc->dbg = getenv("MI_LZ_DEBUG") ? cv.take<uint64_t>(64) : nullptr;
-    sc->wave_min = LZ2_WAVE;
+    // bits 16..: the row replay's switch (MI_LZ_ROWS, lz2_stage_b): with it the wave classes are three (128..255 apart)
+    { const char *e = getenv("MI_LZ_ROWS"); const uint32_t rows = e ? (uint32_t)atoi(e) : 1u; sc->wave_min = LZ2_WAVE | ((rows ? 1u : 0u) << 16); }
 #ifdef MI_MEASURE
     sc->stop_phase = getenv("MI_LZ_STOP_PHASE") ? (uint32_t)atoi(getenv("MI_LZ_STOP_PHASE")) : 0u;
 #else
@@ -1094,7 +1265,19 @@ mi_status lz2_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &
       // the 512..1024-entry class first and alone (6 KiB of LDS per wave), then the 128..511 class on 3 KiB: twice as many of its
       // waves fit into what the LDS-filling kernels of the other stages leave on a CU (MI_LZ_BIG_SPLIT=0: one launch, A/B)
       static const bool split = !(getenv("MI_LZ_BIG_SPLIT") && getenv("MI_LZ_BIG_SPLIT")[0] == '0');
-      if (split && sc.wave_min == LZ2_WAVE) {
+      // row replay first (four clusters per wave, off a cursor): MI_LZ_ROWS=0 none, 1 = the 128..511 class (default), 2 = both classes;
+      // k_lz2_big below takes what it leaves (the cluster that covers bucket 0 / T) — its grids then stride over the descriptors
+      // row replay (four clusters per wave, off a cursor) of the 128..511-entry clusters, the 256..511 ones first (MI_LZ_ROWS=0: the
+      // wave replay for everything, A/B); k_lz2_big then takes what the rows leave (the cluster that covers bucket 0 / T) with
+      // small grids that stride over the descriptors
+      const uint32_t rows = sc.wave_min >> 16;
+      static const uint32_t rows_waves = lz2_env_u32("MI_LZ_ROWS_WAVES", 9);
+      if (rows >= 1 && split && (sc.wave_min & 0xFFFFu) == LZ2_WAVE) {
+          hipLaunchKernelGGL((k_lz2_big<LZ2_BIG_SMALL, 1>), dim3(grid_of((uint64_t)nb * lz2_class_cap(4))), dim3(64), 0, s, P, sc, 3);
+          hipLaunchKernelGGL((k_lz2_rows<16>), dim3(ncu * rows_waves), dim3(64), 0, s, P, sc, 5, 3, 9);
+          hipLaunchKernelGGL((k_lz2_big<512, 1>), dim3(ncu * 4u), dim3(64), 0, s, P, sc, 2);
+          hipLaunchKernelGGL((k_lz2_big<256, 1>), dim3(ncu * 4u), dim3(64), 0, s, P, sc, 4);
+      } else if (split && (sc.wave_min & 0xFFFFu) == LZ2_WAVE) {
           hipLaunchKernelGGL((k_lz2_big<LZ2_BIG_SMALL, 1>), dim3(grid_of((uint64_t)nb * lz2_class_cap(4))), dim3(64), 0, s, P, sc, 3);
           hipLaunchKernelGGL((k_lz2_big<512, 1>), dim3(grid_of((uint64_t)nb * lz2_class_cap(5))), dim3(64), 0, s, P, sc, 2);
       } else {
