@@ -738,12 +738,11 @@ void k_lz2_big(LzP P, Lz2Scratch sc, int large)
     const uint32_t lane = threadIdx.x;
     // a launch lasts as long as its longest cluster: the 512..1024-entry class is dispatched before the 128..511 one
     // large: 0 = classes 4 (512..1024 entries) and 5 (128..511) in one launch, 1 = class 6, 2 = class 5 alone, 3 = class 4 alone
-    // 5 = classes 5 (256..511 entries) and 3 (128..255) in one launch, the longer ones first
-    const uint32_t nhi = large == 1 ? sc.big_count[6] : (large == 2 || large == 4) ? 0u : large == 5 ? sc.big_count[5] : sc.big_count[4],
-                   ncl = nhi + ((large == 0 || large == 2) ? sc.big_count[5] : (large == 4 || large == 5) ? sc.big_count[3] : 0u);
+    const uint32_t nhi = large == 1 ? sc.big_count[6] : (large == 2 || large == 4) ? 0u : sc.big_count[4],
+                   ncl = nhi + ((large == 0 || large == 2) ? sc.big_count[5] : large == 4 ? sc.big_count[3] : 0u);
     const uint32_t W = 1u << P.wbits;
     for (uint32_t ci = blockIdx.x; ci < ncl; ci += gridDim.x) {
-        const Lz2BigDesc *dp = large == 1 ? &sc.desc[6][ci] : large == 4 ? &sc.desc[3][ci] : large == 5 ? (ci < nhi ? &sc.desc[5][ci] : &sc.desc[3][ci - nhi]) : (ci < nhi ? &sc.desc[4][ci] : &sc.desc[5][ci - nhi]);
+        const Lz2BigDesc *dp = large == 1 ? &sc.desc[6][ci] : large == 4 ? &sc.desc[3][ci] : (ci < nhi ? &sc.desc[4][ci] : &sc.desc[5][ci - nhi]);
         const uint32_t d_block = dp->block, d_start = dp->start, n = dp->count;
         if (n & 0x80000000u) continue;                       // k_lz2_dom has replayed it (class 6 only: counts are <= LZ2_CAP otherwise)
         const uint32_t d_anom = dp->anom, d_limit = dp->limit;
@@ -1273,11 +1272,7 @@ mi_status lz2_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &
       // small grids that stride over the descriptors
       const uint32_t rows = sc.wave_min >> 16;
       static const uint32_t rows_waves = lz2_env_u32("MI_LZ_ROWS_WAVES", 9);
-      static const bool rows_wave = getenv("MI_LZ_ROWS") && atoi(getenv("MI_LZ_ROWS")) == 3;     // A/B: the three classes, long first, on the WAVE replay
-      if (rows_wave && split) {
-          hipLaunchKernelGGL((k_lz2_big<LZ2_BIG_SMALL, 1>), dim3(grid_of((uint64_t)nb * lz2_class_cap(4))), dim3(64), 0, s, P, sc, 3);
-          hipLaunchKernelGGL((k_lz2_big<512, 1>), dim3(grid_of((uint64_t)nb * (lz2_class_cap(5) + lz2_class_cap(3)))), dim3(64), 0, s, P, sc, 5);
-      } else if (rows >= 1 && split && (sc.wave_min & 0xFFFFu) == LZ2_WAVE) {
+      if (rows >= 1 && split && (sc.wave_min & 0xFFFFu) == LZ2_WAVE) {
           hipLaunchKernelGGL((k_lz2_big<LZ2_BIG_SMALL, 1>), dim3(grid_of((uint64_t)nb * lz2_class_cap(4))), dim3(64), 0, s, P, sc, 3);
           hipLaunchKernelGGL((k_lz2_rows<16>), dim3(ncu * rows_waves), dim3(64), 0, s, P, sc, 5, 3, 9);
           hipLaunchKernelGGL((k_lz2_big<512, 1>), dim3(ncu * 4u), dim3(64), 0, s, P, sc, 2);
