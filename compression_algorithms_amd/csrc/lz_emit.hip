@@ -523,7 +523,7 @@ mi_status lz_run_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n
 mi_status lz_check_params(const mi_lz_params *p);
 mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
                         const LzScratch &sc, hipStream_t s);
-uint32_t lz_batch_blocks(uint64_t nblocks);
+uint32_t lz_batch_blocks(mi_ctx *ctx, uint64_t nblocks);
 
 void defh_launch_encode(const uint32_t *trec, uint32_t *slots, uint64_t *block_bits, uint32_t nb, hipStream_t s);
 
@@ -582,7 +582,7 @@ static mi_status lz_encode_impl(mi_ctx *ctx, const mi_lz_params *p, const uint8_
         MI_HIP(ctx, hipGetLastError());
         return MI_OK;
     }
-    const uint32_t nbmax = lz_batch_blocks(nblocks);
+    const uint32_t nbmax = lz_batch_blocks(ctx, nblocks);
     // three stages on three streams, MI_SETS scratch sets in rotation:
     //   `s`          partition + find of batch i+2          (LDS heavy: one / three workgroups per CU)
     //   ctx->side    replay of the exported clusters of i+1 (almost no LDS: runs beside the find)

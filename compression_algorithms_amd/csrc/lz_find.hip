@@ -918,12 +918,23 @@ mi_status lz_find_batch(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t
     return MI_OK;
 }
 
-uint32_t lz_batch_blocks(uint64_t nblocks)
+uint32_t lz_batch_blocks(mi_ctx *ctx, uint64_t nblocks)
 {
-    // measured in round 1: 256 -> 9.2, 512 -> 9.9, 1024 -> 10.3 GB/s (the replay kernels' tails amortise).  End of round 2, 10^9 B
-    // (15 259 blocks), same box: 1024 / 1536 / 2048 / 3072 / 4096 blocks per batch 17.71 / 17.83 / 17.96 / 18.14 / 18.01 GB/s —
-    // larger batches as long as three stages still have three batches to overlap (288 GB of HBM: ~5 GB per set at 3072)
-    uint64_t cap = nblocks >= 3u * 3072u ? 3072u : nblocks >= 3u * 2048u ? 2048u : 1024u;
+    // As few, as large and as EQUAL batches as fit 3840 blocks (round 4).  The three-stream overlap buys 8 % over running every kernel
+    // alone, while every batch pays every kernel's tail: 10^8 B (1 526 blocks) in one batch 17.9 GB/s against 16.5 in two (1 024 + 502),
+    // 125 MB 18.4 / 17.6, 2 x 10^8 B 19.9 / 18.6, 3 x 10^8 B 20.5 (2 x 2 289) / 18.8 (1 024 x 4 + 482), 5 x 10^8 B 21.5 (2 x 3 815) / 20.8
+    // (2 048 x 3 + 1 486), 10^9 B 21.8-21.9 (4 x 3 815) / 21.7 (3 072 x 4 + 2 971) — same box, mode H.  (Until then: 1 024 below 6 144
+    // blocks, 2 048 below 9 216, else 3 072 — "as long as three stages have three batches to overlap".)  ~1.6 GB of workspace per 1 024
+    // blocks and set, three sets: 288 GB of HBM make that free; k_lz_scan_blocks holds a batch to 4 096 blocks.
+    const uint64_t nbat = (nblocks + 3839u) / 3840u;
+    uint64_t cap = nbat ? (nblocks + nbat - 1u) / nbat : 1u;
+    // ... unless the input lives in the fallback pipeline (the hint an earlier call left, lz_emit.hip: at least a sixteenth of a batch's
+    // blocks): its chains are long serial kernels on few workgroups, and what helps THEM is two batches' chains side by side on two
+    // streams — "runs" 4.7 GB/s in two batches against 3.8 in one, "pages" 3.5 / 3.4 (10^8 B): the old rule stays for such input
+    if (ctx && ctx->h_order) {
+        const uint32_t fb = __atomic_load_n(ctx->h_order + 1, __ATOMIC_RELAXED), of = __atomic_load_n(ctx->h_order + 2, __ATOMIC_RELAXED);
+        if (fb > 8u && (uint64_t)fb * 16u >= of) cap = nblocks >= 3u * 3072u ? 3072u : nblocks >= 3u * 2048u ? 2048u : 1024u;
+    }
     if (const char *e = getenv("MI_LZ_BATCH")) { long v = atol(e); if (v >= 1 && v <= 4096) cap = (uint64_t)v; }
     return (uint32_t)(nblocks < cap ? (nblocks ? nblocks : 1) : cap);
 }
@@ -938,7 +949,7 @@ extern "C" mi_status mi_lz_find_all_dev(mi_ctx *ctx, const mi_lz_params *p, cons
     hipStream_t s = (hipStream_t)stream;
     const LzP P = lz_params_of(ctx, p);
     const uint64_t nblocks = (n + P.block - 1) / P.block;
-    const uint32_t nbmax = lz_batch_blocks(nblocks);
+    const uint32_t nbmax = lz_batch_blocks(ctx, nblocks);
     st = mi_ws_reserve(ctx, lz_scratch_bytes(nbmax));
     if (st) return st;
     LzScratch sc; Lz2Scratch sc2;
