@@ -1265,8 +1265,6 @@ mi_status lz2_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &
       // the 512..1024-entry class first and alone (6 KiB of LDS per wave), then the 128..511 class on 3 KiB: twice as many of its
       // waves fit into what the LDS-filling kernels of the other stages leave on a CU (MI_LZ_BIG_SPLIT=0: one launch, A/B)
       static const bool split = !(getenv("MI_LZ_BIG_SPLIT") && getenv("MI_LZ_BIG_SPLIT")[0] == '0');
-      // row replay first (four clusters per wave, off a cursor): MI_LZ_ROWS=0 none, 1 = the 128..511 class (default), 2 = both classes;
-      // k_lz2_big below takes what it leaves (the cluster that covers bucket 0 / T) — its grids then stride over the descriptors
       // row replay (four clusters per wave, off a cursor) of the 128..511-entry clusters, the 256..511 ones first (MI_LZ_ROWS=0: the
       // wave replay for everything, A/B); k_lz2_big then takes what the rows leave (the cluster that covers bucket 0 / T) with
       // small grids that stride over the descriptors
@@ -1282,6 +1280,8 @@ mi_status lz2_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &
           hipLaunchKernelGGL((k_lz2_big<512, 1>), dim3(grid_of((uint64_t)nb * lz2_class_cap(5))), dim3(64), 0, s, P, sc, 2);
       } else {
           hipLaunchKernelGGL((k_lz2_big<LZ2_BIG_SMALL, 1>), dim3(grid_of((uint64_t)nb * (lz2_class_cap(4) + lz2_class_cap(5)))), dim3(64), 0, s, P, sc, 0);
+          // (with the row replay's three classes but MI_LZ_BIG_SPLIT=0: the 128..255 class has its own list)
+          if (rows) hipLaunchKernelGGL((k_lz2_big<256, 1>), dim3(grid_of((uint64_t)nb * lz2_class_cap(3))), dim3(64), 0, s, P, sc, 4);
       } }
     { mi_prof_scope p(ctx, "k_lz2_dom", s, (uint64_t)nb * P.block);
       // clusters above 1024 entries that one word dominates (none in text: an empty launch of 13 KiB workgroups); what it leaves
