@@ -1239,7 +1239,8 @@ mi_status lz2_stage_find_wide(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, ui
 }
 
 // stage B: replay of the exported clusters (almost no LDS: runs beside the next batch's stage A)
-mi_status lz2_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &sc, hipStream_t s)
+// which: 1 = the lane replays of 8..31-entry clusters, 4 = of 32..127-entry clusters, 2 = the wave / row replays; 7 = all on `s`
+mi_status lz2_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &sc, hipStream_t s, int which)
 {
     // Replay grids cover the worst case and the kernels stride, so any grid is correct.  MI_LZ_REPLAY_WAVES=k caps them at
     // k workgroups per CU (0 / unset = worst case).  Measured (round 2, same box): persistent grids sized by LDS (16 / 12 /
@@ -1251,15 +1252,20 @@ mi_status lz2_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &
         const uint64_t g = (uint64_t)ncu * lz2_env_u32("MI_LZ_REPLAY_WAVES", 0);             // 0 = the worst-case grid
         return (uint32_t)((g == 0 || worst < g) ? (worst ? worst : 1) : g);
     };
+    if (which & 1) {
     { mi_prof_scope p(ctx, "k_lz2_mid<16>", s, (uint64_t)nb * P.block);
       hipLaunchKernelGGL((k_lz2_mid_direct<16, 64>), dim3(grid_of((uint64_t)nb * lz2_class_cap(7) / 64 + 1)), dim3(64), 0, s, P, sc, 7); }
     { mi_prof_scope p(ctx, "k_lz2_mid<32>", s, (uint64_t)nb * P.block);
       hipLaunchKernelGGL((k_lz2_mid_direct<32, 64>), dim3(grid_of((uint64_t)nb * lz2_class_cap(0) / 64 + 1)), dim3(64), 0, s, P, sc, 0); }
+    }
+    if (which & 4) {
     { mi_prof_scope p(ctx, "k_lz2_mid<64>", s, (uint64_t)nb * P.block);
       hipLaunchKernelGGL((k_lz2_mid_direct<64, 64>), dim3(grid_of((uint64_t)nb * lz2_class_cap(1) / 64 + 1)), dim3(64), 0, s, P, sc, 1); }
     { mi_prof_scope p(ctx, "k_lz2_mid<128>", s, (uint64_t)nb * P.block);
       // 48 clusters per wave: 31 KiB of LDS instead of 42, five waves per CU instead of three (240 replaying lanes, not 192)
       hipLaunchKernelGGL((k_lz2_mid_direct<128, 48>), dim3(grid_of((uint64_t)nb * lz2_class_cap(2) / 48 + 1)), dim3(64), 0, s, P, sc, 2); }
+    }
+    if (which & 2) {
     { mi_prof_scope p(ctx, "k_lz2_big", s, (uint64_t)nb * P.block);
       // the kernel strides over the two wave classes (long chains first); 6 KiB per wave
       // the 512..1024-entry class first and alone (6 KiB of LDS per wave), then the 128..511 class on 3 KiB: twice as many of its
@@ -1290,6 +1296,7 @@ mi_status lz2_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &
       hipLaunchKernelGGL(k_lz2_dom, dim3((unsigned)(worst < (uint64_t)ncu * 4u ? worst : (uint64_t)ncu * 4u)), dim3(256), 0, s, P, sc); }
     { mi_prof_scope p(ctx, "k_lz2_big<4096>", s, (uint64_t)nb * P.block);
       hipLaunchKernelGGL((k_lz2_big<LZ2_CAP, 4>), dim3(grid_of((uint64_t)nb * lz2_class_cap(6) < 4096 ? (uint64_t)nb * lz2_class_cap(6) : 4096)), dim3(64), 0, s, P, sc, 1); }   // 24 KiB each, normally none: a small striding grid
+    }
     MI_HIP(ctx, hipGetLastError());
     return MI_OK;
 }

@@ -516,7 +516,7 @@ void     lz_carve(mi_ctx *ctx, uint32_t nb, LzScratch *sc, Lz2Scratch *sc2, int 
 mi_status lz_find_stage_a(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
                           const LzScratch &sc, const Lz2Scratch &sc2, hipStream_t s, hipStream_t sf, hipEvent_t ev_part, hipEvent_t ev_fb,
                           hipEvent_t ev_wide);
-mi_status lz_find_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &sc2, hipStream_t s);
+mi_status lz_find_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &sc2, hipStream_t s, int which);
 bool     lz_use_v2();
 mi_status lz_run_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
                       const LzScratch &sc, const Lz2Scratch &sc2, hipStream_t s);
@@ -679,8 +679,10 @@ static mi_status lz_encode_impl(mi_ctx *ctx, const mi_lz_params *p, const uint8_
         nb_next = nb;
         const int k = (int)(batch % (uint64_t)nsets);
         if (overlap && batch >= (uint64_t)nsets) MI_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_done[k], 0));   // set k is free again
+        static const bool b_split = !(getenv("MI_LZ_B_SPLIT") && getenv("MI_LZ_B_SPLIT")[0] == '0');
+        const bool solo = !overlap && b_split && lz_use_v2() && !skip;
         st = lz_find_stage_a(ctx, P, d_in, n, b0, nb, sc[k], sc2[k], s,
-                             overlap ? ((batch & 1u) && fb_busy && (ctx->fb2 || fb2_side) ? (fb2_side ? sb : ctx->fb2) : ctx->fb) : s, ctx->ev_part[k], ctx->ev_fb[k], ctx->ev_wide[k]);
+                             overlap ? ((batch & 1u) && fb_busy && (ctx->fb2 || fb2_side) ? (fb2_side ? sb : ctx->fb2) : ctx->fb) : (solo ? ctx->fb : s), ctx->ev_part[k], ctx->ev_fb[k], ctx->ev_wide[k]);
         if (st) return st;
         if (hold_parse && prev_k >= 0) {
             MI_HIP(ctx, hipStreamWaitEvent(sp, ctx->ev_part[k], 0));
@@ -691,7 +693,24 @@ static mi_status lz_encode_impl(mi_ctx *ctx, const mi_lz_params *p, const uint8_
             MI_HIP(ctx, hipEventRecord(ctx->ev_find[k], s)); MI_HIP(ctx, hipStreamWaitEvent(sb, ctx->ev_find[k], 0));
             if (lz_use_v2() && !getenv("MI_LZ_WIDE_INLINE")) MI_HIP(ctx, hipStreamWaitEvent(sb, ctx->ev_wide[k], 0));    // the wide parts' exports (lz_find.hip)
         }
-        if (!(skip & 1)) st = lz_find_stage_b(ctx, P, nb, sc2[k], sb);
+        // ONE batch (no pipeline: the side, parse and fallback streams are idle): the lane replays run BESIDE the wave / row replays, the
+        // long size classes on the side stream, the short ones on the parse stream — the groups are independent, each is a chain of
+        // launches with tails, and what follows needs all of them; the (normally empty) fallback chain and the wide finder leave the
+        // partition -> find chain for the fallback stream as in the pipeline (MI_LZ_B_SPLIT=0: one chain on one stream, A/B)
+        if (solo && !(skip & 1)) {
+            if (!getenv("MI_LZ_WIDE_INLINE")) MI_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_wide[0], 0));        // the wide parts' exports
+            MI_HIP(ctx, hipEventRecord(ctx->ev_find[0], s));
+            MI_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_find[0], 0)); MI_HIP(ctx, hipStreamWaitEvent(ctx->parse, ctx->ev_find[0], 0));
+            st = lz_find_stage_b(ctx, P, nb, sc2[k], ctx->side, 4);
+            if (st) return st;
+            MI_HIP(ctx, hipEventRecord(ctx->ev_replay[0], ctx->side));
+            st = lz_find_stage_b(ctx, P, nb, sc2[k], ctx->parse, 1);
+            if (st) return st;
+            MI_HIP(ctx, hipEventRecord(ctx->ev_done[0], ctx->parse));
+            st = lz_find_stage_b(ctx, P, nb, sc2[k], s, 2);
+            MI_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_replay[0], 0)); MI_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_done[0], 0));
+            MI_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_fb[0], 0));                                           // the fallback blocks' candidates
+        } else if (!(skip & 1)) st = lz_find_stage_b(ctx, P, nb, sc2[k], sb, 7);
         if (st) return st;
         if (overlap) {
             MI_HIP(ctx, hipEventRecord(ctx->ev_replay[k], sb));

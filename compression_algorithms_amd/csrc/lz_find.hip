@@ -784,7 +784,7 @@ mi_status lz2_stage_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_
                          const Lz2Scratch &sc, hipStream_t s);
 mi_status lz2_stage_find_wide(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
                               const Lz2Scratch &sc, hipStream_t s, bool aside);
-mi_status lz2_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &sc, hipStream_t s);
+mi_status lz2_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &sc, hipStream_t s, int which);
 void   lz2_launch_scatter(const Lz2Scratch &sc, uint16_t *cand_by_pos, uint32_t nb, hipStream_t s);
 
 bool lz_use_v2()
@@ -844,15 +844,15 @@ mi_status lz_find_stage_a(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64
     if (st || wide_aside) return st;
     return lz2_stage_find_wide(ctx, P, d_in, n, block0, nb, sc2, s, false);
 }
-mi_status lz_find_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &sc2, hipStream_t s)
+mi_status lz_find_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &sc2, hipStream_t s, int which)
 {
-    return lz_use_v2() ? lz2_stage_b(ctx, P, nb, sc2, s) : MI_OK;
+    return lz_use_v2() ? lz2_stage_b(ctx, P, nb, sc2, s, which) : MI_OK;
 }
 mi_status lz_run_find(mi_ctx *ctx, const LzP &P, const uint8_t *d_in, uint64_t n, uint64_t block0, uint32_t nb,
                       const LzScratch &sc, const Lz2Scratch &sc2, hipStream_t s)
 {
     mi_status st = lz_find_stage_a(ctx, P, d_in, n, block0, nb, sc, sc2, s, s, nullptr, nullptr, nullptr);
-    return st ? st : lz_find_stage_b(ctx, P, nb, sc2, s);
+    return st ? st : lz_find_stage_b(ctx, P, nb, sc2, s, 7);
 }
 mi_status lz_check_params(const mi_lz_params *p)
 {
