@@ -13,8 +13,9 @@
 //                       - larger mixed ones are exported on 16-byte boundaries, by size class.
 //   k_lz2_mid_direct  lane per exported cluster of 8..127 entries (64 clusters per wave, LDS regions per lane),
 //                     eight entries per load.
-//   k_lz2_big         one WAVE per exported cluster of >= 128 entries: occupancy bitmap in registers, first fit by
-//                     ballot + v_readlane, 6 bytes of LDS per entry; bound by scalar-instruction issue.
+//   k_lz2_big         one WAVE per exported cluster of 512..1024 entries (and of what the row replay leaves): occupancy bitmap in
+//                     registers, first fit by ballot + v_readlane, 6 bytes of LDS per entry; bound by scalar-instruction issue.
+//   k_lz2_rows        FOUR exported clusters of 128..511 entries per wave, one per 16-lane row, 256..511 first (round 4).
 //   k_lz2_scatter     lists -> by-position array (test hook and fallback boundary).
 //
 // Replaces the same reference functions as lz_find.hip (hash / insert_hash_table / find,
@@ -1267,9 +1268,9 @@ mi_status lz2_stage_b(mi_ctx *ctx, const LzP &P, uint32_t nb, const Lz2Scratch &
     }
     if (which & 2) {
     { mi_prof_scope p(ctx, "k_lz2_big", s, (uint64_t)nb * P.block);
-      // the kernel strides over the two wave classes (long chains first); 6 KiB per wave
-      // the 512..1024-entry class first and alone (6 KiB of LDS per wave), then the 128..511 class on 3 KiB: twice as many of its
-      // waves fit into what the LDS-filling kernels of the other stages leave on a CU (MI_LZ_BIG_SPLIT=0: one launch, A/B)
+      // the 512..1024-entry class first and alone on the wave replay (6 KiB of LDS per wave), then the 128..511-entry clusters: on the
+      // row replay (below), or — MI_LZ_ROWS=0 — on the wave replay with 3 KiB per wave (MI_LZ_BIG_SPLIT=0: one launch for both wave
+      // classes, A/B)
       static const bool split = !(getenv("MI_LZ_BIG_SPLIT") && getenv("MI_LZ_BIG_SPLIT")[0] == '0');
       // row replay (four clusters per wave, off a cursor) of the 128..511-entry clusters, the 256..511 ones first (MI_LZ_ROWS=0: the
       // wave replay for everything, A/B); k_lz2_big then takes what the rows leave (the cluster that covers bucket 0 / T) with
